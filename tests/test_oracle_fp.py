@@ -1,0 +1,114 @@
+"""CPU: the fp oracle -- two independent restatements must agree, the reference's formula tests hold,
+and the committed goldens are reproducible.  (Not reference-captured: parity unpinned, oracle/__init__.py.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import make_golden as G
+from oracle import qnet_ref as Q
+from oracle import torch_ref as T
+
+CASES = [("cnn", (20, 20, 4), [32, 32, 32, 128], 5, 2, 8), ("fc", 8, [50, 40], 4, 3, 16),
+         ("cnn", (84, 84, 4), [32, 64, 64, 512], 6, 1, 3)]
+
+
+def _setup(arch, obs, feats, A, K, B, seed=0):
+    p = Q.init_params(seed, arch, obs, A, feats, K, np.float64)
+    pt = Q.init_params(seed + 1, arch, obs, A, feats, K, np.float64)
+    rng = np.random.default_rng(seed + 2)
+    for n in p:
+        if n.endswith("bias"):
+            p[n] = p[n] + 0.05 * rng.standard_normal(p[n].shape)
+    batch = list(Q.synthetic_batch(seed + 3, B, obs, A, arch))
+    batch[4][0] = True
+    return p, pt, tuple(batch)
+
+
+@pytest.mark.parametrize("arch,obs,feats,A,K,B", CASES)
+def test_numpy_and_autograd_restatements_agree(arch, obs, feats, A, K, B):
+    p, pt, batch = _setup(arch, obs, feats, A, K, B)
+    for k in range(K):
+        l1, g1, _ = Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), batch, arch, 0.99)
+        l2, g2 = T.loss_and_grads(Q.head(p, k), Q.head(pt, k), batch, arch, 0.99)
+        assert abs(l1 - l2) <= 1e-12 * max(1.0, abs(l2))
+        for n in g1:
+            assert np.abs(g1[n] - g2[n]).max() <= 1e-9 * (np.abs(g2[n]).max() + 1e-30), n
+
+
+def test_same_padding_geometry():
+    # architectures/dqn.py:43-51 with flax's default padding="SAME": 84 -> 21 -> 11 -> 11, flatten 7744
+    assert Q.same_pad(84, 8, 4) == (21, 2, 2)
+    assert Q.same_pad(21, 4, 2) == (11, 1, 2)
+    assert Q.same_pad(11, 3, 1) == (11, 1, 1)
+    shapes = dict(Q.leaf_shapes("cnn", (84, 84, 4), 6, [32, 64, 64, 512]))
+    assert shapes["Dense_0/kernel"] == (7744, 512)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 4046502  # params per head
+
+
+def test_compute_target_and_loss_formulae():
+    """tests/test_idqn.py:44-71 / tests/test_dqn.py:39-59 restated: target = r + (1-term) * gamma * max Q(s'),
+    loss = (target - Q(s)[a])^2, for a single sample, with the same parameters online and target."""
+    arch, obs, feats, A, K, B = CASES[0]
+    p, _, batch = _setup(arch, obs, feats, A, K, 1, seed=5)
+    for term in (False, True):
+        s, a, r, s2, _ = batch
+        b1 = (s, a, r, s2, np.array([term]))
+        hp = Q.head(p, 1)
+        loss, _, aux = Q.loss_and_grads(hp, hp, b1, arch, 0.94)
+        q_next = Q.forward(hp, s2, arch)
+        assert q_next.shape == (1, A)
+        target = r[0] + (1 - int(term)) * 0.94 * q_next.max()
+        assert aux["target"][0] == pytest.approx(target, rel=1e-14)
+        pred = Q.forward(hp, s, arch)[0, a[0]]
+        assert loss == pytest.approx((target - pred) ** 2, rel=1e-12)
+
+
+def test_adam_first_step_is_sign_like_and_count_advances():
+    theta, g = np.array([1.0, -2.0, 0.5]), np.array([0.3, -0.2, 0.0])
+    new, m, v = Q.adam_update(theta, g, np.zeros(3), np.zeros(3), 0, lr=1e-3, eps=1e-8)
+    np.testing.assert_allclose(m, 0.1 * g)
+    np.testing.assert_allclose(v, 0.001 * g * g)
+    np.testing.assert_allclose(new, theta - 1e-3 * np.sign(g), atol=1e-9)
+
+
+def test_shift_and_sync_semantics():
+    # idqn.py:13-24: shift: params[k] <- params[k+1]; sync: target[k] <- params[k-1] for k >= 1
+    p = {"w": np.arange(4.0)[:, None] * np.ones((4, 3))}
+    t = {"w": -np.ones((4, 3))}
+    np.testing.assert_array_equal(Q.shift_params(p)["w"][:, 0], [1, 2, 3, 3])
+    np.testing.assert_array_equal(Q.sync_target_params(p, t)["w"][:, 0], [-1, 0, 1, 2])
+
+
+@pytest.mark.parametrize("name", ["cnn_small", "fc_lunar_k3"])
+def test_goldens_are_reproducible(name):
+    """The committed fp goldens are exactly what oracle/make_golden.py --fp computes."""
+    arch, obs, A, feats, K, B, steps = G.FP_CASES[name]
+    rec = json.load(open(os.path.join(G.GOLDEN, f"fp_path_{name}.json")))
+    p, pt, batches = G.fp_case_inputs(name)
+    p64 = {n: a.astype(np.float64) for n, a in p.items()}
+    mu = {n: np.zeros_like(a) for n, a in p64.items()}
+    nu = {n: np.zeros_like(a) for n, a in p64.items()}
+    count = np.zeros(K, np.int64)
+    h = rec["hyper"]
+    for s, batch in enumerate(batches):
+        p64, mu, nu, count, losses = Q.learn_on_batch(p64, pt, mu, nu, count, batch, arch, h["gamma"] ** h["n"],
+                                                       h["lr"], h["eps"])
+        np.testing.assert_allclose(losses, rec["steps"][s]["losses"], rtol=1e-12)
+        for leaf, d in rec["steps"][s]["leaves"].items():
+            np.testing.assert_allclose(p64[leaf].reshape(K, -1)[:, d["idx"]], d["param"], rtol=1e-12)
+
+
+def test_batched_fp32_cpu_baseline_matches_fp64_oracle():
+    """The timed CPU baseline (torch fp32, K heads batched) computes the same step as the oracle."""
+    arch, obs, feats, A, K, B = "cnn", (84, 84, 4), [32, 64, 64, 512], 6, 2, 4
+    p, pt, batch = _setup(arch, obs, feats, A, K, B, seed=9)
+    step = T.BatchedStep(p, pt, A, 0.99, 6.25e-5, 1.5e-4)
+    losses32 = step.step(batch)
+    zeros = {n: np.zeros_like(a) for n, a in p.items()}
+    new_p, _, _, _, losses64 = Q.learn_on_batch(p, pt, zeros, zeros, np.zeros(K, np.int64), batch, arch, 0.99,
+                                                6.25e-5, 1.5e-4)
+    np.testing.assert_allclose(losses32, losses64, atol=1e-5)
+    for n in p:
+        np.testing.assert_allclose(step.p[n].detach().numpy(), new_p[n], atol=2e-6)
