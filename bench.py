@@ -1,0 +1,190 @@
+"""bench.py -- i-DQN gradient-steps/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 300 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (iDQN.learn_on_batch, reference slimdqn/networks/idqn.py:96-109:
+2K forwards + K backwards + K Adam updates, per-head losses produced) over one synthetic minibatch
+that is already resident in HBM (K=5, B=32, uint8 84x84x4, A=6, features [32,64,64,512]).
+
+N = 1: the fused path (Dense_0 weight gradient + Adam in one kernel).
+N > 1: data-parallel, weak scaling: every rank takes its own 32-sample shard of a global batch of 32*N,
+       gradients are summed with ONE RCCL all-reduce of the [K][P] fp32 arena, then Adam runs on every
+       rank.  `value` counts 32-sample gradient steps: N per global step (units all ranks processed / time).
+
+roofline: the dominant kernel (k_dense0_wgrad, HBM-bound) timed with hipEvents on its own stream inside
+the timed region; cpu_baseline: the oracle's torch-CPU fp32 restatement of the same step, timed on this
+box's host cores on a bounded sample (rank 0, N = 1 only) -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "i-dqn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+K_HEADS, BATCH, N_ACTIONS, OBS, FEATURES = 5, 32, 6, (84, 84, 4), [32, 64, 64, 512]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic(seed):
+    """SURVEY 8d inputs: iid uint8 frames, uniform actions, rewards in {-1,0,1}, 1 % terminals."""
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
+    s2 = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
+    a = rng.integers(0, N_ACTIONS, size=BATCH).astype(np.int32)
+    r = rng.integers(-1, 2, size=BATCH).astype(np.float32)
+    t = (rng.random(BATCH) < 0.01).astype(np.uint8)
+    return s, a, r, s2, t
+
+
+def cpu_baseline(budget_s=15.0):
+    """The oracle's torch-CPU fp32 restatement (K heads batched), all host cores, bounded sample."""
+    import torch
+
+    from oracle import qnet_ref as Q
+    from oracle import torch_ref as T
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    p = Q.init_params(0, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
+    pt = Q.init_params(1, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
+    step = T.BatchedStep(p, pt, N_ACTIONS, 0.99, 6.25e-5, 1.5e-4)
+    s, a, r, s2, t = synthetic(0)
+    batch = (s, a, r, s2, t.astype(bool))
+    step.step(batch)
+    step.step(batch)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step.step(batch)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same K=5 B=32 Nature-CNN step in {dt:.1f} s (oracle/torch_ref.BatchedStep, "
+                      f"torch-CPU fp32, {cores} threads; JAX is not installable here)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from collections import namedtuple
+
+    from slimdqn import _hip
+    from slimdqn.networks.idqn import iDQN
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    agent = iDQN(0, OBS, N_ACTIONS, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    s, a, r, s2, t = synthetic(1000 + rank)
+    batch = Batch(*(torch.from_numpy(x).cuda() for x in (s, a, r, s2, t)))  # resident in HBM before the timed region
+    dp = world > 1
+    global_batch = BATCH * world
+
+    def step(profile):
+        if not dp:
+            agent._learn(batch, flags=_hip.F_PROFILE if profile else 0)
+        else:
+            agent._learn(batch, flags=_hip.F_GRADS_ONLY | (_hip.F_PROFILE if profile else 0), mean_divisor=global_batch)
+            dist.all_reduce(agent._grad)       # sum of shard gradients == gradient of the 32*N batch
+            dist.all_reduce(agent._losses)
+            agent._apply_adam()
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        if dp:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dp:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    import ctypes as C
+
+    mean_ms, n_l, name = C.c_double(), C.c_int32(), C.create_string_buffer(64)
+    _hip.check(_hip.lib().idqn_profile_read(agent._handle, C.byref(mean_ms), C.byref(n_l), name), "idqn_profile_read")
+    losses = agent._losses.cpu().numpy()
+    assert np.isfinite(losses).all(), losses
+
+    if rank == 0:
+        P_w0 = 7744 * 512
+        fused = not dp
+        # algorithmic HBM bytes of one launch of the dominant kernel:
+        # fused: theta, m, v of Dense_0/kernel read + written; unfused: gradient written; + a3 and dh read once
+        per_head = (6 if fused else 1) * P_w0 * 4 + 7744 * 32 * 4 + 512 * 32 * 4
+        alg_bytes = K_HEADS * per_head
+        achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
+        out = {
+            "metric": "i-DQN grad-steps/sec, Nature-CNN K=5 batch=32",
+            "value": args.steps * world / elapsed,
+            "unit": "grad-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Atari synthetic 84x84x4 uint8, i-DQN K=5 Nature-CNN [32,64,64,512] A=6, "
+                                   f"batch 32 per GPU (global {global_batch}), "
+                                   + ("fused wgrad+Adam" if fused else "grad all-reduce (RCCL) then Adam"),
+                       "heads": K_HEADS, "batch_per_gpu": BATCH, "global_batch": global_batch,
+                       "parallelism": f"dp{world}" if dp else "single"},
+            "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes},
+            "final_losses": [float(x) for x in losses],
+        }
+        if not dp and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,705 @@
+// gfx950 kernels of the Nature-CNN i-DQN gradient step (included by qnet.hip).
+//
+// Data layout in HBM (one choice drives every kernel): activations are BATCH-MINOR,
+//     act[net][batch_block][row = (h, w, c)][32 samples]            (f32)
+// i.e. a "row" is one (pixel, channel) for a block of 32 samples = 128 B.  With the batch on the
+// 32-wide side of v_mfma_f32_32x32x2_f32, both operands of every contraction are plain 128-byte
+// rows (weights [k][out] row-major, activations [k][32]), so MFMA fragments load straight from
+// L2/HBM fully coalesced, results store as whole rows, and nothing needs an LDS transpose:
+//   forward      D[i = out channel][j = sample] += W[k][i] * act[k][j]          (rows of W, rows of act)
+//   weight grad  D[i = in  row   ][j = out row] += act[i][b] * dout[j][b]       (k = sample, in registers)
+//   data grad    D[i = in channel][j = sample] += W[i][k] * dout[k][j]          (k = out channel)
+// Where the reduced index is the contiguous one (weight grad: the sample; data grad: the out
+// channel of W[.][k]) each lane loads 16 consecutive floats of ITS row with 4 dwordx4 and feeds
+// register t to MFMA step t; the matching operand uses the same k-permutation (k = 16*half + t).
+// Spatial SAME padding (flax default, architectures/dqn.py:43-51) is materialised as zero borders of
+// the activation buffers, so no kernel has a bounds branch in its k-loop.
+//
+// Every kernel: 256-thread workgroups = 4 independent waves, one work item per wave, no LDS and no
+// barrier in the MFMA kernels (k_head / k_prep use LDS).  f32 MFMA is 64 FLOP/clk/SIMD: one
+// dword of each operand per 64-cycle instruction, so L2 operand traffic is far below its limit.
+#pragma once
+#include "common.h"
+
+struct ActGeom {
+    int H, W, C;        // logical extent
+    int lo_h, lo_w;     // zero border before the first row / column
+    int Hp, Wp;         // padded extent
+    long block;         // floats per (net, batch block) = Hp * Wp * C * 32
+};
+
+// --------------------------------------------------------------------------------------------
+// input staging: uint8 NHWC minibatch -> f32 / 255 batch-minor, through an LDS tile (the (s, s')
+// minibatch tile is transposed in LDS so that both the HBM read and the HBM write are coalesced)
+// architectures/dqn.py:44  `jnp.array(x, ndmin=4) / 255.0`
+// --------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const uint8_t* src[2];  // state, next_state  [B][E]
+    float* x;               // [n_sets][nb][g.block]
+    long E;                 // H*W*C
+    int B, nb, n_sets;
+    ActGeom g;
+};
+
+__global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
+    __shared__ float tile[64][33];
+    const int t = threadIdx.x;
+    const long e0 = (long)blockIdx.x * 64;
+    const int bb = blockIdx.y, set = blockIdx.z;
+    const uint8_t* src = a.src[set];
+    {
+        const int b = t >> 3, c = t & 7;
+        const int bg = bb * 32 + b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            long e = e0 + c * 8 + i;
+            float v = 0.f;
+            if (bg < a.B && e < a.E) v = (float)src[(long)bg * a.E + e] / 255.0f;
+            tile[c * 8 + i][b] = v;
+        }
+    }
+    __syncthreads();
+    float* x = a.x + ((long)set * a.nb + bb) * a.g.block;
+    const int b = t & 31;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        int el = pass * 8 + (t >> 5);
+        long e = e0 + el;
+        if (e < a.E) {
+            int c = (int)(e % a.g.C);
+            long hw = e / a.g.C;
+            int w = (int)(hw % a.g.W), h = (int)(hw / a.g.W);
+            long row = ((long)(h + a.g.lo_h) * a.g.Wp + (w + a.g.lo_w)) * a.g.C + c;
+            x[row * 32 + b] = tile[el][b];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// conv forward + bias + ReLU  (architectures/dqn.py:42-52; flax nn.Conv: NHWC x HWIO, cross-correlation)
+// item = (net, batch block, group of NP output positions, 32-wide out-channel tile)
+// --------------------------------------------------------------------------------------------
+struct ConvFwdArgs {
+    const float* in;            // [n_in_sets][nb][in_block]  zero-bordered
+    float* out;                 // [n_nets][nb][out_block]
+    const float* const* wbase;  // [n_nets] parameter base of each net (online or target arena slice)
+    const int* in_set;          // [n_nets] which input set a net reads
+    long w_off, b_off, in_block, out_block, n_items;
+    int n_nets, nb, npg, n_ct;
+    int KH, KWCI, S, CI, CO, IWp;       // KWCI = KW * CI (taps of one kernel row are contiguous rows)
+    int OH, OW, out_Wp, out_lo_h, out_lo_w;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int ct = (int)(item % a.n_ct);
+    item /= a.n_ct;
+    const int pg = (int)(item % a.npg);
+    item /= a.npg;
+    const int bb = (int)(item % a.nb);
+    const int n = (int)(item / a.nb);
+    const float* pbase = a.wbase[n];
+    const float* W = pbase + a.w_off + (long)h * a.CO + ct * 32 + bl;
+    const float* bias = pbase + a.b_off + ct * 32;
+    const float* X = a.in + ((long)a.in_set[n] * a.nb + bb) * a.in_block + lane;
+    float* Y = a.out + ((long)n * a.nb + bb) * a.out_block;
+    const int npos = a.OH * a.OW;
+
+    f32x16 acc[NP];
+    long xoff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int pos = min(pg * NP + p, npos - 1);
+        int oh = pos / a.OW, ow = pos - oh * a.OW;
+        xoff[p] = ((long)(oh * a.S) * a.IWp + ow * a.S) * a.CI * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = bias[mfma_row(r, h)];
+    }
+    const int J = a.KWCI >> 1;
+    const long wstep = 2L * a.CO;
+    for (int kh = 0; kh < a.KH; ++kh) {
+        const float* wk = W + (long)kh * a.KWCI * a.CO;
+        const long roff = (long)kh * a.IWp * a.CI * 32;
+#pragma unroll 4
+        for (int j = 0; j < J; ++j) {
+            float av = wk[j * wstep];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float bv = X[xoff[p] + roff + (long)j * 64];
+                acc[p] = mfma32(av, bv, acc[p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int pos = pg * NP + p;
+        if (pos < npos) {
+            int oh = pos / a.OW, ow = pos - oh * a.OW;
+            long row0 = ((long)(oh + a.out_lo_h) * a.out_Wp + (ow + a.out_lo_w)) * a.CO + ct * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[(row0 + mfma_row(r, h)) * 32 + bl] = fmaxf(acc[p][r], 0.f);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Dense_0 forward, split-K partials (architectures/dqn.py:67-68).  M = 32 samples, so this is a
+// weight-streaming kernel: every W element is used once per net; 16 B per lane straight to VGPRs.
+// item = (net, batch block, k-split, 128-wide column tile); partials are reduced (with bias + ReLU)
+// by k_head in fixed split order.
+// --------------------------------------------------------------------------------------------
+struct DenseFwdArgs {
+    const float* in;  // [n_nets][nb][F*32]
+    float* part;      // [n_nets][nb][NS][J][32]
+    const float* const* wbase;
+    long w_off, n_items;
+    int n_nets, nb, NS, n_jt, F, J, rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int jt = (int)(item % a.n_jt);
+    item /= a.n_jt;
+    const int s = (int)(item % a.NS);
+    item /= a.NS;
+    const int bb = (int)(item % a.nb);
+    const int n = (int)(item / a.nb);
+    const int f0 = s * a.rows_per_split;
+    const int f1 = min(a.F, f0 + a.rows_per_split);
+    const float* W = a.wbase[n] + a.w_off + (long)(f0 + h) * a.J + jt * 128 + 4 * bl;
+    const float* X = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)f0 * 32 + lane;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const long wstep = 2L * a.J;
+#pragma unroll 8
+    for (int f = f0; f < f1; f += 2) {
+        float4 w = *reinterpret_cast<const float4*>(W);
+        float x = *X;
+        W += wstep;
+        X += 64;
+        acc[0] = mfma32(w.x, x, acc[0]);
+        acc[1] = mfma32(w.y, x, acc[1]);
+        acc[2] = mfma32(w.z, x, acc[2]);
+        acc[3] = mfma32(w.w, x, acc[3]);
+    }
+    float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = mfma_row(r, h);
+        P[(4 * i + 0) * 32] = acc[0][r];
+        P[(4 * i + 1) * 32] = acc[1][r];
+        P[(4 * i + 2) * 32] = acc[2][r];
+        P[(4 * i + 3) * 32] = acc[3][r];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Head kernel: split-K reduce + bias + ReLU, Dense_1, TD target with the wavefront max over actions,
+// squared loss, dL/dq, Dense_1 gradients and dL/dh.  One workgroup per head.
+//   idqn.py:111-124  loss_on_batch / loss / compute_target;  architectures/dqn.py:70 final Dense
+// --------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* part;          // [2K][nb][NS][J][32]
+    const float* const* wbase;  // [2K]
+    long b0_off, w1_off, b1_off, P;
+    int K, nb, NS, J, A, B, Bdiv;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+    float gamma_n;
+    float* dh;      // [K][nb][J][32]
+    float* q_dbg;   // [2K][nb][32][32]
+    float* grad;    // [K][P]
+    float* losses;  // [K]
+};
+
+// hs[j*33 + b] = relu(b0[j] + sum_s part[s][j][b]);  qs[a*32 + b] = b1[a] + sum_j hs[j][b] * W1[j][a]
+__device__ __forceinline__ void head_hidden_and_q(float* hs, float* qs, const float* part, const float* b0,
+                                                  const float* w1, const float* b1, int NS, int J, int A) {
+    const int t = threadIdx.x;
+    for (int e = t; e < J * 32; e += 256) {
+        int j = e >> 5, b = e & 31;
+        float s = b0[j];
+        for (int sp = 0; sp < NS; ++sp) s += part[((long)sp * J + j) * 32 + b];
+        hs[j * 33 + b] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    const int g = t >> 5, b = t & 31;
+    for (int a = g; a < A; a += 8) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int j = 0; j < J; j += 4) {
+            s0 = fmaf(hs[(j + 0) * 33 + b], w1[(j + 0) * A + a], s0);
+            s1 = fmaf(hs[(j + 1) * 33 + b], w1[(j + 1) * A + a], s1);
+            s2 = fmaf(hs[(j + 2) * 33 + b], w1[(j + 2) * A + a], s2);
+            s3 = fmaf(hs[(j + 3) * 33 + b], w1[(j + 3) * A + a], s3);
+        }
+        qs[a * 32 + b] = ((s0 + s1) + (s2 + s3)) + b1[a];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* hs = lds;                 // [J][33]
+    float* qs = hs + a.J * 33;       // [32][32]
+    float* qmax = qs + 32 * 32;      // [32]
+    float* cs = qmax + 32;           // [32]  2 * td / B
+    int* as = (int*)(cs + 32);       // [32]
+    float* red = (float*)(as + 32);  // [32]
+    const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
+    const float* po = a.wbase[k];
+    const float* pt = a.wbase[a.K + k];
+    float* G = a.grad + (long)k * a.P;
+    float loss_acc = 0.f;
+    for (int bb = 0; bb < a.nb; ++bb) {
+        // ---- target head on s'
+        head_hidden_and_q(hs, qs, a.part + (((long)(a.K + k) * a.nb + bb) * a.NS) * a.J * 32, pt + a.b0_off,
+                          pt + a.w1_off, pt + a.b1_off, a.NS, a.J, a.A);
+        for (int e = t; e < a.A * 32; e += 256) a.q_dbg[(((long)(a.K + k) * a.nb + bb) * 32) * 32 + e] = qs[e];
+        if (t < 64) {  // wave 0: max over actions, half the actions per half-wave, one cross-lane step
+            float m = -INFINITY;
+            for (int ac = h; ac < a.A; ac += 2) m = fmaxf(m, qs[ac * 32 + bl]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (h == 0) qmax[bl] = m;
+        }
+        __syncthreads();
+        // ---- online head on s
+        head_hidden_and_q(hs, qs, a.part + (((long)k * a.nb + bb) * a.NS) * a.J * 32, po + a.b0_off, po + a.w1_off,
+                          po + a.b1_off, a.NS, a.J, a.A);
+        for (int e = t; e < a.A * 32; e += 256) a.q_dbg[(((long)k * a.nb + bb) * 32) * 32 + e] = qs[e];
+        if (t < 64) {
+            const int bg = bb * 32 + bl;
+            const bool valid = bg < a.B;
+            int ac = valid ? a.action[bg] : 0;
+            float td = 0.f;
+            if (valid) {
+                // idqn.py:122  r + (1 - terminal) * gamma**n * max_a Q_target(s')
+                float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * qmax[bl];
+                td = qs[ac * 32 + bl] - tgt;
+            }
+            if (h == 0) {
+                cs[bl] = 2.0f * td / (float)a.Bdiv;
+                as[bl] = ac;
+            }
+            float sq = (h == 0) ? td * td : 0.f;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+            if (lane == 0) red[0] = sq;
+        }
+        __syncthreads();
+        loss_acc += red[0];
+        // ---- dL/dh (ReLU mask) -> HBM, Dense_0 bias gradient
+        float* dh = a.dh + ((long)k * a.nb + bb) * a.J * 32;
+        const float* w1 = po + a.w1_off;
+        for (int e = t; e < a.J * 32; e += 256) {
+            int j = e >> 5, b = e & 31;
+            float d = hs[j * 33 + b] > 0.f ? w1[j * a.A + as[b]] * cs[b] : 0.f;
+            dh[e] = d;
+            float sb = d;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) sb += __shfl_xor(sb, o);
+            if (b == 0) G[a.b0_off + j] = (bb == 0 ? 0.f : G[a.b0_off + j]) + sb;
+        }
+        // ---- Dense_1 gradients: gW1[j][a] = sum_b h[j][b] * dq[a][b],  gb1[a] = sum_b dq[a][b]
+        for (int o = t; o < a.J * a.A; o += 256) {
+            int j = o / a.A, ac = o - j * a.A;
+            float s = 0.f;
+            for (int b = 0; b < 32; ++b) s += (as[b] == ac) ? hs[j * 33 + b] * cs[b] : 0.f;
+            G[a.w1_off + o] = (bb == 0 ? 0.f : G[a.w1_off + o]) + s;
+        }
+        if (t < a.A) {
+            float s = 0.f;
+            for (int b = 0; b < 32; ++b) s += (as[b] == t) ? cs[b] : 0.f;
+            G[a.b1_off + t] = (bb == 0 ? 0.f : G[a.b1_off + t]) + s;
+        }
+        __syncthreads();
+    }
+    if (t == 0) a.losses[k] = loss_acc / (float)a.Bdiv;
+}
+
+// Inference variant: Q-values of one net for <= 32 states (idqn.py:131 / dqn.py:90 network.apply).
+struct HeadQArgs {
+    const float* part;
+    const float* const* wbase;
+    long b0_off, w1_off, b1_off;
+    int NS, J, A, n;
+    float* q_out;  // [n][A]
+};
+__global__ __launch_bounds__(256) void k_head_q(HeadQArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* hs = lds;
+    float* qs = hs + a.J * 33;
+    const float* p = a.wbase[0];
+    head_hidden_and_q(hs, qs, a.part, p + a.b0_off, p + a.w1_off, p + a.b1_off, a.NS, a.J, a.A);
+    for (int e = threadIdx.x; e < a.A * 32; e += 256) {
+        int ac = e >> 5, b = e & 31;
+        if (b < a.n) a.q_out[b * a.A + ac] = qs[e];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Dense_0 data gradient: da3[f][b] = relu'(a3[f][b]) * sum_j W0[f][j] * dh[j][b]
+// item = (head, batch block, 32-row f tile).  W rows are read 16 floats per lane (k in registers).
+// --------------------------------------------------------------------------------------------
+struct DenseDgradArgs {
+    const float* dh;   // [K][nb][J][32]
+    const float* a3;   // [2K][nb][F*32]  (online nets first)
+    float* da3;        // [K][nb][g.block]
+    const float* const* wbase;
+    long w_off, n_items;
+    int K, nb, n_ft, F, J, C;  // C = channels of a3 (f = pos*C + c)
+    ActGeom g;                 // geometry of da3
+};
+
+__global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int ft = (int)(item % a.n_ft);
+    item /= a.n_ft;
+    const int bb = (int)(item % a.nb);
+    const int k = (int)(item / a.nb);
+    const int f0 = ft * 32;
+    const float* W = a.wbase[k] + a.w_off + (long)(f0 + bl) * a.J + 16 * h;
+    const float* D = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(16 * h) * 32 + bl;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < a.J; c += 32) {
+        float4 w0 = *reinterpret_cast<const float4*>(W + c);
+        float4 w1 = *reinterpret_cast<const float4*>(W + c + 4);
+        float4 w2 = *reinterpret_cast<const float4*>(W + c + 8);
+        float4 w3 = *reinterpret_cast<const float4*>(W + c + 12);
+        const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                              w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        const float* d = D + (long)c * 32;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = mfma32(wv[t], d[t * 32], acc);
+    }
+    const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32;
+    float* O = a.da3 + ((long)k * a.nb + bb) * a.g.block;
+    const int pos = f0 / a.C, c0 = f0 - pos * a.C;
+    const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
+    const long row0 = ((long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w)) * a.C + c0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = mfma_row(r, h);
+        float m = A3[(long)(f0 + i) * 32 + bl];
+        O[(row0 + i) * 32 + bl] = m > 0.f ? acc[r] : 0.f;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Dense_0 weight gradient (+ optionally fused Adam): g[f][j] = sum_b a3[f][b] * dh[j][b]
+// item = (head, 32-row f tile, 128-col j tile).  HBM-bound: the output (and, fused, theta/m/v) is
+// the 15.9 MB/head matrix; MFMA work is ~10 % of the streaming time.
+// --------------------------------------------------------------------------------------------
+struct AdamConsts {
+    float lr_neg, b1, b2, omb1, omb2, eps;
+};
+__device__ __forceinline__ void adam_bias_corr(const AdamConsts& c, int count, float& bc1, float& bc2) {
+    const double t = (double)(count + 1);
+    bc1 = 1.0f - (float)pow((double)c.b1, t);
+    bc2 = 1.0f - (float)pow((double)c.b2, t);
+}
+__device__ __forceinline__ void adam_elem(const AdamConsts& c, float bc1, float bc2, float g, float& th, float& m,
+                                          float& v) {
+    m = c.omb1 * g + c.b1 * m;
+    v = c.omb2 * (g * g) + c.b2 * v;
+    float mh = m / bc1, vh = v / bc2;
+    th = th + c.lr_neg * (mh / (sqrtf(vh) + c.eps));
+}
+
+struct DenseWgradArgs {
+    const float* a3;  // [2K][nb][F*32]
+    const float* dh;  // [K][nb][J][32]
+    float* grad;      // [K][P]
+    float *theta, *mu, *nu;
+    const int32_t* count;
+    AdamConsts ad;
+    long w_off, P, n_items;
+    int K, nb, n_ft, n_jt, F, J;
+};
+
+template <bool FUSE_ADAM>
+__global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int jt = (int)(item % a.n_jt);
+    item /= a.n_jt;
+    const int ft = (int)(item % a.n_ft);
+    const int k = (int)(item / a.n_ft);
+    const int f0 = ft * 32, j0 = jt * 128;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int bb = 0; bb < a.nb; ++bb) {
+        const float* Ap = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
+        float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
+        float4 x2 = *reinterpret_cast<const float4*>(Ap + 8), x3 = *reinterpret_cast<const float4*>(Ap + 12);
+        const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
+                              x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+        const float* Dp = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(j0 + 4 * bl) * 32 + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* dq = Dp + q * 32;
+            float4 y0 = *reinterpret_cast<const float4*>(dq), y1 = *reinterpret_cast<const float4*>(dq + 4);
+            float4 y2 = *reinterpret_cast<const float4*>(dq + 8), y3 = *reinterpret_cast<const float4*>(dq + 12);
+            const float bv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
+                                  y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[q] = mfma32(av[t], bv[t], acc[q]);
+        }
+    }
+    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0 + 4 * bl;
+    if (FUSE_ADAM) {
+        float bc1, bc2;
+        adam_bias_corr(a.ad, a.count[k], bc1, bc2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long o = base + (long)mfma_row(r, h) * a.J;
+            float4 th = *reinterpret_cast<float4*>(a.theta + o);
+            float4 m = *reinterpret_cast<float4*>(a.mu + o);
+            float4 v = *reinterpret_cast<float4*>(a.nu + o);
+            adam_elem(a.ad, bc1, bc2, acc[0][r], th.x, m.x, v.x);
+            adam_elem(a.ad, bc1, bc2, acc[1][r], th.y, m.y, v.y);
+            adam_elem(a.ad, bc1, bc2, acc[2][r], th.z, m.z, v.z);
+            adam_elem(a.ad, bc1, bc2, acc[3][r], th.w, m.w, v.w);
+            *reinterpret_cast<float4*>(a.theta + o) = th;
+            *reinterpret_cast<float4*>(a.mu + o) = m;
+            *reinterpret_cast<float4*>(a.nu + o) = v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long o = base + (long)mfma_row(r, h) * a.J;
+            *reinterpret_cast<float4*>(a.grad + o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// conv data gradient (+ ReLU mask of the layer below)
+//   din[ih][iw][ci][b] = relu'(act_in) * sum_{kh,kw,co} W[kh][kw][ci][co] * dout[oh][ow][co][b],
+//   oh = (ih + PLh - kh) / S for the kh with (ih + PLh - kh) % S == 0 (zero-bordered dout covers oh = -1 ..)
+// item = (head, batch block, input position, 32-wide ci tile)
+// --------------------------------------------------------------------------------------------
+struct ConvDgradArgs {
+    const float* dout;    // [K][nb][gd.block]   zero-bordered
+    const float* act_in;  // [2K][nb][gm.block]  forward activation of this conv's INPUT (online nets first)
+    float* din;           // [K][nb][gi.block]
+    const float* const* wbase;
+    long w_off, n_items;
+    int K, nb, n_cit, KH, KW, S, PLh, PLw, CI, CO, IH, IW;
+    ActGeom gd, gm, gi;
+};
+
+__global__ __launch_bounds__(256) void k_conv_dgrad(ConvDgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int cit = (int)(item % a.n_cit);
+    item /= a.n_cit;
+    const int pos = (int)(item % (a.IH * a.IW));
+    item /= (a.IH * a.IW);
+    const int bb = (int)(item % a.nb);
+    const int k = (int)(item / a.nb);
+    const int ih = pos / a.IW, iw = pos - ih * a.IW;
+    const float* W = a.wbase[k] + a.w_off + (long)(cit * 32 + bl) * a.CO + 16 * h;
+    const float* D = a.dout + ((long)k * a.nb + bb) * a.gd.block + (long)(16 * h) * 32 + bl;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kh = (ih + a.PLh) % a.S; kh < a.KH; kh += a.S) {
+        const int ohp = (ih + a.PLh - kh) / a.S + a.gd.lo_h;
+        for (int kw = (iw + a.PLw) % a.S; kw < a.KW; kw += a.S) {
+            const int owp = (iw + a.PLw - kw) / a.S + a.gd.lo_w;
+            const float* wt = W + (long)(kh * a.KW + kw) * a.CI * a.CO;
+            const float* dr = D + ((long)ohp * a.gd.Wp + owp) * a.CO * 32;
+            for (int c = 0; c < a.CO; c += 32) {
+                float4 w0 = *reinterpret_cast<const float4*>(wt + c);
+                float4 w1 = *reinterpret_cast<const float4*>(wt + c + 4);
+                float4 w2 = *reinterpret_cast<const float4*>(wt + c + 8);
+                float4 w3 = *reinterpret_cast<const float4*>(wt + c + 12);
+                const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
+                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                const float* d = dr + (long)c * 32;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = mfma32(wv[t], d[t * 32], acc);
+            }
+        }
+    }
+    const float* M = a.act_in + ((long)k * a.nb + bb) * a.gm.block +
+                     (((long)(ih + a.gm.lo_h) * a.gm.Wp + (iw + a.gm.lo_w)) * a.CI + cit * 32) * 32 + bl;
+    float* O = a.din + ((long)k * a.nb + bb) * a.gi.block +
+               (((long)(ih + a.gi.lo_h) * a.gi.Wp + (iw + a.gi.lo_w)) * a.CI + cit * 32) * 32 + bl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = mfma_row(r, h);
+        O[i * 32] = M[i * 32] > 0.f ? acc[r] : 0.f;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// conv weight gradient: partial slabs over chunks of output positions
+//   gW[kh][kw][ci][co] = sum_{b, oh, ow} in[oh*S+kh][ow*S+kw][ci][b] * dout[oh][ow][co][b]
+// item = (head, kh, kw, position chunk); NIT x NOT accumulator tiles of 32x32 ([ci tile][co tile]).
+// Conv_0 (CI = 4) runs the same code with the 32 rows (kw, ci) of one kernel row as its "ci tile".
+// --------------------------------------------------------------------------------------------
+struct ConvWgradArgs {
+    const float* in;    // [n_in_sets or 2K][nb][gin.block]  forward input of the conv (online set / nets first)
+    const float* dout;  // [K][nb][gd.block]
+    float* slab;        // [npc][K][slab_stride]   weights then bias
+    long in_net_stride; // 0 when all heads share the input (Conv_0 reads the staged s)
+    long slab_stride, n_items;
+    int K, nb, npc, KH, KWe, S, in_C, CIe, CO, OH, OW, pos_per_chunk;
+    ActGeom gin, gd;
+};
+
+template <int NIT, int NOT>
+__global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int pc = (int)(item % a.npc);
+    item /= a.npc;
+    const int kw = (int)(item % a.KWe);
+    item /= a.KWe;
+    const int kh = (int)(item % a.KH);
+    const int k = (int)(item / a.KH);
+    f32x16 acc[NIT][NOT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int o = 0; o < NOT; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][o][r] = 0.f;
+    float bsum[NOT];
+#pragma unroll
+    for (int o = 0; o < NOT; ++o) bsum[o] = 0.f;
+    const int npos = a.OH * a.OW;
+    const int p0 = pc * a.pos_per_chunk, p1 = min(npos, p0 + a.pos_per_chunk);
+    for (int bb = 0; bb < a.nb; ++bb) {
+        const float* IN = a.in + (long)k * a.in_net_stride + (long)bb * a.gin.block + (long)bl * 32 + 16 * h;
+        const float* DO = a.dout + ((long)k * a.nb + bb) * a.gd.block + (long)bl * 32 + 16 * h;
+        for (int pos = p0; pos < p1; ++pos) {
+            const int oh = pos / a.OW, ow = pos - oh * a.OW;
+            const float* ip = IN + (((long)(oh * a.S + kh) * a.gin.Wp + (ow * a.S + kw)) * a.in_C) * 32;
+            const float* dp = DO + (((long)(oh + a.gd.lo_h) * a.gd.Wp + (ow + a.gd.lo_w)) * a.CO) * 32;
+            float bv[NOT][16];
+#pragma unroll
+            for (int o = 0; o < NOT; ++o) {
+                const float* q = dp + (long)o * 32 * 32;
+                float4 y0 = *reinterpret_cast<const float4*>(q), y1 = *reinterpret_cast<const float4*>(q + 4);
+                float4 y2 = *reinterpret_cast<const float4*>(q + 8), y3 = *reinterpret_cast<const float4*>(q + 12);
+                bv[o][0] = y0.x; bv[o][1] = y0.y; bv[o][2] = y0.z; bv[o][3] = y0.w;
+                bv[o][4] = y1.x; bv[o][5] = y1.y; bv[o][6] = y1.z; bv[o][7] = y1.w;
+                bv[o][8] = y2.x; bv[o][9] = y2.y; bv[o][10] = y2.z; bv[o][11] = y2.w;
+                bv[o][12] = y3.x; bv[o][13] = y3.y; bv[o][14] = y3.z; bv[o][15] = y3.w;
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s += bv[o][t];
+                bsum[o] += s;
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const float* q = ip + (long)i * 32 * 32;
+                float4 x0 = *reinterpret_cast<const float4*>(q), x1 = *reinterpret_cast<const float4*>(q + 4);
+                float4 x2 = *reinterpret_cast<const float4*>(q + 8), x3 = *reinterpret_cast<const float4*>(q + 12);
+                const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
+                                      x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+#pragma unroll
+                for (int o = 0; o < NOT; ++o)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[i][o] = mfma32(av[t], bv[o][t], acc[i][o]);
+            }
+        }
+    }
+    float* S = a.slab + ((long)pc * a.K + k) * a.slab_stride;
+    const long wrow0 = (long)(kh * a.KWe + kw) * a.CIe;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int o = 0; o < NOT; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                S[(wrow0 + i * 32 + mfma_row(r, h)) * a.CO + o * 32 + bl] = acc[i][o][r];
+    if (kh == 0 && kw == 0) {
+        const long wsize = (long)a.KH * a.KWe * a.CIe * a.CO;
+#pragma unroll
+        for (int o = 0; o < NOT; ++o) {
+            float s = bsum[o] + __shfl_xor(bsum[o], 32);
+            if (h == 0) S[wsize + o * 32 + bl] = s;
+        }
+    }
+}
+
+// slab reduce: grad[k][off + e] = sum_pc slab[pc][k][e]   (fixed order -> reproducible)
+struct SlabReduceArgs {
+    const float* slab;
+    float* grad;
+    long slab_stride, P, w_off, b_off, wsize;
+    int K, npc, bsize;
+};
+__global__ void k_slab_reduce(SlabReduceArgs a) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (e >= a.wsize + a.bsize) return;
+    float s = 0.f;
+    for (int pc = 0; pc < a.npc; ++pc) s += a.slab[((long)pc * a.K + k) * a.slab_stride + e];
+    const long o = e < a.wsize ? a.w_off + e : a.b_off + (e - a.wsize);
+    a.grad[(long)k * a.P + o] = s;
+}
+
+// --------------------------------------------------------------------------------------------
+// Adam over (part of) the arenas (optax.adam, idqn.py:52,106-107) and the step epilogue
+// --------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float *theta, *mu, *nu;
+    const float* grad;
+    const int32_t* count;
+    AdamConsts ad;
+    long P, begin, end;  // element range inside a head, multiples of 4
+    long skip_begin, skip_end;  // sub-range already updated by a fused kernel (empty when begin==end)
+};
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    const int k = blockIdx.y;
+    long e = a.begin + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= a.end) return;
+    if (e >= a.skip_begin && e < a.skip_end) return;
+    float bc1, bc2;
+    adam_bias_corr(a.ad, a.count[k], bc1, bc2);
+    const long o = (long)k * a.P + e;
+    float4 g = *reinterpret_cast<const float4*>(a.grad + o);
+    float4 th = *reinterpret_cast<float4*>(a.theta + o);
+    float4 m = *reinterpret_cast<float4*>(a.mu + o);
+    float4 v = *reinterpret_cast<float4*>(a.nu + o);
+    adam_elem(a.ad, bc1, bc2, g.x, th.x, m.x, v.x);
+    adam_elem(a.ad, bc1, bc2, g.y, th.y, m.y, v.y);
+    adam_elem(a.ad, bc1, bc2, g.z, th.z, m.z, v.z);
+    adam_elem(a.ad, bc1, bc2, g.w, th.w, m.w, v.w);
+    *reinterpret_cast<float4*>(a.theta + o) = th;
+    *reinterpret_cast<float4*>(a.mu + o) = m;
+    *reinterpret_cast<float4*>(a.nu + o) = v;
+}
+
+// count += 1 (optax count, idqn.py:53), cum_losses += losses in f64 (idqn.py:72)
+__global__ void k_step_epilogue(int32_t* count, const float* losses, double* cum, int K, int bump_count) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    if (bump_count) count[k] += 1;
+    cum[k] = cum[k] + (double)losses[k];
+}
+
+__global__ void k_set_ptr(const float** dst, const float* v) { *dst = v; }

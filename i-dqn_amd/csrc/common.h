@@ -1,0 +1,40 @@
+// Shared helpers for the gfx950 kernels of libidqn_hip.so.  CDNA4 only: 64-wide wavefronts,
+// v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fmaf chain) for every contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/idqn_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// D = A * B + C on one wave.  Operand maps (cdna_hip_programming.md section 3):
+//   a: lane l holds A[i = l & 31][k = l >> 5]      b: lane l holds B[k = l >> 5][j = l & 31]
+//   c/d: register r of lane l holds D[i = mfma_row(r, l >> 5)][j = l & 31]
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+void idqn_set_error(const char* fmt, ...);
+
+#define IDQN_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            idqn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return IDQN_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define IDQN_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            idqn_set_error(__VA_ARGS__); \
+            return IDQN_E_INVALID;       \
+        }                                \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

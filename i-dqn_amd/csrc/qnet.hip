@@ -1,0 +1,603 @@
+// Host side of the C ABI for the i-DQN gradient step: layout, workspace, kernel orchestration.
+//
+// Replaces (reference file:line):
+//   iDQN.learn_on_batch          slimdqn/networks/idqn.py:96-109   (jit o vmap of value_and_grad + optax.adam)
+//   iDQN.update_target_params    slimdqn/networks/idqn.py:74-94    (copy + shift / sync, as device copies)
+//   DQNNet.apply                 slimdqn/networks/architectures/dqn.py:38-70
+// One launch sequence per step on the caller's stream; nothing here synchronises with the host.
+// Scratch buffers are addressed compactly with the ACTIVE number of 32-sample batch blocks of a call
+// (slot = (net * nb + bb) * block); zero borders sit at fixed offsets inside every block-sized slot
+// and only interiors are ever written, so they stay zero for any nb.
+#include <string>
+#include <vector>
+
+#include "cnn_kernels.h"
+#include "fc_kernels.h"
+
+namespace {
+
+struct ConvL {
+    int K, S, PLh, PLw, CI, CO, IH, IW, OH, OW;
+    long w_off, b_off;
+};
+
+void same_pad(int i, int k, int s, int* out, int* lo, int* hi) {
+    *out = (i + s - 1) / s;
+    int p = (*out - 1) * s + k - i;
+    if (p < 0) p = 0;
+    *lo = p / 2;
+    *hi = p - *lo;
+}
+
+ActGeom make_geom(int H, int W, int C, int lo_h, int hi_h, int lo_w, int hi_w) {
+    ActGeom g;
+    g.H = H; g.W = W; g.C = C; g.lo_h = lo_h; g.lo_w = lo_w;
+    g.Hp = H + lo_h + hi_h; g.Wp = W + lo_w + hi_w;
+    g.block = (long)g.Hp * g.Wp * C * 32;
+    return g;
+}
+
+// zero border a dout buffer needs so that the data-gradient loop never leaves it
+void dgrad_pad(int I, int O, int K, int S, int PL, int* lo, int* hi) {
+    int mn = 0, mx = O - 1;
+    for (int i = 0; i < I; ++i)
+        for (int k = 0; k < K; ++k) {
+            int t = i + PL - k;
+            if (((t % S) + S) % S) continue;
+            int o = t >= 0 ? t / S : -((-t) / S);
+            if (o < mn) mn = o;
+            if (o > mx) mx = o;
+        }
+    *lo = -mn;
+    *hi = mx - (O - 1);
+}
+
+struct Layout {
+    int n_leaves = 0;
+    idqn_leaf_t leaves[IDQN_MAX_LEAVES];
+    long head_stride = 0;
+};
+
+void add_leaf(Layout& L, const char* name, int ndim, const long* shape, long* off) {
+    idqn_leaf_t& lf = L.leaves[L.n_leaves++];
+    memset(&lf, 0, sizeof(lf));
+    snprintf(lf.name, sizeof(lf.name), "%s", name);
+    lf.ndim = ndim;
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) { lf.shape[i] = shape[i]; n *= shape[i]; }
+    lf.offset = *off;
+    *off += (n + 63) / 64 * 64;  // every leaf starts on a 256-byte boundary
+}
+
+const int KS[3][2] = {{8, 4}, {4, 2}, {3, 1}};  // (kernel, stride) of Conv_0..2, architectures/dqn.py:43-51
+
+int build_layout(const idqn_config_t& c, Layout& L) {
+    IDQN_REQUIRE(c.n_heads >= 1 && c.n_actions >= 1 && c.n_actions <= 32, "n_heads >= 1 and 1 <= n_actions <= 32 required");
+    IDQN_REQUIRE(c.n_features >= 1 && c.n_features <= IDQN_MAX_FEATURES, "n_features out of range");
+    IDQN_REQUIRE(c.max_batch >= 1, "max_batch must be positive");
+    long off = 0;
+    char nm[32];
+    if (c.arch == IDQN_ARCH_CNN) {
+        IDQN_REQUIRE(c.n_features == 4, "cnn: exactly 4 features (three convs + one hidden dense) are built; got %d", c.n_features);
+        IDQN_REQUIRE(c.obs_c == 4, "cnn: obs_c must be 4 (Conv_0 packs (kw, c) into 32 rows), got %d", c.obs_c);
+        IDQN_REQUIRE(c.obs_h >= 8 && c.obs_w >= 8, "cnn: observation smaller than the first kernel");
+        for (int i = 0; i < 3; ++i)
+            IDQN_REQUIRE(c.features[i] == 32 || c.features[i] == 64, "cnn: conv features must be 32 or 64, got %d", c.features[i]);
+        IDQN_REQUIRE(c.features[3] % 128 == 0 && c.features[3] >= 128 && c.features[3] <= 512,
+                     "cnn: dense width must be a multiple of 128 in [128, 512], got %d", c.features[3]);
+        int h = c.obs_h, w = c.obs_w, ch = c.obs_c;
+        for (int i = 0; i < 3; ++i) {
+            long ks[4] = {KS[i][0], KS[i][0], ch, c.features[i]};
+            snprintf(nm, sizeof nm, "Conv_%d/kernel", i);
+            add_leaf(L, nm, 4, ks, &off);
+            long bs[1] = {c.features[i]};
+            snprintf(nm, sizeof nm, "Conv_%d/bias", i);
+            add_leaf(L, nm, 1, bs, &off);
+            int lo, hi;
+            same_pad(h, KS[i][0], KS[i][1], &h, &lo, &hi);
+            same_pad(w, KS[i][0], KS[i][1], &w, &lo, &hi);
+            ch = c.features[i];
+        }
+        long d0[2] = {(long)h * w * ch, c.features[3]};
+        add_leaf(L, "Dense_0/kernel", 2, d0, &off);
+        long b0[1] = {c.features[3]};
+        add_leaf(L, "Dense_0/bias", 1, b0, &off);
+        long d1[2] = {c.features[3], c.n_actions};
+        add_leaf(L, "Dense_1/kernel", 2, d1, &off);
+        long b1[1] = {c.n_actions};
+        add_leaf(L, "Dense_1/bias", 1, b1, &off);
+    } else if (c.arch == IDQN_ARCH_FC) {
+        long fan = (long)c.obs_h * c.obs_w * c.obs_c;
+        for (int i = 0; i <= c.n_features; ++i) {
+            long f = i < c.n_features ? c.features[i] : c.n_actions;
+            IDQN_REQUIRE(f >= 1 && f <= FC_MAX_WIDTH && fan <= FC_MAX_WIDTH, "fc: layer widths must be in [1, %d]", FC_MAX_WIDTH);
+            long ws[2] = {fan, f};
+            snprintf(nm, sizeof nm, "Dense_%d/kernel", i);
+            add_leaf(L, nm, 2, ws, &off);
+            long bs[1] = {f};
+            snprintf(nm, sizeof nm, "Dense_%d/bias", i);
+            add_leaf(L, nm, 1, bs, &off);
+            fan = f;
+        }
+    } else {
+        IDQN_REQUIRE(false, "unknown arch %d (impala is out of scope of the HIP path)", c.arch);
+    }
+    L.head_stride = off;
+    return IDQN_OK;
+}
+
+// One set of nets that run forward together: the 2K training nets, or the single inference net.
+struct NetSet {
+    int n_nets = 0, nb_cap = 0, n_in_sets = 0;
+    const float** wbase = nullptr;  // dev [n_nets]
+    int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
+    int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
+    float *x = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *part = nullptr;
+};
+
+}  // namespace
+
+struct idqn_handle_s {
+    idqn_config_t cfg;
+    Layout L;
+    float *online, *target, *mu, *nu, *grad, *losses;
+    int32_t* count;
+    double* cum;
+    AdamConsts ad;
+    float gamma_n;
+    int nb_max;
+    // cnn
+    ConvL conv[3];
+    ActGeom gx, ga1, ga2, ga3, gda3, gda2, gda1;
+    int F = 0, J = 0, NS = 0, rows_per_split = 0;
+    long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
+    NetSet train, infer;
+    float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
+    int npc[3], pos_per_chunk[3];
+    long slab_stride[3];
+    int head_lds = 0;
+    // fc
+    FcNet fc;
+    float* fc_ws = nullptr;
+    // profiling of the dominant kernel
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    const char* dominant = "";
+    std::vector<void*> owned;
+    std::vector<std::pair<std::string, std::pair<void*, long>>> dbg;
+};
+
+namespace {
+
+int alloc_zero(float** p, long n_floats, idqn_handle_s* h, const char* name) {
+    IDQN_HIP_CHECK(hipMalloc((void**)p, (size_t)n_floats * 4));
+    IDQN_HIP_CHECK(hipMemset(*p, 0, (size_t)n_floats * 4));
+    h->owned.push_back((void*)*p);
+    h->dbg.push_back({name, {(void*)*p, n_floats * 4}});
+    return IDQN_OK;
+}
+
+int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag) {
+    s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
+    IDQN_HIP_CHECK(hipMalloc((void**)&s.wbase, sizeof(float*) * n_nets));
+    IDQN_HIP_CHECK(hipMalloc((void**)&s.in_set, sizeof(int) * n_nets));
+    IDQN_HIP_CHECK(hipMalloc((void**)&s.ident, sizeof(int) * n_nets));
+    h->owned.push_back((void*)s.wbase); h->owned.push_back((void*)s.in_set); h->owned.push_back((void*)s.ident);
+    std::vector<int> id(n_nets);
+    for (int i = 0; i < n_nets; ++i) id[i] = i;
+    IDQN_HIP_CHECK(hipMemcpy(s.ident, id.data(), sizeof(int) * n_nets, hipMemcpyHostToDevice));
+    std::string t(tag);
+    int rc;
+    if ((rc = alloc_zero(&s.x, (long)n_in_sets * nb * h->gx.block, h, (t + "x").c_str()))) return rc;
+    if ((rc = alloc_zero(&s.a1, (long)n_nets * nb * h->ga1.block, h, (t + "a1").c_str()))) return rc;
+    if ((rc = alloc_zero(&s.a2, (long)n_nets * nb * h->ga2.block, h, (t + "a2").c_str()))) return rc;
+    if ((rc = alloc_zero(&s.a3, (long)n_nets * nb * h->ga3.block, h, (t + "a3").c_str()))) return rc;
+    if ((rc = alloc_zero(&s.part, (long)n_nets * nb * h->NS * h->J * 32, h, (t + "part").c_str()))) return rc;
+    return IDQN_OK;
+}
+
+int cnn_setup(idqn_handle_s* h) {
+    const idqn_config_t& c = h->cfg;
+    int ih = c.obs_h, iw = c.obs_w, ci = c.obs_c;
+    int lo_h[3], hi_h[3], lo_w[3], hi_w[3];
+    for (int i = 0; i < 3; ++i) {
+        ConvL& l = h->conv[i];
+        l.K = KS[i][0]; l.S = KS[i][1]; l.CI = ci; l.CO = c.features[i]; l.IH = ih; l.IW = iw;
+        same_pad(ih, l.K, l.S, &l.OH, &lo_h[i], &hi_h[i]);
+        same_pad(iw, l.K, l.S, &l.OW, &lo_w[i], &hi_w[i]);
+        l.PLh = lo_h[i]; l.PLw = lo_w[i];
+        l.w_off = h->L.leaves[2 * i].offset;
+        l.b_off = h->L.leaves[2 * i + 1].offset;
+        ih = l.OH; iw = l.OW; ci = l.CO;
+    }
+    h->off_w0 = h->L.leaves[6].offset; h->off_b0 = h->L.leaves[7].offset;
+    h->off_w1 = h->L.leaves[8].offset; h->off_b1 = h->L.leaves[9].offset;
+    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
+    h->gx = make_geom(c0->IH, c0->IW, c0->CI, lo_h[0], hi_h[0], lo_w[0], hi_w[0]);
+    h->ga1 = make_geom(c1->IH, c1->IW, c1->CI, lo_h[1], hi_h[1], lo_w[1], hi_w[1]);
+    h->ga2 = make_geom(c2->IH, c2->IW, c2->CI, lo_h[2], hi_h[2], lo_w[2], hi_w[2]);
+    h->ga3 = make_geom(c2->OH, c2->OW, c2->CO, 0, 0, 0, 0);
+    int l, hh, l2, h2;
+    dgrad_pad(c2->IH, c2->OH, c2->K, c2->S, c2->PLh, &l, &hh);
+    dgrad_pad(c2->IW, c2->OW, c2->K, c2->S, c2->PLw, &l2, &h2);
+    h->gda3 = make_geom(c2->OH, c2->OW, c2->CO, l, hh, l2, h2);
+    dgrad_pad(c1->IH, c1->OH, c1->K, c1->S, c1->PLh, &l, &hh);
+    dgrad_pad(c1->IW, c1->OW, c1->K, c1->S, c1->PLw, &l2, &h2);
+    h->gda2 = make_geom(c1->OH, c1->OW, c1->CO, l, hh, l2, h2);
+    h->gda1 = make_geom(c0->OH, c0->OW, c0->CO, 0, 0, 0, 0);
+    h->F = c2->OH * c2->OW * c2->CO;
+    h->J = c.features[3];
+    // split-K of Dense_0 forward: even row counts, ~16 splits
+    h->rows_per_split = ((h->F + 15) / 16 + 1) / 2 * 2;
+    h->NS = (h->F + h->rows_per_split - 1) / h->rows_per_split;
+    const int K = c.n_heads, nb = h->nb_max;
+    int rc;
+    if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
+    if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_"))) return rc;
+    std::vector<const float*> wb(2 * K);
+    std::vector<int> is(2 * K);
+    for (int k = 0; k < K; ++k) {
+        wb[k] = h->online + (long)k * h->L.head_stride; is[k] = 0;
+        wb[K + k] = h->target + (long)k * h->L.head_stride; is[K + k] = 1;
+    }
+    IDQN_HIP_CHECK(hipMemcpy(h->train.wbase, wb.data(), sizeof(float*) * 2 * K, hipMemcpyHostToDevice));
+    IDQN_HIP_CHECK(hipMemcpy(h->train.in_set, is.data(), sizeof(int) * 2 * K, hipMemcpyHostToDevice));
+    IDQN_HIP_CHECK(hipMemset(h->infer.in_set, 0, sizeof(int)));
+    if ((rc = alloc_zero(&h->dh, (long)K * nb * h->J * 32, h, "dh"))) return rc;
+    if ((rc = alloc_zero(&h->da3, (long)K * nb * h->gda3.block, h, "da3"))) return rc;
+    if ((rc = alloc_zero(&h->da2, (long)K * nb * h->gda2.block, h, "da2"))) return rc;
+    if ((rc = alloc_zero(&h->da1, (long)K * nb * h->gda1.block, h, "da1"))) return rc;
+    if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
+    // weight-gradient slabs: one chunk of output positions (one output row) per item
+    long maxslab = 0;
+    for (int i = 0; i < 3; ++i) {
+        const ConvL& cl = h->conv[i];
+        int npos = cl.OH * cl.OW;
+        h->pos_per_chunk[i] = cl.OW;
+        h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
+        h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
+        long e = (long)h->npc[i] * K * h->slab_stride[i];
+        if (e > maxslab) maxslab = e;
+    }
+    if ((rc = alloc_zero(&h->slab, maxslab, h, "slab"))) return rc;
+    // k_head / k_head_q need > 64 KB of dynamic LDS at J = 512
+    h->head_lds = (h->J * 33 + 32 * 32 + 4 * 32) * 4;
+    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
+    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head_q, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
+    h->dominant = "k_dense0_wgrad";
+    return IDQN_OK;
+}
+
+int fc_setup(idqn_handle_s* h) {
+    const idqn_config_t& c = h->cfg;
+    FcNet& n = h->fc;
+    n.L = c.n_features + 1;
+    n.d[0] = c.obs_h * c.obs_w * c.obs_c;
+    n.dmax = n.d[0];
+    for (int l = 0; l < n.L; ++l) {
+        n.d[l + 1] = l < c.n_features ? c.features[l] : c.n_actions;
+        if (n.d[l + 1] > n.dmax) n.dmax = n.d[l + 1];
+        n.w_off[l] = h->L.leaves[2 * l].offset;
+        n.b_off[l] = h->L.leaves[2 * l + 1].offset;
+    }
+    const long B = c.max_batch, K = c.n_heads;
+    int rc;
+    if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
+    if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
+    h->dominant = "k_fc_step";
+    return IDQN_OK;
+}
+
+// ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
+int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q) {
+    const int nb = cdiv(B, 32);
+    IDQN_REQUIRE(nb <= s.nb_cap, "batch %d exceeds the workspace (%d blocks of 32)", B, s.nb_cap);
+    PrepArgs pa;
+    pa.src[0] = st; pa.src[1] = st2 ? st2 : st;
+    pa.x = s.x; pa.E = (long)h->gx.H * h->gx.W * h->gx.C; pa.B = B; pa.nb = nb; pa.n_sets = s.n_in_sets; pa.g = h->gx;
+    hipLaunchKernelGGL(k_prep_u8, dim3(cdiv(pa.E, 64), nb, s.n_in_sets), dim3(256), 0, q, pa);
+    const float* ins[3] = {s.x, s.a1, s.a2};
+    float* outs[3] = {s.a1, s.a2, s.a3};
+    const ActGeom* gin[3] = {&h->gx, &h->ga1, &h->ga2};
+    const ActGeom* gout[3] = {&h->ga1, &h->ga2, &h->ga3};
+    for (int i = 0; i < 3; ++i) {
+        const ConvL& l = h->conv[i];
+        ConvFwdArgs a;
+        a.in = ins[i]; a.out = outs[i]; a.wbase = s.wbase; a.in_set = (i == 0) ? s.in_set : s.ident;
+        a.w_off = l.w_off; a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
+        a.n_nets = s.n_nets; a.nb = nb;
+        a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
+        a.OH = l.OH; a.OW = l.OW; a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
+        a.n_ct = l.CO / 32;
+        const int NP = (i == 0) ? 3 : 1;
+        a.npg = cdiv(l.OH * l.OW, NP);
+        a.n_items = (long)s.n_nets * nb * a.npg * a.n_ct;
+        if (i == 0)
+            hipLaunchKernelGGL(k_conv_fwd<3>, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+        else
+            hipLaunchKernelGGL(k_conv_fwd<1>, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+    }
+    DenseFwdArgs d;
+    d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
+    d.n_nets = s.n_nets; d.nb = nb; d.NS = h->NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
+    d.rows_per_split = h->rows_per_split;
+    d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
+    hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, hipStream_t q) {
+    AdamArgs a;
+    a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.count = h->count; a.ad = h->ad;
+    a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
+    hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, const uint8_t* terminal, int B,
+                 int Bdiv, bool fuse_adam, bool profile, hipStream_t q) {
+    const int K = h->cfg.n_heads, nb = cdiv(B, 32);
+    NetSet& s = h->train;
+    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
+    // head: loss, dL/dq, Dense_1 + Dense_0-bias gradients, dL/dh
+    HeadArgs ha;
+    ha.part = s.part; ha.wbase = s.wbase; ha.b0_off = h->off_b0; ha.w1_off = h->off_w1; ha.b1_off = h->off_b1;
+    ha.P = h->L.head_stride; ha.K = K; ha.nb = nb; ha.NS = h->NS; ha.J = h->J; ha.A = h->cfg.n_actions; ha.B = B;
+    ha.Bdiv = Bdiv; ha.action = action; ha.reward = reward; ha.terminal = terminal; ha.gamma_n = h->gamma_n;
+    ha.dh = h->dh; ha.q_dbg = h->qdbg; ha.grad = h->grad; ha.losses = h->losses;
+    hipLaunchKernelGGL(k_head, dim3(K), dim3(256), h->head_lds, q, ha);
+    // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
+    DenseDgradArgs dd;
+    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+    dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
+    dd.n_items = (long)K * nb * dd.n_ft;
+    hipLaunchKernelGGL(k_dense0_dgrad, dim3(cdiv(dd.n_items, 4)), dim3(256), 0, q, dd);
+    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
+    DenseWgradArgs dw;
+    dw.a3 = s.a3; dw.dh = h->dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
+    dw.count = h->count; dw.ad = h->ad; dw.w_off = h->off_w0; dw.P = h->L.head_stride;
+    dw.K = K; dw.nb = nb; dw.n_ft = h->F / 32; dw.n_jt = h->J / 128; dw.F = h->F; dw.J = h->J;
+    dw.n_items = (long)K * dw.n_ft * dw.n_jt;
+    if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
+    if (fuse_adam)
+        hipLaunchKernelGGL(k_dense0_wgrad<true>, dim3(cdiv(dw.n_items, 4)), dim3(256), 0, q, dw);
+    else
+        hipLaunchKernelGGL(k_dense0_wgrad<false>, dim3(cdiv(dw.n_items, 4)), dim3(256), 0, q, dw);
+    if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
+        IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
+        h->ev_used += 2;
+    }
+    // conv data gradients
+    const ConvL* cl[3] = {c0, c1, c2};
+    const float* douts[3] = {h->da1, h->da2, h->da3};
+    const ActGeom* gdo[3] = {&h->gda1, &h->gda2, &h->gda3};
+    const float* acts_in[3] = {s.x, s.a1, s.a2};
+    const ActGeom* gact[3] = {&h->gx, &h->ga1, &h->ga2};
+    float* dins[3] = {nullptr, h->da1, h->da2};
+    const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
+    for (int i = 2; i >= 1; --i) {
+        ConvDgradArgs a;
+        a.dout = douts[i]; a.act_in = acts_in[i]; a.din = dins[i]; a.wbase = s.wbase; a.w_off = cl[i]->w_off;
+        a.K = K; a.nb = nb; a.n_cit = cl[i]->CI / 32; a.KH = cl[i]->K; a.KW = cl[i]->K; a.S = cl[i]->S;
+        a.PLh = cl[i]->PLh; a.PLw = cl[i]->PLw; a.CI = cl[i]->CI; a.CO = cl[i]->CO; a.IH = cl[i]->IH; a.IW = cl[i]->IW;
+        a.gd = *gdo[i]; a.gm = *gact[i]; a.gi = *gdi[i];
+        a.n_items = (long)K * nb * a.IH * a.IW * a.n_cit;
+        hipLaunchKernelGGL(k_conv_dgrad, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+        // weight gradient of layer i can run as soon as its dout exists (it does: douts[i])
+    }
+    // conv weight gradients: slabs, then reduce into the gradient arena
+    for (int i = 2; i >= 0; --i) {
+        ConvWgradArgs a;
+        a.in = acts_in[i]; a.dout = douts[i]; a.slab = h->slab;
+        a.in_net_stride = (i == 0) ? 0 : (long)nb * gact[i]->block;
+        a.slab_stride = h->slab_stride[i];
+        a.K = K; a.nb = nb; a.npc = h->npc[i]; a.KH = cl[i]->K; a.S = cl[i]->S; a.CO = cl[i]->CO;
+        a.OH = cl[i]->OH; a.OW = cl[i]->OW; a.pos_per_chunk = h->pos_per_chunk[i];
+        a.gin = *gact[i]; a.gd = *gdo[i]; a.in_C = cl[i]->CI;
+        if (i == 0) { a.KWe = 1; a.CIe = cl[i]->K * cl[i]->CI; } else { a.KWe = cl[i]->K; a.CIe = cl[i]->CI; }
+        a.n_items = (long)K * a.KH * a.KWe * a.npc;
+        const int nit = a.CIe / 32, not_ = a.CO / 32;
+        dim3 grid(cdiv(a.n_items, 4));
+        if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
+        else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
+        else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
+        else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
+        SlabReduceArgs r;
+        r.slab = h->slab; r.grad = h->grad; r.slab_stride = a.slab_stride; r.P = h->L.head_stride;
+        r.w_off = cl[i]->w_off; r.b_off = cl[i]->b_off; r.wsize = (long)a.KH * a.KWe * a.CIe * a.CO;
+        r.K = K; r.npc = a.npc; r.bsize = a.CO;
+        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(r.wsize + r.bsize, 256), K), dim3(256), 0, q, r);
+    }
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int step_epilogue(idqn_handle_s* h, bool bump, hipStream_t q) {
+    hipLaunchKernelGGL(k_step_epilogue, dim3(cdiv(h->cfg.n_heads, 64)), dim3(64), 0, q, h->count, h->losses, h->cum,
+                       h->cfg.n_heads, bump ? 1 : 0);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int idqn_layout(const idqn_config_t* cfg, int32_t* n_leaves, idqn_leaf_t* leaves, int64_t* head_stride) {
+    IDQN_REQUIRE(cfg && n_leaves && leaves && head_stride, "idqn_layout: null pointer");
+    Layout L;
+    int rc = build_layout(*cfg, L);
+    if (rc) return rc;
+    *n_leaves = L.n_leaves;
+    memcpy(leaves, L.leaves, sizeof(idqn_leaf_t) * L.n_leaves);
+    *head_stride = L.head_stride;
+    return IDQN_OK;
+}
+
+extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* target_dev, float* mu_dev, float* nu_dev,
+                           float* grad_dev, int32_t* count_dev, float* losses_dev, double* cum_losses_dev,
+                           idqn_handle_t* out) {
+    IDQN_REQUIRE(cfg && out, "idqn_create: null pointer");
+    IDQN_REQUIRE(online_dev && target_dev && mu_dev && nu_dev && grad_dev && count_dev && losses_dev && cum_losses_dev,
+                 "idqn_create: every arena pointer is required");
+    IDQN_REQUIRE(online_dev != target_dev, "idqn_create: online and target must be distinct buffers (the reference's "
+                                           "aliasing at idqn.py:56 is only safe for immutable arrays)");
+    int ndev = 0;
+    IDQN_HIP_CHECK(hipGetDeviceCount(&ndev));
+    IDQN_REQUIRE(ndev > 0, "idqn_create: no HIP device");
+    idqn_handle_s* h = new idqn_handle_s();
+    h->cfg = *cfg;
+    int rc = build_layout(*cfg, h->L);
+    if (rc) { delete h; return rc; }
+    h->online = online_dev; h->target = target_dev; h->mu = mu_dev; h->nu = nu_dev; h->grad = grad_dev;
+    h->count = count_dev; h->losses = losses_dev; h->cum = cum_losses_dev;
+    h->ad.lr_neg = (float)(-cfg->learning_rate);
+    h->ad.b1 = (float)cfg->adam_b1; h->ad.b2 = (float)cfg->adam_b2;
+    h->ad.omb1 = (float)(1.0 - cfg->adam_b1); h->ad.omb2 = (float)(1.0 - cfg->adam_b2);
+    h->ad.eps = (float)cfg->adam_eps;
+    h->gamma_n = (float)cfg->gamma_n;
+    h->nb_max = cdiv(cfg->max_batch, 32);
+    rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
+    if (rc) { idqn_destroy(h); return rc; }
+    h->ev.resize(2 * 2048);
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) { idqn_set_error("hipEventCreate failed"); idqn_destroy(h); return IDQN_E_HIP; }
+    IDQN_HIP_CHECK(hipDeviceSynchronize());
+    *out = h;
+    return IDQN_OK;
+}
+
+extern "C" int idqn_destroy(idqn_handle_t h) {
+    if (!h) return IDQN_OK;
+    (void)hipDeviceSynchronize();
+    for (void* p : h->owned) (void)hipFree(p);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete h;
+    return IDQN_OK;
+}
+
+extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
+                                   const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
+                                   int32_t batch, int32_t batch_mean_divisor, uint32_t flags, void* stream) {
+    IDQN_REQUIRE(h && state_dev && next_state_dev && action_dev && reward_dev && terminal_dev, "idqn_learn_on_batch: null pointer");
+    IDQN_REQUIRE(batch >= 1 && batch <= h->cfg.max_batch, "idqn_learn_on_batch: batch %d not in [1, %d]", batch, h->cfg.max_batch);
+    IDQN_REQUIRE(batch_mean_divisor >= batch, "idqn_learn_on_batch: mean divisor %d < batch %d", batch_mean_divisor, batch);
+    hipStream_t q = (hipStream_t)stream;
+    const bool grads_only = flags & IDQN_F_GRADS_ONLY, profile = flags & IDQN_F_PROFILE;
+    int rc;
+    if (h->cfg.arch == IDQN_ARCH_CNN) {
+        if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q))) return rc;
+        if ((rc = cnn_backward(h, action_dev, reward_dev, terminal_dev, batch, batch_mean_divisor, !grads_only, profile, q)))
+            return rc;
+        if (!grads_only) {
+            // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
+            const long w0_b = h->off_w0, w0_e = h->off_b0;
+            if ((rc = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, q))) return rc;
+        }
+    } else {
+        FcArgs a;
+        a.net = h->fc; a.online = h->online; a.target = h->target; a.grad = h->grad; a.P = h->L.head_stride;
+        a.s = (const float*)state_dev; a.s2 = (const float*)next_state_dev; a.action = action_dev; a.reward = reward_dev;
+        a.terminal = terminal_dev; a.gamma_n = h->gamma_n; a.B = batch; a.Bdiv = batch_mean_divisor; a.K = h->cfg.n_heads;
+        a.ws = h->fc_ws; a.losses = h->losses; a.q_dbg = h->qdbg;
+        if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
+        hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
+        if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
+            IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
+            h->ev_used += 2;
+        }
+        IDQN_HIP_CHECK(hipGetLastError());
+        if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, q))) return rc;
+    }
+    if (!grads_only) return step_epilogue(h, true, q);
+    return IDQN_OK;
+}
+
+extern "C" int idqn_apply_adam(idqn_handle_t h, void* stream) {
+    IDQN_REQUIRE(h, "idqn_apply_adam: null handle");
+    int rc = launch_adam(h, 0, h->L.head_stride, 0, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return step_epilogue(h, true, (hipStream_t)stream);
+}
+
+extern "C" int idqn_target_update(idqn_handle_t h, void* stream) {
+    IDQN_REQUIRE(h, "idqn_target_update: null handle");
+    hipStream_t q = (hipStream_t)stream;
+    const long P = h->L.head_stride;
+    const int K = h->cfg.n_heads;
+    // idqn.py:78  target_params = params.copy()  -- a real copy, BEFORE the shift (idqn.py:80)
+    IDQN_HIP_CHECK(hipMemcpyAsync(h->target, h->online, (size_t)K * P * 4, hipMemcpyDeviceToDevice, q));
+    // idqn.py:13-17  params[k] <- params[k+1]; ascending k so every source is read before it is overwritten
+    for (int k = 0; k + 1 < K; ++k)
+        IDQN_HIP_CHECK(hipMemcpyAsync(h->online + (long)k * P, h->online + (long)(k + 1) * P, (size_t)P * 4,
+                                      hipMemcpyDeviceToDevice, q));
+    return IDQN_OK;
+}
+
+extern "C" int idqn_target_sync(idqn_handle_t h, void* stream) {
+    IDQN_REQUIRE(h, "idqn_target_sync: null handle");
+    const long P = h->L.head_stride;
+    const int K = h->cfg.n_heads;
+    // idqn.py:20-24  target[k] <- params[k-1] for k >= 1; target[0] stays frozen
+    if (K > 1)
+        IDQN_HIP_CHECK(hipMemcpyAsync(h->target + P, h->online, (size_t)(K - 1) * P * 4, hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream));
+    return IDQN_OK;
+}
+
+extern "C" int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                             float* q_out_dev, void* stream) {
+    IDQN_REQUIRE(h && states_dev && q_out_dev, "idqn_q_values: null pointer");
+    IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_q_values: bad head / which");
+    IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_q_values: n = %d, must be in [1, 32]", n);
+    hipStream_t q = (hipStream_t)stream;
+    const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
+    if (h->cfg.arch == IDQN_ARCH_CNN) {
+        hipLaunchKernelGGL(k_set_ptr, dim3(1), dim3(1), 0, q, h->infer.wbase, params);
+        int rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q);
+        if (rc) return rc;
+        HeadQArgs a;
+        a.part = h->infer.part; a.wbase = h->infer.wbase; a.b0_off = h->off_b0; a.w1_off = h->off_w1; a.b1_off = h->off_b1;
+        a.NS = h->NS; a.J = h->J; a.A = h->cfg.n_actions; a.n = n; a.q_out = q_out_dev;
+        hipLaunchKernelGGL(k_head_q, dim3(1), dim3(256), h->head_lds, q, a);
+    } else {
+        FcQArgs a;
+        a.net = h->fc; a.params = params; a.s = (const float*)states_dev; a.n = n; a.q_out = q_out_dev;
+        a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
+        hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
+    }
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {
+    IDQN_REQUIRE(h && name && ptr_dev && nbytes, "idqn_debug_buffer: null pointer");
+    for (auto& e : h->dbg)
+        if (e.first == name) {
+            *ptr_dev = e.second.first;
+            *nbytes = e.second.second;
+            return IDQN_OK;
+        }
+    IDQN_REQUIRE(false, "idqn_debug_buffer: no buffer named '%s'", name);
+}
+
+extern "C" int idqn_profile_read(idqn_handle_t h, double* mean_ms, int32_t* n_launches, char* kernel_name) {
+    IDQN_REQUIRE(h && mean_ms && n_launches, "idqn_profile_read: null pointer");
+    double total = 0;
+    int n = h->ev_used / 2;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0;
+        IDQN_HIP_CHECK(hipEventSynchronize(h->ev[2 * i + 1]));
+        IDQN_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        total += ms;
+    }
+    *mean_ms = n ? total / n : 0.0;
+    *n_launches = n;
+    if (kernel_name) snprintf(kernel_name, 64, "%s", h->dominant);
+    h->ev_used = 0;
+    return IDQN_OK;
+}

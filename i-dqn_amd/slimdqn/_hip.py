@@ -1,0 +1,123 @@
+"""ctypes binding of libidqn_hip.so (include/idqn_hip.h) -- the only door to the device code.
+
+There is NO host fallback: if the shared library is missing or a call fails, this module raises.
+PyTorch-ROCm is used for device storage only (``tensor.data_ptr()``), never for arithmetic on the
+hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libidqn_hip.so")
+
+IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
+IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24
+F_GRADS_ONLY, F_PROFILE = 1, 2
+E_INVALID, E_HIP, E_RANGE, E_ASSERT = -1, -2, -3, -4
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("arch", C.c_int32), ("n_heads", C.c_int32), ("n_actions", C.c_int32),
+        ("obs_h", C.c_int32), ("obs_w", C.c_int32), ("obs_c", C.c_int32),
+        ("n_features", C.c_int32), ("features", C.c_int32 * IDQN_MAX_FEATURES),
+        ("max_batch", C.c_int32),
+        ("learning_rate", C.c_double), ("adam_b1", C.c_double), ("adam_b2", C.c_double), ("adam_eps", C.c_double),
+        ("gamma_n", C.c_double),
+    ]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("offset", C.c_int64), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+# every exported symbol of include/idqn_hip.h: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "idqn_last_error": (C.c_char_p, []),
+    "idqn_abi_version": (C.c_int, []),
+    "idqn_layout": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_int32), C.POINTER(Leaf), C.POINTER(C.c_int64)]),
+    "idqn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
+    "idqn_destroy": (C.c_int, [_P]),
+    "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "idqn_apply_adam": (C.c_int, [_P, _P]),
+    "idqn_target_update": (C.c_int, [_P, _P]),
+    "idqn_target_sync": (C.c_int, [_P, _P]),
+    "idqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
+    "idqn_debug_buffer": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "idqn_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p]),
+    "sumtree_set": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
+    "sumtree_get": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P]),
+    "sumtree_query": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    "replay_gather": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P]),
+    "replay_gather_scalars": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the extension (once).  Raises HipExtensionError if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    """Maps C return codes to the exception types the reference raises."""
+    if rc == 0:
+        return
+    msg = lib().idqn_last_error().decode(errors="replace")
+    if rc == E_RANGE:
+        raise ValueError(msg or what)
+    if rc == E_ASSERT:
+        raise AssertionError(msg or what)
+    raise HipExtensionError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """Device address of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(arch, n_heads, n_actions, obs, features, max_batch, lr, eps, gamma_n, b1=0.9, b2=0.999):
+    cfg = Config()
+    cfg.arch = {"cnn": IDQN_ARCH_CNN, "fc": IDQN_ARCH_FC}[arch]
+    cfg.n_heads, cfg.n_actions = int(n_heads), int(n_actions)
+    cfg.obs_h, cfg.obs_w, cfg.obs_c = (int(x) for x in obs)
+    cfg.n_features = len(features)
+    for i, f in enumerate(features):
+        cfg.features[i] = int(f)
+    cfg.max_batch = int(max_batch)
+    cfg.learning_rate, cfg.adam_b1, cfg.adam_b2, cfg.adam_eps, cfg.gamma_n = float(lr), b1, b2, float(eps), float(gamma_n)
+    return cfg
+
+
+def layout(cfg):
+    """[(name, offset, shape)], head_stride -- needs no GPU."""
+    n = C.c_int32()
+    leaves = (Leaf * IDQN_MAX_LEAVES)()
+    stride = C.c_int64()
+    check(lib().idqn_layout(C.byref(cfg), C.byref(n), leaves, C.byref(stride)), "idqn_layout")
+    out = [(leaves[i].name.decode(), int(leaves[i].offset), tuple(int(s) for s in leaves[i].shape[: leaves[i].ndim]))
+           for i in range(n.value)]
+    return out, int(stride.value)

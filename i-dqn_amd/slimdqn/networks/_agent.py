@@ -1,0 +1,177 @@
+"""Device state shared by ``iDQN`` and ``DQN``: parameter arenas in HBM + the C-ABI handle.
+
+All arithmetic of the gradient step runs in ``libidqn_hip.so``; torch tensors are storage.
+Arenas are ``[K][head_stride]`` float32; ``params`` / ``target_params`` / ``optimizer_state`` are
+pytrees of VIEWS into them with the flax leaf names of the reference
+(``{"params": {"Conv_0": {"kernel", "bias"}, ...}}``, leading K axis for iDQN -- idqn.py:48-50).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from slimdqn import _hip, prng
+from slimdqn.networks.architectures.dqn import DQNNet
+
+
+def _obs_triplet(observation_dim, arch):
+    if isinstance(observation_dim, (int, np.integer)):
+        return (int(observation_dim), 1, 1)
+    dims = tuple(int(d) for d in observation_dim)
+    if arch == "cnn":
+        assert len(dims) == 3, "cnn expects observation_dim = (H, W, C)"
+        return dims
+    return (int(np.prod(dims)), 1, 1)
+
+
+class DeviceAgent:
+    def __init__(self, key, observation_dim, n_actions, n_heads, features, architecture_type, learning_rate, gamma,
+                 update_horizon, adam_eps, stacked):
+        self.network = DQNNet(features, architecture_type, n_actions)
+        self._K = int(n_heads)
+        self._stacked = stacked  # iDQN leaves carry a leading K axis, DQN leaves do not
+        self._arch = architecture_type
+        self._obs = _obs_triplet(observation_dim, architecture_type)
+        self._lr, self._eps = float(learning_rate), float(adam_eps)
+        self.gamma, self.update_horizon = gamma, update_horizon
+        self._gamma_n = float(gamma) ** update_horizon  # a Python double, folded like idqn.py:122
+        _hip.lib()  # fail loudly (HipExtensionError) before any allocation if the extension is missing
+        if not torch.cuda.is_available():
+            raise _hip.HipExtensionError("no HIP device visible: the i-DQN step has no CPU path")
+        self._leaves, self._P = _hip.layout(self._config(32))
+        K, P = self._K, self._P
+        dev = "cuda"
+        self._online = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        self._target = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        self._mu = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        self._nu = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        self._grad = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        self._count = torch.zeros(K, dtype=torch.int32, device=dev)
+        self._losses = torch.zeros(K, dtype=torch.float32, device=dev)
+        self._cum = torch.zeros(K, dtype=torch.float64, device=dev)
+        self._handle, self._handle_batch = None, 0
+        self._q_out = torch.zeros((32, n_actions), dtype=torch.float32, device=dev)
+        # initial parameters (idqn.py:48-50 / dqn.py:29); target starts equal to online (idqn.py:56)
+        rng = prng.generator(key)
+        host = np.zeros((K, P), np.float32)
+        for name, off, shape in self._leaves:
+            host[:, off : off + int(np.prod(shape))] = self.network.init_leaf(rng, name, shape, K).reshape(K, -1)
+        self._online.copy_(torch.from_numpy(host))
+        self._target.copy_(self._online)
+        self.params = self._tree(self._online)
+        self.target_params = self._tree(self._target)
+        self.optimizer_state = {"mu": self._tree(self._mu), "nu": self._tree(self._nu), "count": self._count}
+
+    # ---- plumbing ----------------------------------------------------------------------------------
+    def _config(self, max_batch):
+        return _hip.make_config(self._arch, self._K, self.network.n_actions, self._obs, self.network.features,
+                                max_batch, self._lr, self._eps, self._gamma_n)
+
+    def _tree(self, arena):
+        tree = {}
+        for name, off, shape in self._leaves:
+            mod, leaf = name.split("/")
+            view = arena[:, off : off + int(np.prod(shape))].view((self._K,) + tuple(shape))
+            tree.setdefault(mod, {})[leaf] = view if self._stacked else view[0]
+        return {"params": tree}
+
+    def _ensure_handle(self, batch):
+        if self._handle is not None and batch <= self._handle_batch:
+            return
+        self._destroy_handle()
+        cfg = self._config(max(batch, 32))
+        h = C.c_void_p()
+        _hip.check(_hip.lib().idqn_create(C.byref(cfg), _hip.ptr(self._online), _hip.ptr(self._target),
+                                          _hip.ptr(self._mu), _hip.ptr(self._nu), _hip.ptr(self._grad),
+                                          _hip.ptr(self._count), _hip.ptr(self._losses), _hip.ptr(self._cum),
+                                          C.byref(h)), "idqn_create")
+        self._handle, self._handle_batch = h, max(batch, 32)
+
+    def _destroy_handle(self):
+        if getattr(self, "_handle", None) is not None:
+            _hip.lib().idqn_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy_handle()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _dev(x, dtype):
+        t = getattr(x, "tensor", x)
+        if not isinstance(t, torch.Tensor):
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(t)))
+        return t.to(device="cuda", dtype=dtype).contiguous()
+
+    # ---- the step ------------------------------------------------------------------------------------
+    def _learn(self, batch, flags=0, mean_divisor=None):
+        """One gradient step on a ReplayElement-like batch; returns the per-head losses (device, [K])."""
+        if self._arch == "cnn":
+            s, s2 = self._dev(batch.state, torch.uint8), self._dev(batch.next_state, torch.uint8)
+            assert tuple(s.shape[1:]) == self._obs, f"state shape {tuple(s.shape)} vs observation_dim {self._obs}"
+        else:
+            s, s2 = self._dev(batch.state, torch.float32), self._dev(batch.next_state, torch.float32)
+            assert int(np.prod(s.shape[1:])) == self._obs[0], f"state shape {tuple(s.shape)} vs dim {self._obs[0]}"
+        B = int(s.shape[0])
+        a = self._dev(batch.action, torch.int32)
+        r = self._dev(batch.reward, torch.float32)
+        t = self._dev(batch.is_terminal, torch.uint8)
+        assert a.numel() == B and r.numel() == B and t.numel() == B
+        self._ensure_handle(B)
+        self._keep = (s, s2, a, r, t)  # keep inputs alive until the stream has consumed them
+        _hip.check(_hip.lib().idqn_learn_on_batch(self._handle, _hip.ptr(s), _hip.ptr(s2), _hip.ptr(a), _hip.ptr(r),
+                                                  _hip.ptr(t), B, int(mean_divisor or B), int(flags),
+                                                  _hip.current_stream()), "idqn_learn_on_batch")
+        return self._losses
+
+    def _apply_adam(self):
+        _hip.check(_hip.lib().idqn_apply_adam(self._handle, _hip.current_stream()), "idqn_apply_adam")
+
+    def _q_values(self, which, head, state):
+        """Q-values [n, A] (device) of one head for <= 32 states."""
+        dt = torch.uint8 if self._arch == "cnn" else torch.float32
+        s = self._dev(state, dt)
+        n = 1 if s.numel() == int(np.prod(self._obs)) else int(s.shape[0])
+        self._ensure_handle(32)
+        self._keep_q = s
+        _hip.check(_hip.lib().idqn_q_values(self._handle, int(which), int(head), _hip.ptr(s), n, _hip.ptr(self._q_out),
+                                            _hip.current_stream()), "idqn_q_values")
+        return self._q_out[:n]
+
+    def _debug(self, name):
+        """Internal activation buffer as a flat float32 device tensor (tests only)."""
+        p, nbytes = C.c_void_p(), C.c_int64()
+        _hip.check(_hip.lib().idqn_debug_buffer(self._handle, name.encode(), C.byref(p), C.byref(nbytes)), name)
+        out = torch.empty(nbytes.value // 4, dtype=torch.float32, device="cuda")
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(nbytes.value), 3)
+        return out
+
+    def _numpy_tree(self, arena):
+        host = arena.cpu().numpy()
+        tree = {}
+        for name, off, shape in self._leaves:
+            mod, leaf = name.split("/")
+            v = host[:, off : off + int(np.prod(shape))].reshape((self._K,) + tuple(shape)).copy()
+            tree.setdefault(mod, {})[leaf] = v if self._stacked else v[0]
+        return {"params": tree}
+
+    def _load_flat(self, arena, flat):
+        """flat: {"Conv_0/kernel": array [K, ...]} -> arena (fixture injection in tests)."""
+        host = arena.cpu().numpy()
+        for name, off, shape in self._leaves:
+            v = np.asarray(flat[name], np.float32)
+            if not self._stacked and v.shape == tuple(shape):
+                v = v[None]
+            host[:, off : off + int(np.prod(shape))] = v.reshape(self._K, -1)
+        arena.copy_(torch.from_numpy(host))
+
+    def _flat(self, arena):
+        host = arena.cpu().numpy()
+        return {name: host[:, off : off + int(np.prod(shape))].reshape((self._K,) + tuple(shape)).copy()
+                for name, off, shape in self._leaves}
+
+    def get_model(self):
+        """Picklable ``{"params": pytree of numpy arrays}`` (idqn.py:133-134, experiments/base/utils.py:134)."""
+        return self._numpy_tree(self._online)

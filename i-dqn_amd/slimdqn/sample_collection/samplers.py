@@ -1,0 +1,105 @@
+"""Sampling distributions: host index maps + numpy PCG64 stream, priorities in the HBM sum tree.
+
+Drop-in for the reference's ``slimdqn/sample_collection/samplers.py``.  What stays on the host is
+exactly what is integer bookkeeping in the reference too: the dense ``index -> key`` array with
+swap-remove (``samplers.py:26-37``) and the ``numpy.random.Generator`` whose stream defines the
+sampled indices (``:17,43,110``) -- keeping numpy's generator IS bit-parity of the index stream.
+Priorities and the inverse-CDF query run on the device (``sum_tree.SumTree``).
+"""
+import numpy as np
+
+from slimdqn.sample_collection import ReplayItemID, sum_tree
+
+
+class IndexMap:
+    """Dense local index <-> replay key map with O(1) swap-remove (pure host logic, no GPU)."""
+
+    def __init__(self) -> None:
+        self.key_to_index = {}
+        self.index_to_key = []
+
+    def __len__(self) -> int:
+        return len(self.index_to_key)
+
+    def add(self, key) -> int:
+        self.key_to_index[key] = len(self.index_to_key)
+        self.index_to_key.append(key)
+        return len(self.index_to_key) - 1
+
+    def remove(self, key):
+        """Returns (hole, last): the index freed and the index whose entry moved into it."""
+        assert key in self.key_to_index, ValueError(f"Key {key} not found.")
+        hole = self.key_to_index.pop(key)
+        last = len(self.index_to_key) - 1
+        moved = self.index_to_key.pop()
+        if moved != key:
+            self.index_to_key[hole] = moved
+            self.key_to_index[moved] = hole
+        return hole, last
+
+    def keys_at(self, indices) -> np.ndarray:
+        table = self.index_to_key
+        return np.fromiter((table[i] for i in indices), dtype=np.int32, count=len(indices))
+
+
+class UniformSamplingDistribution:
+    """samplers.py:13-49."""
+
+    def __init__(self, seed: int) -> None:
+        self._rng_key = np.random.default_rng(seed)
+        self._map = IndexMap()
+
+    # attribute names the reference's tests reach into (tests/test_replay_buffer.py:161,246-273)
+    _key_to_index = property(lambda self: self._map.key_to_index)
+    _index_to_key = property(lambda self: self._map.index_to_key)
+
+    def add(self, key: ReplayItemID) -> None:
+        self._map.add(key)
+
+    def remove(self, key: ReplayItemID) -> None:
+        self._map.remove(key)
+
+    def sample(self, size: int):
+        assert self._map.index_to_key, ValueError("No keys to sample from.")
+        return self._map.keys_at(self._rng_key.integers(len(self._map), size=size))
+
+
+class PrioritizedSamplingDistribution(UniformSamplingDistribution):
+    """samplers.py:52-116, with the sum tree in HBM."""
+
+    def __init__(self, seed: int, max_capacity: int, priority_exponent: float = 1.0) -> None:
+        self._max_capacity = max_capacity
+        self._priority_exponent = priority_exponent
+        self._sum_tree = sum_tree.SumTree(self._max_capacity)
+        super().__init__(seed=seed)
+
+    def add(self, key: ReplayItemID, priority: float) -> None:
+        index = self._map.add(key)
+        if priority is None:
+            priority = 0.0
+        self._sum_tree.set(index, 0.0 if priority == 0.0 else priority**self._priority_exponent)
+
+    def update(self, keys, priorities) -> None:
+        if not isinstance(keys, np.ndarray):
+            keys = np.asarray([keys], dtype=np.int32)
+        shaped = np.where(priorities == 0.0, 0.0, priorities**self._priority_exponent)
+        local = np.fromiter((self._map.key_to_index[k] for k in keys), dtype=np.int32)
+        self._sum_tree.set(local, shaped)
+
+    def remove(self, key: ReplayItemID) -> None:
+        hole = self._map.key_to_index[key]
+        last = len(self._map) - 1
+        if hole == last:
+            self._sum_tree.set(hole, 0.0)
+        else:  # the last entry's priority moves into the hole, one two-element set (samplers.py:98-102)
+            self._sum_tree.set(np.asarray([hole, last], dtype=np.int32),
+                               np.asarray([self._sum_tree.get(last), 0.0]))
+        self._map.remove(key)
+
+    def sample(self, size: int):
+        root = self._sum_tree.root
+        if root == 0.0:
+            # the reference's branch here is `super().sample(size).keys` -> AttributeError (samplers.py:106-108)
+            raise AttributeError("'numpy.ndarray' object has no attribute 'keys'")
+        targets = self._rng_key.uniform(0.0, root, size=size)
+        return self._map.keys_at(self._sum_tree.query(targets))

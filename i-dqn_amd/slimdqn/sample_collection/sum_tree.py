@@ -1,0 +1,100 @@
+"""Sum tree whose node array lives in HBM (fp64), driven through the C ABI.
+
+Drop-in for the reference's ``slimdqn/sample_collection/sum_tree.py:8-102`` (same constructor,
+``set`` / ``get`` / ``root`` / ``query`` / ``max_recorded_priority``, same exception types).  The
+arithmetic -- including the order of the fp64 additions, which the reference inherits from
+``np.unique`` + ``np.add.at`` -- runs in ``csrc/sumtree.hip``; this file only validates arguments,
+moves the (tiny) index / value vectors to the device and maps status codes to exceptions.
+"""
+import math
+
+import numpy as np
+import torch
+
+from slimdqn import _hip
+
+_MAX_SET = 4096
+
+
+class SumTree:
+    def __init__(self, capacity: int) -> None:
+        assert capacity > 0, "Capacity to sum tree must be positive."
+        self._capacity = capacity
+        self._depth = int(math.ceil(math.log2(capacity))) + 1
+        self._first_leaf_offset = (2 ** (self._depth - 1)) - 1
+        _hip.lib()  # fail loudly before touching the GPU if the extension is not built
+        self._nodes_dev = torch.zeros((2**self._depth) - 1, dtype=torch.float64, device="cuda")
+        self._scratch = torch.empty(_MAX_SET * 2, dtype=torch.float64, device="cuda")
+        self._status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.max_recorded_priority = 1.0
+
+    # the reference's tests read ``_nodes`` directly (tests/test_sum_tree.py:34-37)
+    @property
+    def _nodes(self) -> np.ndarray:
+        return self._nodes_dev.cpu().numpy()
+
+    def _launch_set(self, idx: np.ndarray, val: np.ndarray) -> None:
+        i_dev = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).cuda()
+        v_dev = torch.from_numpy(np.ascontiguousarray(val, dtype=np.float64)).cuda()
+        _hip.check(
+            _hip.lib().sumtree_set(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(i_dev), _hip.ptr(v_dev),
+                                   int(idx.size), _hip.ptr(self._scratch), _hip.current_stream()),
+            "sumtree_set")
+
+    def set(self, indices, values) -> None:
+        if isinstance(indices, (int, np.integer)):
+            indices = np.asarray([indices], np.int32)
+        if isinstance(values, (int, float, np.floating)):
+            values = np.asarray([values], np.float64)
+        indices, values = np.asarray(indices), np.asarray(values)
+        assert indices.shape == values.shape, "Indices and values must have the same shape."
+        assert (values >= 0.0).all(), "Values must be positive."
+        if indices.size == 0:
+            return
+        if ((indices < 0) | (indices >= self._nodes_dev.numel() - self._first_leaf_offset)).any():
+            raise IndexError("sum tree index out of range")
+        self.max_recorded_priority = max(self.max_recorded_priority, max(values))
+        idx = indices.reshape(-1).astype(np.int32)
+        val = values.reshape(-1).astype(np.float64)  # f32 -> f64 is exact, as in `values - nodes[...]`
+        if idx.size <= _MAX_SET:
+            self._launch_set(idx, val)
+            return
+        # rare: more than one workgroup's worth.  De-duplicate here (first occurrence wins, ascending
+        # leaves) and feed ascending chunks; every node then still accumulates in ascending-leaf order.
+        uniq, first = np.unique(idx, return_index=True)
+        for lo in range(0, uniq.size, _MAX_SET):
+            self._launch_set(uniq[lo : lo + _MAX_SET], val[first[lo : lo + _MAX_SET]])
+
+    def get(self, index):
+        if isinstance(index, (int, np.integer)):
+            return float(self._nodes_dev[self._first_leaf_offset + int(index)].item())
+        idx = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32).reshape(-1)).cuda()
+        out = torch.empty(idx.numel(), dtype=torch.float64, device="cuda")
+        _hip.check(_hip.lib().sumtree_get(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(idx), idx.numel(),
+                                          _hip.ptr(out), _hip.current_stream()), "sumtree_get")
+        return out.cpu().numpy().reshape(np.shape(index))
+
+    @property
+    def root(self) -> float:
+        return float(self._nodes_dev[0].item())
+
+    def query_device(self, targets_dev: torch.Tensor) -> torch.Tensor:
+        """Device-to-device query (no host sync): int32 leaf indices; status bits land in ``_status``."""
+        out = torch.empty(targets_dev.numel(), dtype=torch.int32, device="cuda")
+        _hip.check(_hip.lib().sumtree_query(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(targets_dev),
+                                            targets_dev.numel(), _hip.ptr(out), _hip.ptr(self._status),
+                                            _hip.current_stream()), "sumtree_query")
+        return out
+
+    def query(self, targets):
+        if isinstance(targets, (int, float)):
+            targets = np.asarray([targets], np.float64)
+        targets = np.asarray(targets)
+        t_dev = torch.from_numpy(np.ascontiguousarray(targets.reshape(-1), dtype=np.float64)).cuda()
+        self._status.zero_()
+        out = self.query_device(t_dev).cpu().numpy().reshape(targets.shape)
+        status = int(self._status.item())
+        if status & 1:
+            raise ValueError(f"Targets must be in the interval [0.0, {self.root}).")
+        assert not (status & 2), "sum tree traversal: target not below its node (sum_tree.py:81)"
+        return out

@@ -1,0 +1,147 @@
+/*
+ * idqn_hip.h -- C ABI of the MI355X-native i-DQN hot path (libidqn_hip.so, gfx950 only).
+ *
+ * Plain pointers and sizes only; every pointer marked "dev" is a device (HBM) address, every
+ * `stream` is a hipStream_t passed as void*.  All functions return 0 on success or a negative
+ * IDQN_E_* code; nothing here falls back to a host implementation.
+ *
+ * The reference (theovincent/i-DQN) has no FFI: its seam is the Python object protocol used by
+ * experiments/base/dqn.py.  Each entry point below names the reference operation it replaces
+ * (file:line under the reference root); the Python mirror in i-dqn_amd/slimdqn binds them with
+ * ctypes.
+ */
+#ifndef IDQN_HIP_H
+#define IDQN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDQN_OK 0
+#define IDQN_E_INVALID (-1)     /* bad argument / unsupported shape (message via idqn_last_error) */
+#define IDQN_E_HIP (-2)         /* a HIP runtime call failed */
+#define IDQN_E_RANGE (-3)       /* sumtree_query: a target is outside [0, root)   -> ValueError   */
+#define IDQN_E_ASSERT (-4)      /* reference `assert` would have fired            -> AssertionError */
+
+#define IDQN_ARCH_CNN 0         /* slimdqn/networks/architectures/dqn.py:39-53 */
+#define IDQN_ARCH_FC 1          /* slimdqn/networks/architectures/dqn.py:61-63 */
+#define IDQN_MAX_FEATURES 8
+#define IDQN_MAX_LEAVES 24
+
+const char* idqn_last_error(void);
+int idqn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Q-network / agent state.  Replaces iDQN.__init__ (slimdqn/networks/idqn.py:28-63) and
+ * DQN.__init__ (slimdqn/networks/dqn.py:14-39) as far as device state goes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct idqn_config {
+    int32_t arch;                         /* IDQN_ARCH_*                                        */
+    int32_t n_heads;                      /* K  (n_networks, idqn.py:44; 1 for DQN)              */
+    int32_t n_actions;                    /* A <= 32                                            */
+    int32_t obs_h, obs_w, obs_c;          /* cnn: (84, 84, 4); fc: (dim, 1, 1)                    */
+    int32_t n_features;
+    int32_t features[IDQN_MAX_FEATURES];  /* cnn: [F0, F1, F2, F3]; fc: hidden widths            */
+    int32_t max_batch;                    /* largest minibatch a call may pass                   */
+    /* doubles: folded to f32 inside exactly like the reference's Python floats are by jit        */
+    double learning_rate;                 /* optax.adam(lr, eps=adam_eps), idqn.py:52            */
+    double adam_b1, adam_b2, adam_eps;
+    double gamma_n;                       /* gamma ** update_horizon (a Python double), idqn.py:122 */
+} idqn_config_t;
+
+typedef struct idqn_leaf {
+    char name[32];        /* flax leaf path, e.g. "Conv_0/kernel" (idqn.py:48-50 pytree)        */
+    int64_t offset;       /* float offset of the leaf inside one head's slice of an arena        */
+    int32_t ndim;
+    int64_t shape[4];     /* per-head shape (HWIO for conv kernels, [in,out] for dense)          */
+} idqn_leaf_t;
+
+/* Arena layout: every parameter-like array (online, target, mu, nu, grad) is [K][head_stride]
+ * floats; head k, leaf l lives at arena + k*head_stride + leaf[l].offset.                        */
+int idqn_layout(const idqn_config_t* cfg, int32_t* n_leaves, idqn_leaf_t* leaves /*[IDQN_MAX_LEAVES]*/,
+                int64_t* head_stride);
+
+typedef struct idqn_handle_s* idqn_handle_t;
+
+/* The caller (PyTorch-ROCm tensors, storage only) owns the arenas; the handle owns activations
+ * and scratch.  count: optax step counter per head (int32, idqn.py:53); losses: per-head loss of
+ * the last step (idqn.py:109); cum_losses: f64 running sum == `cumulated_losses += losses`
+ * (idqn.py:72) kept on the device so that no per-step host sync is needed.                        */
+int idqn_create(const idqn_config_t* cfg, float* online_dev, float* target_dev, float* mu_dev, float* nu_dev,
+                float* grad_dev, int32_t* count_dev, float* losses_dev, double* cum_losses_dev,
+                idqn_handle_t* out);
+int idqn_destroy(idqn_handle_t h);
+
+/* flags for idqn_learn_on_batch */
+#define IDQN_F_GRADS_ONLY 1u   /* stop after the gradients are in grad_dev (data-parallel: all-reduce, then idqn_apply_adam) */
+#define IDQN_F_PROFILE 2u      /* bracket the dominant kernel with hipEvents (see idqn_profile_read) */
+
+/* iDQN.learn_on_batch (idqn.py:96-109) == DQN.learn_on_batch (dqn.py:60-73) for K == 1:
+ * 2K forwards, TD target (idqn.py:120-124), squared loss mean over the batch (idqn.py:111-118),
+ * K backwards, Adam, count += 1, losses written, cum_losses accumulated.
+ * state / next_state: cnn: uint8 [B][H][W][C] (NHWC, the reference's stacked batch, replay_buffer.py:229);
+ *                     fc : float32 [B][dim].
+ * batch_mean_divisor: the B of the `.mean()` -- pass the GLOBAL batch size when the minibatch is
+ * sharded over ranks so that summed shard gradients equal the full-batch gradient.                */
+int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
+                        const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
+                        int32_t batch, int32_t batch_mean_divisor, uint32_t flags, void* stream);
+/* Second half of the data-parallel step: Adam from grad_dev, count += 1. */
+int idqn_apply_adam(idqn_handle_t h, void* stream);
+
+/* iDQN.update_target_params, T-step (idqn.py:78-80): target <- online (a REAL copy; the reference
+ * aliases immutable arrays), then online[k] <- online[k+1] for k < K-1.  Adam state is not shifted. */
+int idqn_target_update(idqn_handle_t h, void* stream);
+/* D-step, sync_target_params (idqn.py:20-24,92): target[k] <- online[k-1] for k >= 1.              */
+int idqn_target_sync(idqn_handle_t h, void* stream);
+
+/* network.apply(params[head], states) (idqn.py:131, dqn.py:90): Q-values of one head for n <= 32
+ * states; which = 0 online / 1 target.  q_out_dev: float32 [n][A].                                 */
+int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                  float* q_out_dev, void* stream);
+
+/* Test / debug access to internal activation buffers by name (device pointer + byte size).        */
+int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes);
+/* Mean duration (ms) and launch count of the dominant kernel over the IDQN_F_PROFILE calls since
+ * the last read; synchronises the events it reads.                                                 */
+int idqn_profile_read(idqn_handle_t h, double* mean_ms, int32_t* n_launches, char* kernel_name /*[64]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * Sum tree (slimdqn/sample_collection/sum_tree.py).  nodes_dev: float64 [2**depth - 1] in HBM,
+ * depth = ceil(log2(capacity)) + 1, first leaf at 2**(depth-1) - 1 (sum_tree.py:14-17).
+ * ---------------------------------------------------------------------------------------- */
+/* SumTree.set (sum_tree.py:20-47): deltas against the current leaves BEFORE de-duplication, first
+ * occurrence of a duplicate wins, per-level sequential accumulation in ascending node order
+ * (bit-exact with np.add.at).  n <= 4096.  scratch_dev: >= 16 * 4096 bytes.                        */
+int sumtree_set(double* nodes_dev, int32_t depth, const int32_t* indices_dev, const double* values_dev,
+                int32_t n, void* scratch_dev, void* stream);
+/* SumTree.get (sum_tree.py:49-51) */
+int sumtree_get(const double* nodes_dev, int32_t depth, const int32_t* indices_dev, int32_t n,
+                double* out_dev, void* stream);
+/* SumTree.query (sum_tree.py:58-102).  status_dev[0] |= 1 if a target is outside [0, root)
+ * (-> ValueError, :73-74), |= 2 if the per-level invariant `target < node` fails (-> the reference's
+ * assert at :81).  out_dev: int32 leaf indices.                                                     */
+int sumtree_query(const double* nodes_dev, int32_t depth, const double* targets_dev, int32_t n,
+                  int32_t* out_dev, int32_t* status_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Replay store in HBM (slimdqn/sample_collection/replay_buffer.py:202-230).  One slot holds one
+ * ReplayElement's state and next_state back to back: [2][obs_bytes]; slot = key % capacity (keys
+ * are the monotonically increasing add_count and eviction is FIFO, :206-213).
+ * ---------------------------------------------------------------------------------------- */
+/* ReplayBuffer.sample's gather + np.stack (replay_buffer.py:223-229): copies the sampled slots'
+ * state / next_state into contiguous [n][obs_bytes] batches.                                       */
+int replay_gather(const uint8_t* store_dev, int64_t obs_bytes, const int32_t* slots_dev, int32_t n,
+                  uint8_t* state_out_dev, uint8_t* next_state_out_dev, void* stream);
+/* Gather of the per-slot scalars kept as arrays [capacity]: action i32, reward f32, terminal u8.   */
+int replay_gather_scalars(const int32_t* action_store_dev, const float* reward_store_dev,
+                          const uint8_t* terminal_store_dev, const int32_t* slots_dev, int32_t n,
+                          int32_t* action_out_dev, float* reward_out_dev, uint8_t* terminal_out_dev,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDQN_HIP_H */

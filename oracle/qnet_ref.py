@@ -153,8 +153,9 @@ def forward(p, x, arch, dtype=np.float64, keep=False):
     return (a, tape) if keep else a
 
 
-def backward(p, tape, dq, dtype=np.float64):
-    """Gradients of every leaf of one head given dL/dQ [B, A]."""
+def backward(p, tape, dq, dtype=np.float64, trace=None):
+    """Gradients of every leaf of one head given dL/dQ [B, A].  trace (optional dict) receives the
+    gradient w.r.t. every layer's pre-activation ("d_dense{i}", "d_conv{i}")."""
     grads = {}
     d = dq
     n_dense = sum(1 for t in tape if t[0] == "dense")
@@ -162,12 +163,16 @@ def backward(p, tape, dq, dtype=np.float64):
         if kind == "dense":
             if li != n_dense - 1:
                 d = d * (out > 0)
+            if trace is not None:
+                trace[f"d_dense{li}"] = d
             w = p[f"Dense_{li}/kernel"].astype(dtype)
             grads[f"Dense_{li}/kernel"] = inp.T @ d
             grads[f"Dense_{li}/bias"] = d.sum(0)
             d = d @ w.T
         else:
             d = d.reshape(out.shape) * (out > 0)
+            if trace is not None:
+                trace[f"d_conv{li}"] = d
             w = p[f"Conv_{li}/kernel"].astype(dtype)
             k, s = CNN_GEOM[li]
             dx, dw, db = conv_bwd(inp, cols, w, s, d, need_dx=(li > 0))
@@ -195,8 +200,9 @@ def loss_and_grads(p_online, p_target, batch, arch, gamma_n, dtype=np.float64):
     loss = (td * td).mean()
     dq = np.zeros_like(q)
     dq[np.arange(bsz), action] = 2.0 * td / bsz
-    grads = backward(p_online, tape, dq, dtype)
-    return loss, grads, {"q": q, "q_next": q_next, "target": tgt, "td": td, "tape": tape}
+    trace = {}
+    grads = backward(p_online, tape, dq, dtype, trace)
+    return loss, grads, {"q": q, "q_next": q_next, "target": tgt, "td": td, "tape": tape, "trace": trace}
 
 
 def adam_update(theta, g, m, v, count, lr, eps, dtype=np.float64):

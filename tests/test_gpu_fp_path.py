@@ -1,0 +1,259 @@
+"""GPU parity of the HIP gradient step (through the C ABI) against the oracle and the committed goldens.
+
+Bars (north_star): per-head TD loss within 1e-5 of the fp64 oracle; gradients / parameters to fp32
+accumulation accuracy.  fp goldens are NOT reference-captured (oracle/__init__.py: parity unpinned).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOSS_ATOL = 1e-5  # north_star: fp32 loss within 1e-5
+
+
+def _case(name):
+    from oracle import make_golden as G
+
+    arch, obs, A, feats, K, B, steps = G.FP_CASES[name]
+    p, pt, batches = G.fp_case_inputs(name)
+    rec = json.load(open(os.path.join(GOLDEN, f"fp_path_{name}.json")))
+    return arch, obs, A, feats, K, B, steps, p, pt, batches, rec
+
+
+def _agent(name):
+    from collections import namedtuple
+
+    from slimdqn.networks.idqn import iDQN
+
+    arch, obs, A, feats, K, B, steps, p, pt, batches, rec = _case(name)
+    h = rec["hyper"]
+    agent = iDQN(0, obs, A, K, feats, arch, h["lr"], h["gamma"], h["n"], 1, 10**9, 10**9, adam_eps=h["eps"])
+    agent._load_flat(agent._online, p)
+    agent._load_flat(agent._target, pt)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    bs = [Batch(s, a, r, s2, t) for (s, a, r, s2, t) in batches]
+    return agent, bs, rec, (arch, obs, A, feats, K, B, steps, p, pt, batches)
+
+
+def _unpack_act(buf, n_slots, slot, H, W, C, lo_h, lo_w, Hp, Wp):
+    """device [slot][Hp*Wp*C][32] -> numpy [32, H, W, C]"""
+    a = buf.cpu().numpy()[: n_slots * Hp * Wp * C * 32].reshape(n_slots, Hp, Wp, C, 32)[slot]
+    return a[lo_h : lo_h + H, lo_w : lo_w + W].transpose(3, 0, 1, 2)
+
+
+def _dgrad_pad(I, O, K, S, PL):
+    mn, mx = 0, O - 1
+    for i in range(I):
+        for k in range(K):
+            t = i + PL - k
+            if t % S:
+                continue
+            o = t // S
+            mn, mx = min(mn, o), max(mx, o)
+    return -mn, mx - (O - 1)
+
+
+def _relerr(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5"])
+def test_cnn_every_stage_against_oracle(name):
+    """Forward activations, Q-values, every backward intermediate and every leaf gradient, stage by stage."""
+    import torch
+
+    from oracle import qnet_ref as Q
+    from slimdqn import _hip
+
+    agent, bs, rec, (arch, obs, A, feats, K, B, steps, p, pt, batches) = _agent(name)
+    losses = agent._learn(bs[0], flags=_hip.F_GRADS_ONLY).cpu().numpy()
+    torch.cuda.synchronize()
+    nb = (B + 31) // 32
+    # geometry (same rules as csrc/qnet.hip)
+    H, W, C = obs
+    geo = []
+    for (k, s), f in zip(Q.CNN_GEOM, feats[:3]):
+        oh, lh, hh = Q.same_pad(H, k, s)
+        ow, lw, hw = Q.same_pad(W, k, s)
+        geo.append(dict(IH=H, IW=W, CI=C, OH=oh, OW=ow, CO=f, lo_h=lh, hi_h=hh, lo_w=lw, hi_w=hw, k=k, s=s))
+        H, W, C = oh, ow, f
+    g_hat = rec["hyper"]["gamma"] ** rec["hyper"]["n"]
+    errs = {}
+    for k in range(K):
+        loss, grads, aux = Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), batches[0], arch, g_hat)
+        assert abs(losses[k] - loss) <= LOSS_ATOL, (k, losses[k], loss)
+        tape = aux["tape"]
+        # forward activations of the online net k (slot k*nb + 0)
+        for li, bufname in enumerate(["a1", "a2", "a3"]):
+            if li < 2:
+                gi = geo[li + 1]
+                Hp, Wp = gi["IH"] + gi["lo_h"] + gi["hi_h"], gi["IW"] + gi["lo_w"] + gi["hi_w"]
+                got = _unpack_act(agent._debug(bufname), 2 * K * nb, k * nb, gi["IH"], gi["IW"], gi["CI"], gi["lo_h"],
+                                  gi["lo_w"], Hp, Wp)
+            else:
+                go = geo[2]
+                got = _unpack_act(agent._debug(bufname), 2 * K * nb, k * nb, go["OH"], go["OW"], go["CO"], 0, 0,
+                                  go["OH"], go["OW"])
+            errs[f"h{k}_{bufname}"] = _relerr(got[: min(B, 32)], tape[li][4][:32])
+        q = agent._debug("q").cpu().numpy().reshape(2 * K, nb, 32, 32)
+        errs[f"h{k}_q"] = _relerr(q[k, 0, :A, : min(B, 32)].T, aux["q"][:32])
+        errs[f"h{k}_qnext"] = _relerr(q[K + k, 0, :A, : min(B, 32)].T, aux["q_next"][:32])
+        # backward intermediates
+        dh = agent._debug("dh").cpu().numpy()[: K * nb * feats[3] * 32].reshape(K, nb, feats[3], 32)
+        errs[f"h{k}_dh"] = _relerr(dh[k, 0].T[: min(B, 32)], aux["trace"]["d_dense0"][:32])
+        g2, g1 = geo[2], geo[1]
+        l3h, h3h = _dgrad_pad(g2["IH"], g2["OH"], g2["k"], g2["s"], g2["lo_h"])
+        l3w, h3w = _dgrad_pad(g2["IW"], g2["OW"], g2["k"], g2["s"], g2["lo_w"])
+        got = _unpack_act(agent._debug("da3"), K * nb, k * nb, g2["OH"], g2["OW"], g2["CO"], l3h, l3w,
+                          g2["OH"] + l3h + h3h, g2["OW"] + l3w + h3w)
+        errs[f"h{k}_da3"] = _relerr(got[: min(B, 32)], aux["trace"]["d_conv2"][:32])
+        l2h, h2h = _dgrad_pad(g1["IH"], g1["OH"], g1["k"], g1["s"], g1["lo_h"])
+        l2w, h2w = _dgrad_pad(g1["IW"], g1["OW"], g1["k"], g1["s"], g1["lo_w"])
+        got = _unpack_act(agent._debug("da2"), K * nb, k * nb, g1["OH"], g1["OW"], g1["CO"], l2h, l2w,
+                          g1["OH"] + l2h + h2h, g1["OW"] + l2w + h2w)
+        errs[f"h{k}_da2"] = _relerr(got[: min(B, 32)], aux["trace"]["d_conv1"][:32])
+        g0 = geo[0]
+        got = _unpack_act(agent._debug("da1"), K * nb, k * nb, g0["OH"], g0["OW"], g0["CO"], 0, 0, g0["OH"], g0["OW"])
+        errs[f"h{k}_da1"] = _relerr(got[: min(B, 32)], aux["trace"]["d_conv0"][:32])
+        # leaf gradients
+        G = agent._flat(agent._grad)
+        for leaf in grads:
+            errs[f"h{k}_grad_{leaf}"] = _relerr(G[leaf][k], grads[leaf])
+    print("\nstage relative errors (max |got - want| / max |want|):")
+    for n_, e in errs.items():
+        print(f"  {n_:32s} {e:.3e}")
+    bad = {n_: e for n_, e in errs.items() if not e < 2e-5}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5", "cnn_atari_a18_b64", "fc_lunar_k3"])
+def test_full_steps_against_goldens(name):
+    """Fused path (weight gradient + Adam in one kernel): losses and post-Adam parameters of every step."""
+    agent, bs, rec, _ = _agent(name)
+    K = agent._K
+    for s, batch in enumerate(bs):
+        losses = agent._learn(batch).cpu().numpy()
+        want = np.asarray(rec["steps"][s]["losses"])
+        assert np.abs(losses - want).max() <= LOSS_ATOL, (s, losses, want)
+        flat = agent._flat(agent._online)
+        for leaf, d in rec["steps"][s]["leaves"].items():
+            got = flat[leaf].reshape(K, -1)[:, d["idx"]]
+            np.testing.assert_allclose(got, np.asarray(d["param"]), rtol=0, atol=3e-7, err_msg=f"step {s} {leaf}")
+    assert agent._count.cpu().numpy().tolist() == [len(bs)] * K
+    np.testing.assert_allclose(agent.cumulated_losses, np.sum([r["losses"] for r in rec["steps"]], axis=0), atol=3e-5)
+
+
+@pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5", "fc_lunar_k3"])
+def test_two_phase_path_gradients_and_adam(name):
+    """Data-parallel split: gradients only (what gets all-reduced), then idqn_apply_adam."""
+    from slimdqn import _hip
+
+    agent, bs, rec, _ = _agent(name)
+    K = agent._K
+    step = rec["steps"][0]
+    losses = agent._learn(bs[0], flags=_hip.F_GRADS_ONLY).cpu().numpy()
+    assert np.abs(losses - np.asarray(step["losses"])).max() <= LOSS_ATOL
+    G = agent._flat(agent._grad)
+    for leaf, d in step["leaves"].items():
+        flat = G[leaf].reshape(K, -1)
+        scale = np.asarray(d["grad_absmax"])[:, None]
+        assert (np.abs(flat[:, d["idx"]] - np.asarray(d["grad"])) <= 2e-5 * scale + 1e-12).all(), leaf
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum(1)), d["grad_l2"], rtol=2e-5, err_msg=leaf)
+    assert agent._count.cpu().numpy().tolist() == [0] * K  # nothing applied yet
+    agent._apply_adam()
+    flat = agent._flat(agent._online)
+    for leaf, d in step["leaves"].items():
+        np.testing.assert_allclose(flat[leaf].reshape(K, -1)[:, d["idx"]], np.asarray(d["param"]), rtol=0, atol=3e-7)
+    assert agent._count.cpu().numpy().tolist() == [1] * K
+
+
+def test_q_values_and_formula_known_answers():
+    """tests/test_idqn.py:44-84 restated on the HIP path: target = r + (1-term) * gamma * max Q_target(s'),
+    loss = (target - Q(s)[a])^2 for a single sample; best_action = argmax of the head drawn from the key."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn import prng
+
+    agent, bs, rec, (arch, obs, A, feats, K, B, steps, p, pt, batches) = _agent("cnn_small")
+    s, a, r, s2, t = batches[0]
+    qv = agent.q_values(agent.params, s[:7], 1).cpu().numpy()
+    np.testing.assert_allclose(qv, Q.forward(Q.head(p, 1), s[:7], arch), atol=2e-6)
+    qt = agent.q_values(agent.target_params, s2[:5], 0).cpu().numpy()
+    np.testing.assert_allclose(qt, Q.forward(Q.head(pt, 0), s2[:5], arch), atol=2e-6)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    for term in (False, True):
+        one = Batch(s[:1], a[:1], r[:1], s2[:1], np.array([term]))
+        losses = agent._learn(one, flags=1).cpu().numpy()  # grads only: parameters stay put
+        for k in range(K):
+            q_next = Q.forward(Q.head(pt, k), s2[:1], arch)
+            target = r[0] + (1 - int(term)) * 0.99 * q_next.max()
+            pred = Q.forward(Q.head(p, k), s[:1], arch)[0, a[0]]
+            assert abs(losses[k] - (target - pred) ** 2) <= LOSS_ATOL
+    key = prng.PRNGKey(123)
+    head = prng.randint(key, 0, K)
+    best = int(agent.best_action(agent.params, s[0], key).item())
+    assert best == int(np.argmax(Q.forward(Q.head(p, head), s[:1], arch)[0]))
+
+
+def test_shift_sync_and_log_semantics():
+    """idqn.py:74-94: T-step = copy then shift, D-step = sync, T-step skips the sync, logs normalised by T/utd."""
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.idqn import iDQN
+
+    agent = iDQN(7, 8, 4, 4, [16, 16], "fc", 1e-3, 0.99, 1, 1, target_update_frequency=6, target_sync_frequency=2)
+    p0 = agent._flat(agent._online)
+    t0 = agent._flat(agent._target)
+    for n in p0:  # make heads and target distinguishable
+        p0[n] = p0[n] + np.arange(4, dtype=np.float32).reshape((4,) + (1,) * (p0[n].ndim - 1))
+        t0[n] = t0[n] - 5
+    agent._load_flat(agent._online, p0)
+    agent._load_flat(agent._target, t0)
+    agent.cumulated_losses = np.array([6.0, 12.0, 18.0, 24.0])
+    updated, logs = agent.update_target_params(2)  # D-step
+    assert not updated and logs == {}
+    want_t = Q.sync_target_params(p0, t0)
+    got_t = agent._flat(agent._target)
+    for n in p0:
+        np.testing.assert_array_equal(got_t[n], want_t[n])
+        np.testing.assert_array_equal(agent._flat(agent._online)[n], p0[n])
+    updated, logs = agent.update_target_params(6)  # T-step (also a multiple of D: sync must be skipped)
+    assert updated
+    assert logs["loss"] == pytest.approx(15.0 / 6) and logs["networks/2_loss"] == pytest.approx(3.0)
+    np.testing.assert_array_equal(agent.cumulated_losses, np.zeros(4))
+    got_p, got_t = agent._flat(agent._online), agent._flat(agent._target)
+    want_p = Q.shift_params(p0)
+    for n in p0:
+        np.testing.assert_array_equal(got_t[n], p0[n])  # target <- params BEFORE the shift
+        np.testing.assert_array_equal(got_p[n], want_p[n])
+    updated, _ = agent.update_target_params(3)
+    assert not updated
+
+
+def test_dqn_is_the_k1_case():
+    from collections import namedtuple
+
+    from oracle import make_golden as G
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.dqn import DQN
+
+    arch, obs, A, feats, K, B, steps = G.FP_CASES["fc_lunar_k3"]
+    p, pt, batches = G.fp_case_inputs("fc_lunar_k3")
+    agent = DQN(0, obs, A, feats, arch, 6.25e-5, 0.99, 1, 1, 200, adam_eps=1.5e-4)
+    p1 = {n: a[:1] for n, a in p.items()}
+    pt1 = {n: a[:1] for n, a in pt.items()}
+    agent._load_flat(agent._online, p1)
+    agent._load_flat(agent._target, pt1)
+    assert agent.params["params"]["Dense_0"]["kernel"].shape == (8, 100)  # no leading head axis (dqn.py:29)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    _, _, loss = agent.learn_on_batch(agent.params, agent.target_params, agent.optimizer_state, Batch(*batches[0]))
+    want, _, _ = Q.loss_and_grads(Q.head(p, 0), Q.head(pt, 0), batches[0], arch, 0.99)
+    assert abs(float(loss.item()) - want) <= LOSS_ATOL
+    updated, logs = agent.update_target_params(200)
+    assert updated and logs["loss"] == pytest.approx(want / 200, rel=1e-5)
+    for n, v in agent._flat(agent._target).items():
+        np.testing.assert_array_equal(v, agent._flat(agent._online)[n])
