@@ -64,8 +64,9 @@ def test_replay_with_prioritized_sampler_matches_oracle():
     from oracle.samplers_ref import PrioritizedRef
 
     SumTree, Uniform, Prioritized, ReplayBuffer, Transition = _classes()
-    a = ReplayBuffer(Prioritized(3, 64, 0.6), batch_size=16, max_capacity=64, stack_size=4, update_horizon=3, gamma=0.9)
-    b = ReplayRef(PrioritizedRef(3, 64, 0.6), batch_size=16, max_capacity=64, stack_size=4, update_horizon=3, gamma=0.9)
+    # tree capacity > replay capacity: add() inserts the new key before evicting the oldest (replay_buffer.py:209-213)
+    a = ReplayBuffer(Prioritized(3, 100, 0.6), batch_size=16, max_capacity=64, stack_size=4, update_horizon=3, gamma=0.9)
+    b = ReplayRef(PrioritizedRef(3, 100, 0.6), batch_size=16, max_capacity=64, stack_size=4, update_horizon=3, gamma=0.9)
     rng = np.random.default_rng(5)
     for i in range(150):
         obs = rng.integers(0, 256, size=(12, 12), dtype=np.uint8)
