@@ -90,7 +90,7 @@ struct ConvFwdArgs {
     int OH, OW, out_Wp, out_lo_h, out_lo_w;
 };
 
-template <int NP>
+template <int NP, int U>
 __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
     long item = (long)blockIdx.x * 4 + wave;
@@ -118,21 +118,41 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = bias[mfma_row(r, h)];
     }
-    const int J = a.KWCI >> 1;
-    const long wstep = 2L * a.CO;
-    for (int kh = 0; kh < a.KH; ++kh) {
-        const float* wk = W + (long)kh * a.KWCI * a.CO;
-        const long roff = (long)kh * a.IWp * a.CI * 32;
-#pragma unroll 4
-        for (int j = 0; j < J; ++j) {
-            float av = wk[j * wstep];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                float bv = X[xoff[p] + roff + (long)j * 64];
-                acc[p] = mfma32(av, bv, acc[p]);
-            }
-        }
+    // k runs over (kh, q' = kw*CI + ci) in chunks of U k-steps (2U rows); chunk c+1 is in flight while
+    // chunk c feeds the MFMAs (register double buffer: the compiler does not pipeline these loops itself)
+    const int JU = (a.KWCI >> 1) / U, NC = a.KH * JU;
+    const long wstep = 2L * a.CO, wrow = (long)a.KWCI * a.CO, xrow = (long)a.IWp * a.CI * 32;
+    float av[2][U], bv[2][NP][U];
+#define CONV_FWD_LOAD(c, s)                                                        \
+    {                                                                              \
+        const int kh_ = (c) / JU, j0_ = ((c) - kh_ * JU) * U;                      \
+        const float* wk_ = W + kh_ * wrow + (long)j0_ * wstep;                     \
+        const float* xk_ = X + kh_ * xrow + (long)j0_ * 64;                        \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                            \
+            av[s][u] = wk_[u * wstep];                                             \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) bv[s][p][u] = xk_[xoff[p] + u * 64]; \
+        }                                                                          \
     }
+#define CONV_FWD_MMA(s)                                                            \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) acc[p] = mfma32(av[s][u], bv[s][p][u], acc[p]); \
+    }
+    // Prefetches are unconditional (index clamped) and pinned with sched_barrier so that the loads of the
+    // next chunk stay in flight behind counted vmcnt waits while the current chunk feeds the MFMAs.
+    CONV_FWD_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; c += 2) {
+        CONV_FWD_LOAD(min(c + 1, NC - 1), 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CONV_FWD_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        CONV_FWD_LOAD(min(c + 2, NC - 1), 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NC) CONV_FWD_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CONV_FWD_LOAD
+#undef CONV_FWD_MMA
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         int pos = pg * NP + p;
@@ -179,17 +199,36 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     const long wstep = 2L * a.J;
-#pragma unroll 8
-    for (int f = f0; f < f1; f += 2) {
-        float4 w = *reinterpret_cast<const float4*>(W);
-        float x = *X;
-        W += wstep;
-        X += 64;
-        acc[0] = mfma32(w.x, x, acc[0]);
-        acc[1] = mfma32(w.y, x, acc[1]);
-        acc[2] = mfma32(w.z, x, acc[2]);
-        acc[3] = mfma32(w.w, x, acc[3]);
+    constexpr int U = 8;  // k-steps per chunk; (f1 - f0) is a multiple of 2U rows by construction
+    const int NC = (f1 - f0) / (2 * U);
+    float4 wv[2][U];
+    float xv[2][U];
+#define D0F_LOAD(c, s)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
+        wv[s][u] = *reinterpret_cast<const float4*>(W + ((long)(c) * U + u) * wstep);          \
+        xv[s][u] = X[((long)(c) * U + u) * 64];                                                \
     }
+#define D0F_MMA(s)                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                 \
+        acc[0] = mfma32(wv[s][u].x, xv[s][u], acc[0]);              \
+        acc[1] = mfma32(wv[s][u].y, xv[s][u], acc[1]);              \
+        acc[2] = mfma32(wv[s][u].z, xv[s][u], acc[2]);              \
+        acc[3] = mfma32(wv[s][u].w, xv[s][u], acc[3]);              \
+    }
+    D0F_LOAD(0, 0)  // NC is even and >= 2 (host-checked)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; c += 2) {
+        D0F_LOAD(c + 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        D0F_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        D0F_LOAD(min(c + 2, NC - 1), 0)
+        __builtin_amdgcn_sched_barrier(0);
+        D0F_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef D0F_LOAD
+#undef D0F_MMA
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -202,15 +241,56 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Head kernel: split-K reduce + bias + ReLU, Dense_1, TD target with the wavefront max over actions,
-// squared loss, dL/dq, Dense_1 gradients and dL/dh.  One workgroup per head.
-//   idqn.py:111-124  loss_on_batch / loss / compute_target;  architectures/dqn.py:70 final Dense
+// Head, stage 1 (all 2K nets in parallel): split-K reduce + bias + ReLU -> h, and the per-chunk partial
+// products of Dense_1.  grid = (J / 32 chunks, net * batch block).   architectures/dqn.py:67-70
 // --------------------------------------------------------------------------------------------
-struct HeadArgs {
+struct HiddenArgs {
     const float* part;          // [2K][nb][NS][J][32]
     const float* const* wbase;  // [2K]
+    long b0_off, w1_off;
+    int nb, NS, J, A;
+    float* hbuf;   // [2K][nb][J][32]      relu(Dense_0)
+    float* qpart;  // [2K][nb][J/32][32][32]   sum over the chunk's 32 hidden units of h * W1
+};
+
+__global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
+    __shared__ float hs[32][33];
+    const int t = threadIdx.x, b = t & 31, jj = t >> 5;
+    const int jc = blockIdx.x, slot = blockIdx.y;
+    const float* p = a.wbase[slot / a.nb];
+    const float* part = a.part + (long)slot * a.NS * a.J * 32;
+    float* hb = a.hbuf + (long)slot * a.J * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int jl = jj + 8 * i, j = jc * 32 + jl;
+        float s = p[a.b0_off + j];
+        for (int sp = 0; sp < a.NS; ++sp) s += part[((long)sp * a.J + j) * 32 + b];  // fixed order: reproducible
+        s = fmaxf(s, 0.f);
+        hs[jl][b] = s;
+        hb[j * 32 + b] = s;
+    }
+    __syncthreads();
+    const float* w1 = p + a.w1_off + (long)jc * 32 * a.A;
+    for (int ac = jj; ac < a.A; ac += 8) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int jl = 0; jl < 32; ++jl) s = fmaf(hs[jl][b], w1[jl * a.A + ac], s);
+        a.qpart[(((long)slot * (a.J / 32) + jc) * 32 + ac) * 32 + b] = s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Head, stage 2: Q = b1 + sum of chunk partials, TD target with the wavefront max over actions, squared
+// loss, dL/dq, then for this block's 32 hidden units: dL/dh (ReLU mask), Dense_0-bias and Dense_1
+// gradients.  grid = (J / 32 chunks, head); every block re-derives the (tiny) TD part.
+//   idqn.py:111-124  loss_on_batch / loss / compute_target
+// --------------------------------------------------------------------------------------------
+struct TdArgs {
+    const float* hbuf;
+    const float* qpart;
+    const float* const* wbase;
     long b0_off, w1_off, b1_off, P;
-    int K, nb, NS, J, A, B, Bdiv;
+    int K, nb, J, A, B, Bdiv;
     const int32_t* action;
     const float* reward;
     const uint8_t* terminal;
@@ -220,6 +300,105 @@ struct HeadArgs {
     float* grad;    // [K][P]
     float* losses;  // [K]
 };
+
+__global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
+    __shared__ float hs[32][33];
+    __shared__ float qo[32 * 32], qt[32 * 32];
+    __shared__ float qmax[32], cs[32], red[1];
+    __shared__ int acts[32];
+    const int jc = blockIdx.x, k = blockIdx.y, t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
+    const int b = t & 31, jj = t >> 5, NJC = a.J / 32;
+    const float* po = a.wbase[k];
+    const float* pt = a.wbase[a.K + k];
+    const float* w1 = po + a.w1_off;
+    float* G = a.grad + (long)k * a.P;
+    float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f, loss_acc = 0.f;
+    for (int bb = 0; bb < a.nb; ++bb) {
+        const long so = (long)k * a.nb + bb, st = (long)(a.K + k) * a.nb + bb;
+        for (int e = t; e < a.A * 32; e += 256) {
+            const int ac = e >> 5;
+            float vo = 0.f, vt = 0.f;
+            for (int c = 0; c < NJC; ++c) {
+                vo += a.qpart[(so * NJC + c) * 1024 + e];
+                vt += a.qpart[(st * NJC + c) * 1024 + e];
+            }
+            vo += po[a.b1_off + ac];
+            vt += pt[a.b1_off + ac];
+            qo[e] = vo;
+            qt[e] = vt;
+            if (jc == 0) {
+                a.q_dbg[so * 1024 + e] = vo;
+                a.q_dbg[st * 1024 + e] = vt;
+            }
+        }
+        __syncthreads();
+        if (t < 64) {  // wave 0: max over actions -- each half-wave folds every other action, one cross-lane step
+            float m = -INFINITY;
+            for (int ac = h; ac < a.A; ac += 2) m = fmaxf(m, qt[ac * 32 + bl]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int bg = bb * 32 + bl;
+            const bool valid = bg < a.B;
+            const int ac = valid ? a.action[bg] : 0;
+            float td = 0.f;
+            if (valid) {
+                // idqn.py:122  r + (1 - terminal) * gamma**n * max_a Q_target(s')
+                const float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * m;
+                td = qo[ac * 32 + bl] - tgt;
+            }
+            if (h == 0) {
+                cs[bl] = 2.0f * td / (float)a.Bdiv;
+                acts[bl] = ac;
+            }
+            float sq = (h == 0) ? td * td : 0.f;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+            if (lane == 0) red[0] = sq;
+        }
+        const float* hb = a.hbuf + so * a.J * 32 + (long)jc * 32 * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[jj + 8 * i][b] = hb[(jj + 8 * i) * 32 + b];
+        __syncthreads();
+        loss_acc += red[0];
+        float* dh = a.dh + so * a.J * 32 + (long)jc * 32 * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int jl = jj + 8 * i;
+            float d = hs[jl][b] > 0.f ? w1[(long)(jc * 32 + jl) * a.A + acts[b]] * cs[b] : 0.f;
+            dh[jl * 32 + b] = d;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+            gb0[i] += d;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int o = t + 256 * m;
+            if (o < 32 * a.A) {
+                const int jl = o / a.A, ac = o - jl * a.A;
+                float s = 0.f;
+                for (int x = 0; x < 32; ++x) s += (acts[x] == ac) ? hs[jl][x] * cs[x] : 0.f;
+                gw[m] += s;
+            }
+        }
+        if (jc == 0 && t < a.A) {
+            float s = 0.f;
+            for (int x = 0; x < 32; ++x) s += (acts[x] == t) ? cs[x] : 0.f;
+            gb1 += s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (b == 0) G[a.b0_off + jc * 32 + jj + 8 * i] = gb0[i];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int o = t + 256 * m;
+        if (o < 32 * a.A) G[a.w1_off + (long)jc * 32 * a.A + o] = gw[m];
+    }
+    if (jc == 0) {
+        if (t < a.A) G[a.b1_off + t] = gb1;
+        if (t == 0) a.losses[k] = loss_acc / (float)a.Bdiv;
+    }
+}
 
 // hs[j*33 + b] = relu(b0[j] + sum_s part[s][j][b]);  qs[a*32 + b] = b1[a] + sum_j hs[j][b] * W1[j][a]
 __device__ __forceinline__ void head_hidden_and_q(float* hs, float* qs, const float* part, const float* b0,
@@ -244,85 +423,6 @@ __device__ __forceinline__ void head_hidden_and_q(float* hs, float* qs, const fl
         qs[a * 32 + b] = ((s0 + s1) + (s2 + s3)) + b1[a];
     }
     __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hs = lds;                 // [J][33]
-    float* qs = hs + a.J * 33;       // [32][32]
-    float* qmax = qs + 32 * 32;      // [32]
-    float* cs = qmax + 32;           // [32]  2 * td / B
-    int* as = (int*)(cs + 32);       // [32]
-    float* red = (float*)(as + 32);  // [32]
-    const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
-    const float* po = a.wbase[k];
-    const float* pt = a.wbase[a.K + k];
-    float* G = a.grad + (long)k * a.P;
-    float loss_acc = 0.f;
-    for (int bb = 0; bb < a.nb; ++bb) {
-        // ---- target head on s'
-        head_hidden_and_q(hs, qs, a.part + (((long)(a.K + k) * a.nb + bb) * a.NS) * a.J * 32, pt + a.b0_off,
-                          pt + a.w1_off, pt + a.b1_off, a.NS, a.J, a.A);
-        for (int e = t; e < a.A * 32; e += 256) a.q_dbg[(((long)(a.K + k) * a.nb + bb) * 32) * 32 + e] = qs[e];
-        if (t < 64) {  // wave 0: max over actions, half the actions per half-wave, one cross-lane step
-            float m = -INFINITY;
-            for (int ac = h; ac < a.A; ac += 2) m = fmaxf(m, qs[ac * 32 + bl]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (h == 0) qmax[bl] = m;
-        }
-        __syncthreads();
-        // ---- online head on s
-        head_hidden_and_q(hs, qs, a.part + (((long)k * a.nb + bb) * a.NS) * a.J * 32, po + a.b0_off, po + a.w1_off,
-                          po + a.b1_off, a.NS, a.J, a.A);
-        for (int e = t; e < a.A * 32; e += 256) a.q_dbg[(((long)k * a.nb + bb) * 32) * 32 + e] = qs[e];
-        if (t < 64) {
-            const int bg = bb * 32 + bl;
-            const bool valid = bg < a.B;
-            int ac = valid ? a.action[bg] : 0;
-            float td = 0.f;
-            if (valid) {
-                // idqn.py:122  r + (1 - terminal) * gamma**n * max_a Q_target(s')
-                float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * qmax[bl];
-                td = qs[ac * 32 + bl] - tgt;
-            }
-            if (h == 0) {
-                cs[bl] = 2.0f * td / (float)a.Bdiv;
-                as[bl] = ac;
-            }
-            float sq = (h == 0) ? td * td : 0.f;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
-            if (lane == 0) red[0] = sq;
-        }
-        __syncthreads();
-        loss_acc += red[0];
-        // ---- dL/dh (ReLU mask) -> HBM, Dense_0 bias gradient
-        float* dh = a.dh + ((long)k * a.nb + bb) * a.J * 32;
-        const float* w1 = po + a.w1_off;
-        for (int e = t; e < a.J * 32; e += 256) {
-            int j = e >> 5, b = e & 31;
-            float d = hs[j * 33 + b] > 0.f ? w1[j * a.A + as[b]] * cs[b] : 0.f;
-            dh[e] = d;
-            float sb = d;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) sb += __shfl_xor(sb, o);
-            if (b == 0) G[a.b0_off + j] = (bb == 0 ? 0.f : G[a.b0_off + j]) + sb;
-        }
-        // ---- Dense_1 gradients: gW1[j][a] = sum_b h[j][b] * dq[a][b],  gb1[a] = sum_b dq[a][b]
-        for (int o = t; o < a.J * a.A; o += 256) {
-            int j = o / a.A, ac = o - j * a.A;
-            float s = 0.f;
-            for (int b = 0; b < 32; ++b) s += (as[b] == ac) ? hs[j * 33 + b] * cs[b] : 0.f;
-            G[a.w1_off + o] = (bb == 0 ? 0.f : G[a.w1_off + o]) + s;
-        }
-        if (t < a.A) {
-            float s = 0.f;
-            for (int b = 0; b < 32; ++b) s += (as[b] == t) ? cs[b] : 0.f;
-            G[a.b1_off + t] = (bb == 0 ? 0.f : G[a.b1_off + t]) + s;
-        }
-        __syncthreads();
-    }
-    if (t == 0) a.losses[k] = loss_acc / (float)a.Bdiv;
 }
 
 // Inference variant: Q-values of one net for <= 32 states (idqn.py:131 / dqn.py:90 network.apply).
@@ -373,17 +473,36 @@ __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int c = 0; c < a.J; c += 32) {
-        float4 w0 = *reinterpret_cast<const float4*>(W + c);
-        float4 w1 = *reinterpret_cast<const float4*>(W + c + 4);
-        float4 w2 = *reinterpret_cast<const float4*>(W + c + 8);
-        float4 w3 = *reinterpret_cast<const float4*>(W + c + 12);
-        const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                              w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-        const float* d = D + (long)c * 32;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc = mfma32(wv[t], d[t * 32], acc);
+    const int NC = a.J / 32;  // even (J is a multiple of 128)
+    float4 wv[2][4];
+    float dv[2][16];
+#define D0D_LOAD(c, s)                                                                        \
+    {                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                         \
+            wv[s][u] = *reinterpret_cast<const float4*>(W + (c) * 32 + 4 * u);                \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) dv[s][t] = D[((long)(c) * 32 + t) * 32]; \
     }
+#define D0D_MMA(s)                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                   \
+        acc = mfma32(wv[s][u].x, dv[s][4 * u + 0], acc);              \
+        acc = mfma32(wv[s][u].y, dv[s][4 * u + 1], acc);              \
+        acc = mfma32(wv[s][u].z, dv[s][4 * u + 2], acc);              \
+        acc = mfma32(wv[s][u].w, dv[s][4 * u + 3], acc);              \
+    }
+    D0D_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; c += 2) {
+        D0D_LOAD(c + 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        D0D_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        D0D_LOAD(min(c + 2, NC - 1), 0)
+        __builtin_amdgcn_sched_barrier(0);
+        D0D_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef D0D_LOAD
+#undef D0D_MMA
     const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32;
     float* O = a.da3 + ((long)k * a.nb + bb) * a.g.block;
     const int pos = f0 / a.C, c0 = f0 - pos * a.C;
@@ -521,25 +640,45 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvDgradArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kh = (ih + a.PLh) % a.S; kh < a.KH; kh += a.S) {
-        const int ohp = (ih + a.PLh - kh) / a.S + a.gd.lo_h;
-        for (int kw = (iw + a.PLw) % a.S; kw < a.KW; kw += a.S) {
-            const int owp = (iw + a.PLw - kw) / a.S + a.gd.lo_w;
-            const float* wt = W + (long)(kh * a.KW + kw) * a.CI * a.CO;
-            const float* dr = D + ((long)ohp * a.gd.Wp + owp) * a.CO * 32;
-            for (int c = 0; c < a.CO; c += 32) {
-                float4 w0 = *reinterpret_cast<const float4*>(wt + c);
-                float4 w1 = *reinterpret_cast<const float4*>(wt + c + 4);
-                float4 w2 = *reinterpret_cast<const float4*>(wt + c + 8);
-                float4 w3 = *reinterpret_cast<const float4*>(wt + c + 12);
-                const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w,
-                                      w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-                const float* d = dr + (long)c * 32;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) acc = mfma32(wv[t], d[t * 32], acc);
-            }
-        }
+    // chunks = (valid kh) x (valid kw) x (32-wide co chunk); 16 k-steps each, double-buffered
+    const int kh0 = (ih + a.PLh) % a.S, kw0 = (iw + a.PLw) % a.S;
+    const int nkh = (a.KH - kh0 + a.S - 1) / a.S, nkw = (a.KW - kw0 + a.S - 1) / a.S, ncc = a.CO / 32;
+    const int NC = nkh * nkw * ncc;
+    float4 wv[2][4];
+    float dv[2][16];
+#define CDG_LOAD(c, s)                                                                          \
+    {                                                                                           \
+        const int tap_ = (c) / ncc, cc_ = (c) - tap_ * ncc;                                     \
+        const int ikh_ = tap_ / nkw, ikw_ = tap_ - ikh_ * nkw;                                  \
+        const int kh_ = kh0 + ikh_ * a.S, kw_ = kw0 + ikw_ * a.S;                               \
+        const int ohp_ = (ih + a.PLh - kh_) / a.S + a.gd.lo_h, owp_ = (iw + a.PLw - kw_) / a.S + a.gd.lo_w; \
+        const float* wt_ = W + (long)(kh_ * a.KW + kw_) * a.CI * a.CO + cc_ * 32;               \
+        const float* d_ = D + (((long)ohp_ * a.gd.Wp + owp_) * a.CO + cc_ * 32) * 32;           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
+            wv[s][u] = *reinterpret_cast<const float4*>(wt_ + 4 * u);                           \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) dv[s][t] = d_[t * 32];                   \
     }
+#define CDG_MMA(s)                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                   \
+        acc = mfma32(wv[s][u].x, dv[s][4 * u + 0], acc);              \
+        acc = mfma32(wv[s][u].y, dv[s][4 * u + 1], acc);              \
+        acc = mfma32(wv[s][u].z, dv[s][4 * u + 2], acc);              \
+        acc = mfma32(wv[s][u].w, dv[s][4 * u + 3], acc);              \
+    }
+    CDG_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; c += 2) {
+        CDG_LOAD(min(c + 1, NC - 1), 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CDG_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        CDG_LOAD(min(c + 2, NC - 1), 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NC) CDG_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CDG_LOAD
+#undef CDG_MMA
     const float* M = a.act_in + ((long)k * a.nb + bb) * a.gm.block +
                      (((long)(ih + a.gm.lo_h) * a.gm.Wp + (iw + a.gm.lo_w)) * a.CI + cit * 32) * 32 + bl;
     float* O = a.din + ((long)k * a.nb + bb) * a.gi.block +
@@ -590,42 +729,61 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     for (int o = 0; o < NOT; ++o) bsum[o] = 0.f;
     const int npos = a.OH * a.OW;
     const int p0 = pc * a.pos_per_chunk, p1 = min(npos, p0 + a.pos_per_chunk);
-    for (int bb = 0; bb < a.nb; ++bb) {
-        const float* IN = a.in + (long)k * a.in_net_stride + (long)bb * a.gin.block + (long)bl * 32 + 16 * h;
-        const float* DO = a.dout + ((long)k * a.nb + bb) * a.gd.block + (long)bl * 32 + 16 * h;
-        for (int pos = p0; pos < p1; ++pos) {
-            const int oh = pos / a.OW, ow = pos - oh * a.OW;
-            const float* ip = IN + (((long)(oh * a.S + kh) * a.gin.Wp + (ow * a.S + kw)) * a.in_C) * 32;
-            const float* dp = DO + (((long)(oh + a.gd.lo_h) * a.gd.Wp + (ow + a.gd.lo_w)) * a.CO) * 32;
-            float bv[NOT][16];
-#pragma unroll
-            for (int o = 0; o < NOT; ++o) {
-                const float* q = dp + (long)o * 32 * 32;
-                float4 y0 = *reinterpret_cast<const float4*>(q), y1 = *reinterpret_cast<const float4*>(q + 4);
-                float4 y2 = *reinterpret_cast<const float4*>(q + 8), y3 = *reinterpret_cast<const float4*>(q + 12);
-                bv[o][0] = y0.x; bv[o][1] = y0.y; bv[o][2] = y0.z; bv[o][3] = y0.w;
-                bv[o][4] = y1.x; bv[o][5] = y1.y; bv[o][6] = y1.z; bv[o][7] = y1.w;
-                bv[o][8] = y2.x; bv[o][9] = y2.y; bv[o][10] = y2.z; bv[o][11] = y2.w;
-                bv[o][12] = y3.x; bv[o][13] = y3.y; bv[o][14] = y3.z; bv[o][15] = y3.w;
-                float s = 0.f;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) s += bv[o][t];
-                bsum[o] += s;
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const float* q = ip + (long)i * 32 * 32;
-                float4 x0 = *reinterpret_cast<const float4*>(q), x1 = *reinterpret_cast<const float4*>(q + 4);
-                float4 x2 = *reinterpret_cast<const float4*>(q + 8), x3 = *reinterpret_cast<const float4*>(q + 12);
-                const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
-                                      x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-#pragma unroll
-                for (int o = 0; o < NOT; ++o)
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) acc[i][o] = mfma32(av[t], bv[o][t], acc[i][o]);
-            }
-        }
+    // work list = (batch block, output position); 16 k-steps (the 32 samples) each, double-buffered
+    const int npp = p1 - p0, NE = a.nb * npp;
+    const float* IN0 = a.in + (long)k * a.in_net_stride + (long)bl * 32 + 16 * h;
+    const float* DO0 = a.dout + (long)k * a.nb * a.gd.block + (long)bl * 32 + 16 * h;
+    float4 av[2][NIT][4], bv[2][NOT][4];
+#define CWG_LOAD(e, s)                                                                              \
+    {                                                                                               \
+        const int bb_ = (e) / npp, pos_ = p0 + (e) - bb_ * npp;                                     \
+        const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;                                       \
+        const float* ip_ = IN0 + (long)bb_ * a.gin.block +                                          \
+                           (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32;  \
+        const float* dp_ = DO0 + (long)bb_ * a.gd.block +                                           \
+                           (((long)(oh_ + a.gd.lo_h) * a.gd.Wp + (ow_ + a.gd.lo_w)) * a.CO) * 32;   \
+        _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                           \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
+                bv[s][o][u] = *reinterpret_cast<const float4*>(dp_ + (long)o * 1024 + 4 * u);       \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                           \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
+                av[s][i][u] = *reinterpret_cast<const float4*>(ip_ + (long)i * 1024 + 4 * u);       \
+        }                                                                                           \
     }
+#define CWG_MMA(s)                                                                                  \
+    {                                                                                               \
+        _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                           \
+            float sb_ = 0.f;                                                                        \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
+                sb_ += (bv[s][o][u].x + bv[s][o][u].y) + (bv[s][o][u].z + bv[s][o][u].w);           \
+            bsum[o] += sb_;                                                                         \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                           \
+            _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                       \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                     \
+                    acc[i][o] = mfma32(av[s][i][u].x, bv[s][o][u].x, acc[i][o]);                    \
+                    acc[i][o] = mfma32(av[s][i][u].y, bv[s][o][u].y, acc[i][o]);                    \
+                    acc[i][o] = mfma32(av[s][i][u].z, bv[s][o][u].z, acc[i][o]);                    \
+                    acc[i][o] = mfma32(av[s][i][u].w, bv[s][o][u].w, acc[i][o]);                    \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    CWG_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < NE; e += 2) {
+        CWG_LOAD(min(e + 1, NE - 1), 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CWG_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        CWG_LOAD(min(e + 2, NE - 1), 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (e + 1 < NE) CWG_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CWG_LOAD
+#undef CWG_MMA
     float* S = a.slab + ((long)pc * a.K + k) * a.slab_stride;
     const long wrow0 = (long)(kh * a.KWe + kw) * a.CIe;
 #pragma unroll

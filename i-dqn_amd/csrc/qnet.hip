@@ -153,6 +153,7 @@ struct idqn_handle_s {
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
+    float *hbuf = nullptr, *qpart = nullptr;
     int npc[3], pos_per_chunk[3];
     long slab_stride[3];
     int head_lds = 0;
@@ -227,9 +228,18 @@ int cnn_setup(idqn_handle_s* h) {
     h->gda1 = make_geom(c0->OH, c0->OW, c0->CO, 0, 0, 0, 0);
     h->F = c2->OH * c2->OW * c2->CO;
     h->J = c.features[3];
-    // split-K of Dense_0 forward: even row counts, ~16 splits
-    h->rows_per_split = ((h->F + 15) / 16 + 1) / 2 * 2;
-    h->NS = (h->F + h->rows_per_split - 1) / h->rows_per_split;
+    // split-K of Dense_0 forward: splits are whole multiples of 32 rows (= 2 register chunks of 8 k-steps,
+    // so the double-buffered loop always sees an even chunk count); prefer an even split of F/32 units
+    {
+        const int units = h->F / 32;
+        int best_ns = 1, best_waste = 1 << 30;
+        for (int ns = 12; ns <= 24; ++ns) {
+            int per = (units + ns - 1) / ns, real_ns = (units + per - 1) / per;
+            int waste = real_ns * per - units;
+            if (waste < best_waste) { best_waste = waste; best_ns = real_ns; h->rows_per_split = per * 32; }
+        }
+        h->NS = best_ns;
+    }
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
@@ -248,6 +258,8 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->da2, (long)K * nb * h->gda2.block, h, "da2"))) return rc;
     if ((rc = alloc_zero(&h->da1, (long)K * nb * h->gda1.block, h, "da1"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
+    if ((rc = alloc_zero(&h->hbuf, (long)2 * K * nb * h->J * 32, h, "h"))) return rc;
+    if ((rc = alloc_zero(&h->qpart, (long)2 * K * nb * (h->J / 32) * 32 * 32, h, "qpart"))) return rc;
     // weight-gradient slabs: one chunk of output positions (one output row) per item
     long maxslab = 0;
     for (int i = 0; i < 3; ++i) {
@@ -260,9 +272,8 @@ int cnn_setup(idqn_handle_s* h) {
         if (e > maxslab) maxslab = e;
     }
     if ((rc = alloc_zero(&h->slab, maxslab, h, "slab"))) return rc;
-    // k_head / k_head_q need > 64 KB of dynamic LDS at J = 512
+    // k_head_q needs > 64 KB of dynamic LDS at J = 512
     h->head_lds = (h->J * 33 + 32 * 32 + 4 * 32) * 4;
-    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head_q, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
     h->dominant = "k_dense0_wgrad";
     return IDQN_OK;
@@ -309,13 +320,14 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
         a.OH = l.OH; a.OW = l.OW; a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
         a.n_ct = l.CO / 32;
-        const int NP = (i == 0) ? 3 : 1;
+        const int NP = (i == 0) ? 3 : 1, U = (i == 0) ? 8 : 16;
+        IDQN_REQUIRE((a.KWCI / 2) % U == 0, "conv %d: %d k-steps per kernel row is not a multiple of %d", i, a.KWCI / 2, U);
         a.npg = cdiv(l.OH * l.OW, NP);
         a.n_items = (long)s.n_nets * nb * a.npg * a.n_ct;
         if (i == 0)
-            hipLaunchKernelGGL(k_conv_fwd<3>, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+            hipLaunchKernelGGL((k_conv_fwd<3, 8>), dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
         else
-            hipLaunchKernelGGL(k_conv_fwd<1>, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+            hipLaunchKernelGGL((k_conv_fwd<1, 16>), dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
     }
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
@@ -341,13 +353,17 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const int K = h->cfg.n_heads, nb = cdiv(B, 32);
     NetSet& s = h->train;
     const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
-    // head: loss, dL/dq, Dense_1 + Dense_0-bias gradients, dL/dh
-    HeadArgs ha;
-    ha.part = s.part; ha.wbase = s.wbase; ha.b0_off = h->off_b0; ha.w1_off = h->off_w1; ha.b1_off = h->off_b1;
-    ha.P = h->L.head_stride; ha.K = K; ha.nb = nb; ha.NS = h->NS; ha.J = h->J; ha.A = h->cfg.n_actions; ha.B = B;
-    ha.Bdiv = Bdiv; ha.action = action; ha.reward = reward; ha.terminal = terminal; ha.gamma_n = h->gamma_n;
-    ha.dh = h->dh; ha.q_dbg = h->qdbg; ha.grad = h->grad; ha.losses = h->losses;
-    hipLaunchKernelGGL(k_head, dim3(K), dim3(256), h->head_lds, q, ha);
+    // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
+    HiddenArgs hi;
+    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = h->NS;
+    hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
+    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
+    TdArgs ta;
+    ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
+    ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K; ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
+    ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
+    ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
+    hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
     dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
