@@ -18,6 +18,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// LDS-DMA: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + 16 * lane).
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 void idqn_set_error(const char* fmt, ...);
 
 #define IDQN_HIP_CHECK(expr)                                                                   \

@@ -320,14 +320,14 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
         a.OH = l.OH; a.OW = l.OW; a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
         a.n_ct = l.CO / 32;
-        const int NP = (i == 0) ? 3 : 1, U = (i == 0) ? 8 : 16;
-        IDQN_REQUIRE((a.KWCI / 2) % U == 0, "conv %d: %d k-steps per kernel row is not a multiple of %d", i, a.KWCI / 2, U);
-        a.npg = cdiv(l.OH * l.OW, NP);
-        a.n_items = (long)s.n_nets * nb * a.npg * a.n_ct;
-        if (i == 0)
-            hipLaunchKernelGGL((k_conv_fwd<3, 8>), dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
+        const int npw = (a.n_ct == 1) ? 4 : 2;  // positions per workgroup (one per wave x position subsets)
+        a.npg = cdiv(l.OH * l.OW, npw);
+        a.n_items = (long)s.n_nets * nb * a.npg;
+        if (a.n_ct == 1)
+            hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
         else
-            hipLaunchKernelGGL((k_conv_fwd<1, 16>), dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
+            hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
     }
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
