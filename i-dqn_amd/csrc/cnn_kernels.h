@@ -268,12 +268,32 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
     const float* p = a.wbase[slot / a.nb];
     const float* part = a.part + (long)slot * a.NS * a.J * 32;
     float* hb = a.hbuf + (long)slot * a.J * 32;
+    // 4 rows per thread; the split partials are loaded 4 x 4 at a time (independent loads in flight) and
+    // added in fixed split order, so the sum is reproducible
+    float sv[4];
+    const float* pr = part + (long)(jc * 32 + jj) * 32 + b;
+    const long sstride = (long)a.J * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sv[i] = p[a.b0_off + jc * 32 + jj + 8 * i];
+    int sp = 0;
+    for (; sp + 4 <= a.NS; sp += 4) {
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = pr[(sp + u) * sstride + i * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
+    }
+    for (; sp < a.NS; ++sp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] += pr[sp * sstride + i * 256];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int jl = jj + 8 * i, j = jc * 32 + jl;
-        float s = p[a.b0_off + j];
-        for (int sp = 0; sp < a.NS; ++sp) s += part[((long)sp * a.J + j) * 32 + b];  // fixed order: reproducible
-        s = fmaxf(s, 0.f);
+        const float s = fmaxf(sv[i], 0.f);
         hs[jl][b] = s;
         hb[j * 32 + b] = s;
     }
@@ -307,6 +327,9 @@ struct TdArgs {
     float* q_dbg;   // [2K][nb][32][32]
     float* grad;    // [K][P]
     float* losses;  // [K]
+    const int32_t* count;  // [K] optax step counter (pre-increment)
+    float* bcinv;          // [K][2] out: reciprocal Adam bias corrections of THIS step
+    float b1, b2;          // Adam decay rates (f32, as folded by the host)
 };
 
 __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
@@ -326,9 +349,13 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
         for (int e = t; e < a.A * 32; e += 256) {
             const int ac = e >> 5;
             float vo = 0.f, vt = 0.f;
-            for (int c = 0; c < NJC; ++c) {
-                vo += a.qpart[(so * NJC + c) * 1024 + e];
-                vt += a.qpart[(st * NJC + c) * 1024 + e];
+            const float* qo_ = a.qpart + so * NJC * 1024 + e;
+            const float* qt_ = a.qpart + st * NJC * 1024 + e;
+            for (int c = 0; c < NJC; c += 4) {  // NJC = J / 32 is a multiple of 4 (J is a multiple of 128)
+                float x0 = qo_[(c + 0) * 1024], x1 = qo_[(c + 1) * 1024], x2 = qo_[(c + 2) * 1024], x3 = qo_[(c + 3) * 1024];
+                float y0 = qt_[(c + 0) * 1024], y1 = qt_[(c + 1) * 1024], y2 = qt_[(c + 2) * 1024], y3 = qt_[(c + 3) * 1024];
+                vo = (((vo + x0) + x1) + x2) + x3;
+                vt = (((vt + y0) + y1) + y2) + y3;
             }
             vo += po[a.b1_off + ac];
             vt += pt[a.b1_off + ac];
@@ -404,7 +431,12 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
     }
     if (jc == 0) {
         if (t < a.A) G[a.b1_off + t] = gb1;
-        if (t == 0) a.losses[k] = loss_acc / (float)a.Bdiv;
+        if (t == 0) {
+            a.losses[k] = loss_acc / (float)a.Bdiv;
+            const double tt = (double)(a.count[k] + 1);
+            a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
+            a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+        }
     }
 }
 
@@ -455,7 +487,7 @@ __global__ __launch_bounds__(256) void k_head_q(HeadQArgs a) {
 
 // --------------------------------------------------------------------------------------------
 // Dense_0 data gradient: da3[f][b] = relu'(a3[f][b]) * sum_j W0[f][j] * dh[j][b]
-// item = (head, batch block, 32-row f tile).  W rows are read 16 floats per lane (k in registers).
+// workgroup = (head, batch block, 4 consecutive 32-row f tiles).  W rows are read 16 floats per lane.
 // --------------------------------------------------------------------------------------------
 struct DenseDgradArgs {
     const float* dh;   // [K][nb][J][32]
@@ -468,60 +500,64 @@ struct DenseDgradArgs {
 };
 
 __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;
-    const int ft = (int)(item % a.n_ft);
-    item /= a.n_ft;
-    const int bb = (int)(item % a.nb);
-    const int k = (int)(item / a.nb);
+    // workgroup = 4 consecutive f tiles of one (head, batch block).  dh (J x 32, <= 64 KB) is staged once
+    // by LDS-DMA and shared by the 4 waves (B operand: conflict-free ds_read_b32); the W rows (A operand,
+    // 16 floats per lane and chunk) stream from HBM with register double buffering.
+    extern __shared__ __attribute__((aligned(16))) float dlds[];  // [J][32]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    const int n_wg_ft = (a.n_ft + 3) / 4;
+    int item = blockIdx.x;
+    const int fg = item % n_wg_ft;
+    item /= n_wg_ft;
+    const int bb = item % a.nb;
+    const int k = item / a.nb;
+    const float* dsrc = a.dh + ((long)k * a.nb + bb) * a.J * 32;
+    for (int o = 0; o < a.J * 32; o += 1024) glds16(dsrc + o + t * 4, &dlds[o + wave * 256]);
+    const int ft = min(fg * 4 + wave, a.n_ft - 1);
+    const bool live = fg * 4 + wave < a.n_ft;
     const int f0 = ft * 32;
     const float* W = a.wbase[k] + a.w_off + (long)(f0 + bl) * a.J + 16 * h;
-    const float* D = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(16 * h) * 32 + bl;
+    const float* D = dlds + (16 * h) * 32 + bl;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int NC = a.J / 32;  // even (J is a multiple of 128)
     float4 wv[2][4];
-    float dv[2][16];
-#define D0D_LOAD(c, s)                                                                        \
-    {                                                                                         \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                         \
-            wv[s][u] = *reinterpret_cast<const float4*>(W + (c) * 32 + 4 * u);                \
-        _Pragma("unroll") for (int t = 0; t < 16; ++t) dv[s][t] = D[((long)(c) * 32 + t) * 32]; \
-    }
-#define D0D_MMA(s)                                                    \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                   \
-        acc = mfma32(wv[s][u].x, dv[s][4 * u + 0], acc);              \
-        acc = mfma32(wv[s][u].y, dv[s][4 * u + 1], acc);              \
-        acc = mfma32(wv[s][u].z, dv[s][4 * u + 2], acc);              \
-        acc = mfma32(wv[s][u].w, dv[s][4 * u + 3], acc);              \
+#define D0D_LOAD(c, s) \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) wv[s][u] = *reinterpret_cast<const float4*>(W + (c) * 32 + 4 * u);
+#define D0D_MMA(c, s)                                                          \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                            \
+        acc = mfma32(wv[s][u].x, D[((c) * 32 + 4 * u + 0) * 32], acc);         \
+        acc = mfma32(wv[s][u].y, D[((c) * 32 + 4 * u + 1) * 32], acc);         \
+        acc = mfma32(wv[s][u].z, D[((c) * 32 + 4 * u + 2) * 32], acc);         \
+        acc = mfma32(wv[s][u].w, D[((c) * 32 + 4 * u + 3) * 32], acc);         \
     }
     D0D_LOAD(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
+    D0D_LOAD(1, 1)
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes dh to all waves
     for (int c = 0; c < NC; c += 2) {
-        D0D_LOAD(c + 1, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        D0D_MMA(0)
+        D0D_MMA(c, 0)
         __builtin_amdgcn_sched_barrier(0);
         D0D_LOAD(min(c + 2, NC - 1), 0)
         __builtin_amdgcn_sched_barrier(0);
-        D0D_MMA(1)
+        D0D_MMA(c + 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        D0D_LOAD(min(c + 3, NC - 1), 1)
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef D0D_LOAD
 #undef D0D_MMA
+    if (!live) return;
     const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32;
     float* O = a.da3 + ((long)k * a.nb + bb) * a.g.block;
     const int pos = f0 / a.C, c0 = f0 - pos * a.C;
     const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
     const long row0 = ((long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w)) * a.C + c0;
+    float mk[16];  // all mask loads first: interleaved with the stores they would serialise (may-alias)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int i = mfma_row(r, h);
-        float m = A3[(long)(f0 + i) * 32 + bl];
-        O[(row0 + i) * 32 + bl] = m > 0.f ? acc[r] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) mk[r] = A3[(long)(f0 + mfma_row(r, h)) * 32 + bl];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[(row0 + mfma_row(r, h)) * 32 + bl] = mk[r] > 0.f ? acc[r] : 0.f;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -532,17 +568,20 @@ __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
 struct AdamConsts {
     float lr_neg, b1, b2, omb1, omb2, eps;
 };
-__device__ __forceinline__ void adam_bias_corr(const AdamConsts& c, int count, float& bc1, float& bc2) {
-    const double t = (double)(count + 1);
-    bc1 = 1.0f - (float)pow((double)c.b1, t);
-    bc2 = 1.0f - (float)pow((double)c.b2, t);
-}
-__device__ __forceinline__ void adam_elem(const AdamConsts& c, float bc1, float bc2, float g, float& th, float& m,
+// The reciprocal bias corrections 1 / (1 - b^t), t = count + 1, are computed ONCE per step and head
+// (k_td_dh / k_fc_step, one thread) into bcinv[k][2]; b^t is the correctly rounded f32 power of the
+// f32 base (double pow, then rounded).
+// optax.adam element update (idqn.py:106-107).  The bias corrections are multiplications by the
+// precomputed reciprocals and the final quotient uses the hardware sqrt / rcp (<= 2 ulp each): the
+// IEEE-exact division / sqrt expansions made the fused kernel VALU-bound (4.4 k instructions per
+// wave) while changing the update by < 1e-6 relative (~1e-11 absolute on a parameter).
+__device__ __forceinline__ void adam_elem(const AdamConsts& c, float rbc1, float rbc2, float g, float& th, float& m,
                                           float& v) {
-    m = c.omb1 * g + c.b1 * m;
-    v = c.omb2 * (g * g) + c.b2 * v;
-    float mh = m / bc1, vh = v / bc2;
-    th = th + c.lr_neg * (mh / (sqrtf(vh) + c.eps));
+    m = fmaf(c.omb1, g, c.b1 * m);
+    v = fmaf(c.omb2, g * g, c.b2 * v);
+    const float mh = m * rbc1, vh = v * rbc2;
+    const float d = __builtin_amdgcn_sqrtf(vh) + c.eps;
+    th = fmaf(c.lr_neg, mh * __builtin_amdgcn_rcpf(d), th);
 }
 
 struct DenseWgradArgs {
@@ -550,7 +589,7 @@ struct DenseWgradArgs {
     const float* dh;  // [K][nb][J][32]
     float* grad;      // [K][P]
     float *theta, *mu, *nu;
-    const int32_t* count;
+    const float* bcinv;  // [K][2]
     AdamConsts ad;
     long w_off, P, n_items;
     int K, nb, n_ft, n_jt, F, J;
@@ -571,6 +610,22 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0 + 4 * bl;
+    // Fused Adam streams theta / m / v of this 32 x 128 tile: 16 rows x 3 arrays x 16 B per lane.  Loads
+    // are issued a group of 4 rows AHEAD of the stores of the previous group (a load behind a may-alias
+    // store would otherwise wait for it), and group 0 is requested before the MFMA phase.
+    float4 th[2][4], mm[2][4], vv[2][4];
+#define WG_LOADG(g, s)                                                                   \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                      \
+        const long o_ = base + (long)mfma_row(4 * (g) + x, h) * a.J;                     \
+        th[s][x] = *reinterpret_cast<const float4*>(a.theta + o_);                       \
+        mm[s][x] = *reinterpret_cast<const float4*>(a.mu + o_);                          \
+        vv[s][x] = *reinterpret_cast<const float4*>(a.nu + o_);                          \
+    }
+    if (FUSE_ADAM) {
+        WG_LOADG(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int bb = 0; bb < a.nb; ++bb) {
         const float* Ap = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
         float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
@@ -589,23 +644,29 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
             for (int t = 0; t < 16; ++t) acc[q] = mfma32(av[t], bv[t], acc[q]);
         }
     }
-    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0 + 4 * bl;
     if (FUSE_ADAM) {
-        float bc1, bc2;
-        adam_bias_corr(a.ad, a.count[k], bc1, bc2);
+        const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long o = base + (long)mfma_row(r, h) * a.J;
-            float4 th = *reinterpret_cast<float4*>(a.theta + o);
-            float4 m = *reinterpret_cast<float4*>(a.mu + o);
-            float4 v = *reinterpret_cast<float4*>(a.nu + o);
-            adam_elem(a.ad, bc1, bc2, acc[0][r], th.x, m.x, v.x);
-            adam_elem(a.ad, bc1, bc2, acc[1][r], th.y, m.y, v.y);
-            adam_elem(a.ad, bc1, bc2, acc[2][r], th.z, m.z, v.z);
-            adam_elem(a.ad, bc1, bc2, acc[3][r], th.w, m.w, v.w);
-            *reinterpret_cast<float4*>(a.theta + o) = th;
-            *reinterpret_cast<float4*>(a.mu + o) = m;
-            *reinterpret_cast<float4*>(a.nu + o) = v;
+        for (int g = 0; g < 4; ++g) {
+            const int s = g & 1;
+            if (g + 1 < 4) {
+                if (s == 0) { WG_LOADG(g + 1, 1) } else { WG_LOADG(g + 1, 0) }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int r = 4 * g + x;
+                const long o = base + (long)mfma_row(r, h) * a.J;
+                float4 t4 = th[s][x], m4 = mm[s][x], v4 = vv[s][x];
+                adam_elem(a.ad, bc1, bc2, acc[0][r], t4.x, m4.x, v4.x);
+                adam_elem(a.ad, bc1, bc2, acc[1][r], t4.y, m4.y, v4.y);
+                adam_elem(a.ad, bc1, bc2, acc[2][r], t4.z, m4.z, v4.z);
+                adam_elem(a.ad, bc1, bc2, acc[3][r], t4.w, m4.w, v4.w);
+                *reinterpret_cast<float4*>(a.theta + o) = t4;
+                *reinterpret_cast<float4*>(a.mu + o) = m4;
+                *reinterpret_cast<float4*>(a.nu + o) = v4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
 #pragma unroll
@@ -614,6 +675,7 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
             *reinterpret_cast<float4*>(a.grad + o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
         }
     }
+#undef WG_LOADG
 }
 
 // --------------------------------------------------------------------------------------------
@@ -691,17 +753,18 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvDgradArgs a) {
                      (((long)(ih + a.gm.lo_h) * a.gm.Wp + (iw + a.gm.lo_w)) * a.CI + cit * 32) * 32 + bl;
     float* O = a.din + ((long)k * a.nb + bb) * a.gi.block +
                (((long)(ih + a.gi.lo_h) * a.gi.Wp + (iw + a.gi.lo_w)) * a.CI + cit * 32) * 32 + bl;
+    float mk[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int i = mfma_row(r, h);
-        O[i * 32] = M[i * 32] > 0.f ? acc[r] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) mk[r] = M[mfma_row(r, h) * 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[mfma_row(r, h) * 32] = mk[r] > 0.f ? acc[r] : 0.f;
 }
 
 // --------------------------------------------------------------------------------------------
 // conv weight gradient: partial slabs over chunks of output positions
 //   gW[kh][kw][ci][co] = sum_{b, oh, ow} in[oh*S+kh][ow*S+kw][ci][b] * dout[oh][ow][co][b]
-// item = (head, kh, kw, position chunk); NIT x NOT accumulator tiles of 32x32 ([ci tile][co tile]).
+// workgroup = (head, kh, kw, position chunk), its 4 waves take every 4th position and reduce through LDS;
+// NIT x NOT accumulator tiles of 32x32 ([ci tile][co tile]) per wave.
 // Conv_0 (CI = 4) runs the same code with the 32 rows (kw, ci) of one kernel row as its "ci tile".
 // --------------------------------------------------------------------------------------------
 struct ConvWgradArgs {
@@ -716,15 +779,16 @@ struct ConvWgradArgs {
 
 template <int NIT, int NOT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
+    // waves 1..3 park their accumulators here; wave 0 adds them in wave order and writes the slab
+    __shared__ float red[3][NIT * NOT * 16 + NOT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;
-    const int pc = (int)(item % a.npc);
+    int item = blockIdx.x;  // workgroup = (head, kh, kw, chunk of output positions); waves interleave positions
+    const int pc = item % a.npc;
     item /= a.npc;
-    const int kw = (int)(item % a.KWe);
+    const int kw = item % a.KWe;
     item /= a.KWe;
-    const int kh = (int)(item % a.KH);
-    const int k = (int)(item / a.KH);
+    const int kh = item % a.KH;
+    const int k = item / a.KH;
     f32x16 acc[NIT][NOT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
@@ -736,15 +800,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
 #pragma unroll
     for (int o = 0; o < NOT; ++o) bsum[o] = 0.f;
     const int npos = a.OH * a.OW;
-    const int p0 = pc * a.pos_per_chunk, p1 = min(npos, p0 + a.pos_per_chunk);
-    // work list = (batch block, output position); 16 k-steps (the 32 samples) each, double-buffered
-    const int npp = p1 - p0, NE = a.nb * npp;
+    const int p0 = pc * a.pos_per_chunk + wave, p1 = min(npos, pc * a.pos_per_chunk + a.pos_per_chunk);
+    // work list of this wave = (batch block, every 4th output position of the chunk); 16 k-steps (the 32
+    // samples) each, register double-buffered
+    const int npp = p1 > p0 ? (p1 - p0 + 3) / 4 : 0, NE = a.nb * npp;
     const float* IN0 = a.in + (long)k * a.in_net_stride + (long)bl * 32 + 16 * h;
     const float* DO0 = a.dout + (long)k * a.nb * a.gd.block + (long)bl * 32 + 16 * h;
     float4 av[2][NIT][4], bv[2][NOT][4];
 #define CWG_LOAD(e, s)                                                                              \
     {                                                                                               \
-        const int bb_ = (e) / npp, pos_ = p0 + (e) - bb_ * npp;                                     \
+        const int bb_ = (e) / npp, pos_ = p0 + 4 * ((e) - bb_ * npp);                               \
         const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;                                       \
         const float* ip_ = IN0 + (long)bb_ * a.gin.block +                                          \
                            (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32;  \
@@ -778,20 +843,45 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
             }                                                                                       \
         }                                                                                           \
     }
-    CWG_LOAD(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int e = 0; e < NE; e += 2) {
-        CWG_LOAD(min(e + 1, NE - 1), 1)
+    if (NE > 0) {
+        CWG_LOAD(0, 0)
         __builtin_amdgcn_sched_barrier(0);
-        CWG_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        CWG_LOAD(min(e + 2, NE - 1), 0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (e + 1 < NE) CWG_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < NE; e += 2) {
+            CWG_LOAD(min(e + 1, NE - 1), 1)
+            __builtin_amdgcn_sched_barrier(0);
+            CWG_MMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            CWG_LOAD(min(e + 2, NE - 1), 0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (e + 1 < NE) CWG_MMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #undef CWG_LOAD
 #undef CWG_MMA
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+#pragma unroll
+            for (int o = 0; o < NOT; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][(i * NOT + o) * 16 + r][lane] = acc[i][o][r];
+#pragma unroll
+        for (int o = 0; o < NOT; ++o) red[wave - 1][NIT * NOT * 16 + o][lane] = bsum[o];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+#pragma unroll
+            for (int o = 0; o < NOT; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][o][r] += red[w][(i * NOT + o) * 16 + r][lane];
+#pragma unroll
+        for (int o = 0; o < NOT; ++o) bsum[o] += red[w][NIT * NOT * 16 + o][lane];
+    }
     float* S = a.slab + ((long)pc * a.K + k) * a.slab_stride;
     const long wrow0 = (long)(kh * a.KWe + kw) * a.CIe;
 #pragma unroll
@@ -811,20 +901,38 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     }
 }
 
-// slab reduce: grad[k][off + e] = sum_pc slab[pc][k][e]   (fixed order -> reproducible)
-struct SlabReduceArgs {
+// slab reduce for all conv layers in ONE launch: grad[k][off + e] = sum_pc slab[pc][k][e]  (fixed order)
+struct SlabSeg {
     const float* slab;
-    float* grad;
-    long slab_stride, P, w_off, b_off, wsize;
-    int K, npc, bsize;
+    long slab_stride, w_off, b_off, wsize;
+    int npc, bsize;
+    long first_block;  // blockIdx.x range [first_block, first_block + n_blocks)
 };
-__global__ void k_slab_reduce(SlabReduceArgs a) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+struct SlabReduceArgs {
+    SlabSeg seg[3];
+    float* grad;
+    long P;
+    int K, n_seg;
+};
+__global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs a) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+        if (i < a.n_seg && (long)blockIdx.x >= a.seg[i].first_block) si = i;
+    const SlabSeg& g = a.seg[si];
+    const long e = ((long)blockIdx.x - g.first_block) * 256 + threadIdx.x;
     const int k = blockIdx.y;
-    if (e >= a.wsize + a.bsize) return;
+    if (e >= g.wsize + g.bsize) return;
+    const float* sp = g.slab + (long)k * g.slab_stride + e;
+    const long pstride = (long)a.K * g.slab_stride;
     float s = 0.f;
-    for (int pc = 0; pc < a.npc; ++pc) s += a.slab[((long)pc * a.K + k) * a.slab_stride + e];
-    const long o = e < a.wsize ? a.w_off + e : a.b_off + (e - a.wsize);
+    int pc = 0;
+    for (; pc + 4 <= g.npc; pc += 4) {
+        float x0 = sp[(pc + 0) * pstride], x1 = sp[(pc + 1) * pstride], x2 = sp[(pc + 2) * pstride], x3 = sp[(pc + 3) * pstride];
+        s = (((s + x0) + x1) + x2) + x3;
+    }
+    for (; pc < g.npc; ++pc) s += sp[pc * pstride];
+    const long o = e < g.wsize ? g.w_off + e : g.b_off + (e - g.wsize);
     a.grad[(long)k * a.P + o] = s;
 }
 
@@ -834,7 +942,7 @@ __global__ void k_slab_reduce(SlabReduceArgs a) {
 struct AdamArgs {
     float *theta, *mu, *nu;
     const float* grad;
-    const int32_t* count;
+    const float* bcinv;  // [K][2]
     AdamConsts ad;
     long P, begin, end;  // element range inside a head, multiples of 4
     long skip_begin, skip_end;  // sub-range already updated by a fused kernel (empty when begin==end)
@@ -844,8 +952,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     long e = a.begin + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= a.end) return;
     if (e >= a.skip_begin && e < a.skip_end) return;
-    float bc1, bc2;
-    adam_bias_corr(a.ad, a.count[k], bc1, bc2);
+    const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const long o = (long)k * a.P + e;
     float4 g = *reinterpret_cast<const float4*>(a.grad + o);
     float4 th = *reinterpret_cast<float4*>(a.theta + o);

@@ -35,6 +35,9 @@ struct FcArgs {
     float* ws;            // [K][ (L+1) * B * dmax (online acts) + 2 * B * dmax (target ping-pong / deltas) + 2*B ]
     float* losses;        // [K]
     float* q_dbg;         // [2K][B][A]
+    const int32_t* count; // [K] optax step counter (pre-increment)
+    float* bcinv;         // [K][2] out: reciprocal Adam bias corrections of this step
+    float adam_b1, adam_b2;
 };
 
 // out[b][o] = (relu?)(bias[o] + sum_i in[b][i] * W[i][o])
@@ -104,6 +107,9 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += sq[b];
         a.losses[k] = s / (float)a.Bdiv;
+        const double tt = (double)(a.count[k] + 1);
+        a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.adam_b1, tt));
+        a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.adam_b2, tt));
     }
     // ---- backward
     float* dprev = tB;

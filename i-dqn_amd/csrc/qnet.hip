@@ -153,9 +153,9 @@ struct idqn_handle_s {
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
-    float *hbuf = nullptr, *qpart = nullptr;
+    float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
     int npc[3], pos_per_chunk[3];
-    long slab_stride[3];
+    long slab_stride[3], slab_off[3];
     int head_lds = 0;
     // fc
     FcNet fc;
@@ -260,21 +260,22 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
     if ((rc = alloc_zero(&h->hbuf, (long)2 * K * nb * h->J * 32, h, "h"))) return rc;
     if ((rc = alloc_zero(&h->qpart, (long)2 * K * nb * (h->J / 32) * 32 * 32, h, "qpart"))) return rc;
-    // weight-gradient slabs: one chunk of output positions (one output row) per item
-    long maxslab = 0;
+    // weight-gradient slabs: one per workgroup chunk of 16 output positions; one region per conv layer
+    long slab_total = 0;
     for (int i = 0; i < 3; ++i) {
         const ConvL& cl = h->conv[i];
         int npos = cl.OH * cl.OW;
-        h->pos_per_chunk[i] = cl.OW;
+        h->pos_per_chunk[i] = 16;
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
-        long e = (long)h->npc[i] * K * h->slab_stride[i];
-        if (e > maxslab) maxslab = e;
+        h->slab_off[i] = slab_total;
+        slab_total += (long)h->npc[i] * K * h->slab_stride[i];
     }
-    if ((rc = alloc_zero(&h->slab, maxslab, h, "slab"))) return rc;
+    if ((rc = alloc_zero(&h->slab, slab_total, h, "slab"))) return rc;
     // k_head_q needs > 64 KB of dynamic LDS at J = 512
     h->head_lds = (h->J * 33 + 32 * 32 + 4 * 32) * 4;
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head_q, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
+    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
     h->dominant = "k_dense0_wgrad";
     return IDQN_OK;
 }
@@ -341,7 +342,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
 
 int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, hipStream_t q) {
     AdamArgs a;
-    a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.count = h->count; a.ad = h->ad;
+    a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
     a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
     hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
     IDQN_HIP_CHECK(hipGetLastError());
@@ -363,17 +364,18 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K; ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
     ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
     ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
+    ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
     dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
     dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
-    dd.n_items = (long)K * nb * dd.n_ft;
-    hipLaunchKernelGGL(k_dense0_dgrad, dim3(cdiv(dd.n_items, 4)), dim3(256), 0, q, dd);
+    dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
+    hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
     DenseWgradArgs dw;
     dw.a3 = s.a3; dw.dh = h->dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
-    dw.count = h->count; dw.ad = h->ad; dw.w_off = h->off_w0; dw.P = h->L.head_stride;
+    dw.bcinv = h->bcinv; dw.ad = h->ad; dw.w_off = h->off_w0; dw.P = h->L.head_stride;
     dw.K = K; dw.nb = nb; dw.n_ft = h->F / 32; dw.n_jt = h->J / 128; dw.F = h->F; dw.J = h->J;
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;
     if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
@@ -403,29 +405,33 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         hipLaunchKernelGGL(k_conv_dgrad, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
         // weight gradient of layer i can run as soon as its dout exists (it does: douts[i])
     }
-    // conv weight gradients: slabs, then reduce into the gradient arena
+    // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
+    SlabReduceArgs r;
+    r.grad = h->grad; r.P = h->L.head_stride; r.K = K; r.n_seg = 3;
+    long nblk = 0;
     for (int i = 2; i >= 0; --i) {
         ConvWgradArgs a;
-        a.in = acts_in[i]; a.dout = douts[i]; a.slab = h->slab;
+        a.in = acts_in[i]; a.dout = douts[i]; a.slab = h->slab + h->slab_off[i];
         a.in_net_stride = (i == 0) ? 0 : (long)nb * gact[i]->block;
         a.slab_stride = h->slab_stride[i];
         a.K = K; a.nb = nb; a.npc = h->npc[i]; a.KH = cl[i]->K; a.S = cl[i]->S; a.CO = cl[i]->CO;
         a.OH = cl[i]->OH; a.OW = cl[i]->OW; a.pos_per_chunk = h->pos_per_chunk[i];
         a.gin = *gact[i]; a.gd = *gdo[i]; a.in_C = cl[i]->CI;
         if (i == 0) { a.KWe = 1; a.CIe = cl[i]->K * cl[i]->CI; } else { a.KWe = cl[i]->K; a.CIe = cl[i]->CI; }
-        a.n_items = (long)K * a.KH * a.KWe * a.npc;
+        a.n_items = (long)K * a.KH * a.KWe * a.npc;  // workgroups
         const int nit = a.CIe / 32, not_ = a.CO / 32;
-        dim3 grid(cdiv(a.n_items, 4));
+        dim3 grid((unsigned)a.n_items);
         if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
         else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
         else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
         else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
-        SlabReduceArgs r;
-        r.slab = h->slab; r.grad = h->grad; r.slab_stride = a.slab_stride; r.P = h->L.head_stride;
-        r.w_off = cl[i]->w_off; r.b_off = cl[i]->b_off; r.wsize = (long)a.KH * a.KWe * a.CIe * a.CO;
-        r.K = K; r.npc = a.npc; r.bsize = a.CO;
-        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(r.wsize + r.bsize, 256), K), dim3(256), 0, q, r);
+        SlabSeg& g = r.seg[2 - i];
+        g.slab = a.slab; g.slab_stride = a.slab_stride; g.w_off = cl[i]->w_off; g.b_off = cl[i]->b_off;
+        g.wsize = (long)a.KH * a.KWe * a.CIe * a.CO; g.npc = a.npc; g.bsize = a.CO;
+        g.first_block = nblk;
+        nblk += cdiv(g.wsize + g.bsize, 256);
     }
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)nblk, K), dim3(256), 0, q, r);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -476,7 +482,8 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
     h->ad.eps = (float)cfg->adam_eps;
     h->gamma_n = (float)cfg->gamma_n;
     h->nb_max = cdiv(cfg->max_batch, 32);
-    rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
+    rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
+    if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
     if (rc) { idqn_destroy(h); return rc; }
     h->ev.resize(2 * 2048);
     for (auto& e : h->ev)
@@ -520,6 +527,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         a.s = (const float*)state_dev; a.s2 = (const float*)next_state_dev; a.action = action_dev; a.reward = reward_dev;
         a.terminal = terminal_dev; a.gamma_n = h->gamma_n; a.B = batch; a.Bdiv = batch_mean_divisor; a.K = h->cfg.n_heads;
         a.ws = h->fc_ws; a.losses = h->losses; a.q_dbg = h->qdbg;
+        a.count = h->count; a.bcinv = h->bcinv; a.adam_b1 = h->ad.b1; a.adam_b2 = h->ad.b2;
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
         hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
