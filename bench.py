@@ -45,6 +45,23 @@ def synthetic(seed):
     return s, a, r, s2, t
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity, capped by the cgroup CPU quota and by the
+    16-core share a one-GPU box gives (an over-subscribed torch pool is far slower than a right-sized one)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("IDQN_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(budget_s=15.0):
     """The oracle's torch-CPU fp32 restatement (K heads batched), all host cores, bounded sample."""
     import torch
@@ -52,11 +69,7 @@ def cpu_baseline(budget_s=15.0):
     from oracle import qnet_ref as Q
     from oracle import torch_ref as T
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
     p = Q.init_params(0, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
     pt = Q.init_params(1, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
@@ -106,16 +119,20 @@ def main():
 
     agent = iDQN(0, OBS, N_ACTIONS, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
-    s, a, r, s2, t = synthetic(1000 + rank)
-    batch = Batch(*(torch.from_numpy(x).cuda() for x in (s, a, r, s2, t)))  # resident in HBM before the timed region
+    # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i))) for i in range(8)]
+    it = [0]
     dp = world > 1
     global_batch = BATCH * world
 
-    def step(profile):
+    def step(profile, extra=0):
+        batch = batches[it[0] % len(batches)]
+        it[0] += 1
         if not dp:
-            agent._learn(batch, flags=_hip.F_PROFILE if profile else 0)
+            agent._learn(batch, flags=(_hip.F_PROFILE if profile else 0) | extra)
         else:
-            agent._learn(batch, flags=_hip.F_GRADS_ONLY | (_hip.F_PROFILE if profile else 0), mean_divisor=global_batch)
+            agent._learn(batch, flags=_hip.F_GRADS_ONLY | (_hip.F_PROFILE if profile else 0) | extra,
+                         mean_divisor=global_batch)
             dist.all_reduce(agent._grad)       # sum of shard gradients == gradient of the 32*N batch
             dist.all_reduce(agent._losses)
             agent._apply_adam()
@@ -145,7 +162,6 @@ def main():
     _hip.check(_hip.lib().idqn_profile_read(agent._handle, C.byref(mean_ms), C.byref(n_l), name), "idqn_profile_read")
     losses = agent._losses.cpu().numpy()
     assert np.isfinite(losses).all(), losses
-
     if rank == 0:
         P_w0 = 7744 * 512
         fused = not dp
@@ -176,7 +192,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes},
-            "final_losses": [float(x) for x in losses],
+        "final_losses": [float(x) for x in losses],
         }
         if not dp and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

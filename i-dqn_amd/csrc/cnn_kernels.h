@@ -79,15 +79,27 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
 // conv forward + bias + ReLU  (architectures/dqn.py:42-52; flax nn.Conv: NHWC x HWIO, cross-correlation)
 // workgroup = (net, batch block, group of NPW output positions); waves = (out-channel tile, position subset)
 // --------------------------------------------------------------------------------------------
+// A "variant" is one sub-convolution of a launch.  The forward convs have one; the data gradient of the
+// stride-2 Conv_1 is four stride-1 sub-convolutions (one per output parity) folded into one launch.
+struct ConvVariant {
+    long w_off;                // offset of this variant's [KH][KW*CI][CO] weight block from the net's base
+    int in_off_h, in_off_w;    // added to (oh*S, ow*S): first padded input row / column of output (0, 0)
+    int OH, OW;                // output extent of the variant
+    int out_mul, out_add_h, out_add_w;  // output position (oh, ow) -> (oh*out_mul + out_add_h, ow*out_mul + out_add_w)
+    int pg_begin;              // first position group of this variant inside a (net, batch block)
+};
 struct ConvFwdArgs {
     const float* in;            // [n_in_sets][nb][in_block]  zero-bordered
     float* out;                 // [n_nets][nb][out_block]
-    const float* const* wbase;  // [n_nets] parameter base of each net (online or target arena slice)
+    const float* const* wbase;  // [n_nets] parameter base of each net (online or target arena slice) ...
+    const float* wt_base;       // ... or, when non-null, a dense [n_nets][wt_stride] buffer of transformed weights
     const int* in_set;          // [n_nets] which input set a net reads
-    long w_off, b_off, in_block, out_block, n_items;
-    int n_nets, nb, npg, n_ct;
-    int KH, KWCI, S, CI, CO, IWp;       // KWCI = KW * CI (taps of one kernel row are contiguous rows)
-    int OH, OW, out_Wp, out_lo_h, out_lo_w;
+    const float* mask;          // epilogue 1: forward activation whose sign masks the result [n_nets][nb][mask_block]
+    long wt_stride, b_off, in_block, out_block, mask_block, n_items;
+    int n_nets, nb, npg, n_var, epilogue;  // epilogue 0: + bias, ReLU.   1: * (mask > 0), no bias (data gradient)
+    int KH, KWCI, S, CI, CO, IWp;          // KWCI = KW * CI (taps of one kernel row are contiguous rows)
+    int out_Wp, out_lo_h, out_lo_w, mask_Wp, mask_lo_h, mask_lo_w;
+    ConvVariant var[4];
 };
 
 // Workgroup tile = all CO out channels x NPW output positions (x 32 samples) of one (net, batch block).
@@ -106,29 +118,35 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FL];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     int item = blockIdx.x;
-    const int pg = item % a.npg;
+    int pg = item % a.npg;
     item /= a.npg;
     const int bb = item % a.nb;
     const int n = item / a.nb;
+    int vi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < a.n_var && pg >= a.var[i].pg_begin) vi = i;
+    const ConvVariant& v = a.var[vi];
+    pg -= v.pg_begin;
     const int ct = wave % CT, sub = wave / CT;
-    const float* pbase = a.wbase[n];
-    const float* Wg = pbase + a.w_off + t * 4;
-    const float* bias = pbase + a.b_off + ct * 32;
+    const float* pbase = a.wt_base ? a.wt_base + (long)n * a.wt_stride : a.wbase[n];
+    const float* Wg = pbase + v.w_off + t * 4;
     const float* Xg = a.in + ((long)a.in_set[n] * a.nb + bb) * a.in_block + t * 4;
     float* Y = a.out + ((long)n * a.nb + bb) * a.out_block;
-    const int npos = a.OH * a.OW;
+    const int npos = v.OH * v.OW;
     long xoff[NPW];
 #pragma unroll
     for (int p = 0; p < NPW; ++p) {
         int pos = min(pg * NPW + p, npos - 1);
-        int oh = pos / a.OW, ow = pos - oh * a.OW;
-        xoff[p] = ((long)(oh * a.S) * a.IWp + ow * a.S) * a.CI * 32;
+        int oh = pos / v.OW, ow = pos - oh * v.OW;
+        xoff[p] = ((long)(oh * a.S + v.in_off_h) * a.IWp + ow * a.S + v.in_off_w) * a.CI * 32;
     }
+    const float bias_on = a.epilogue == 0 ? 1.f : 0.f;
     f32x16 acc[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = bias[mfma_row(r, h)];
+        for (int r = 0; r < 16; ++r) acc[i][r] = pbase[a.b_off + ct * 32 + mfma_row(r, h)] * bias_on;  // b_off = 0 when off
     const int JC = a.KWCI / KC, NC = a.KH * JC;
     const long wrow = (long)a.KWCI * CO, xrow = (long)a.IWp * a.CI * 32;
     // LDS-DMA (global_load_lds_dwordx4): every wave copies 1 KiB pieces, lane l <- 16 B at source + 16 l,
@@ -165,12 +183,52 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
     for (int i = 0; i < PPW; ++i) {
         const int pos = pg * NPW + sub * PPW + i;
         if (pos < npos) {
-            int oh = pos / a.OW, ow = pos - oh * a.OW;
-            long row0 = ((long)(oh + a.out_lo_h) * a.out_Wp + (ow + a.out_lo_w)) * a.CO + ct * 32;
+            const int oh = pos / v.OW, ow = pos - oh * v.OW;
+            const int yh = oh * v.out_mul + v.out_add_h, yw = ow * v.out_mul + v.out_add_w;
+            const long row0 = ((long)(yh + a.out_lo_h) * a.out_Wp + (yw + a.out_lo_w)) * CO + ct * 32;
+            if (a.epilogue == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Y[(row0 + mfma_row(r, h)) * 32 + bl] = fmaxf(acc[i][r], 0.f);
+                for (int r = 0; r < 16; ++r) Y[(row0 + mfma_row(r, h)) * 32 + bl] = fmaxf(acc[i][r], 0.f);
+            } else {
+                const float* M = a.mask + ((long)n * a.nb + bb) * a.mask_block +
+                                 (((long)(yh + a.mask_lo_h) * a.mask_Wp + (yw + a.mask_lo_w)) * CO + ct * 32) * 32 + bl;
+                float mk[16];  // all mask loads before the (may-alias) stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mk[r] = M[mfma_row(r, h) * 32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[(row0 + mfma_row(r, h)) * 32 + bl] = mk[r] > 0.f ? acc[i][r] : 0.f;
+            }
         }
     }
+}
+
+// Transformed weights for the data gradients-as-forward-convolutions:
+//   wt[net][variant][kh'][kw'][co][ci] = W[net][kh(kh', variant)][kw(kw', variant)][ci][co]
+// with kh = (r + PL) % S + S * (K/S - 1 - kh') for output parity r (a plain flip when S == 1).  <= 150 KB/head.
+struct WtBuildArgs {
+    const float* const* wbase;  // [K] online parameter bases
+    float* wt;                  // [K][wt_stride]
+    long w_off, wt_stride;
+    int K, KH, KW, CI, CO, S, PLh, PLw, n_var, KHs, KWs;  // KHs x KWs taps per variant
+};
+__global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs a) {
+    const long per_var = (long)a.KHs * a.KWs * a.CO * a.CI;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (e >= per_var * a.n_var) return;
+    const int vi = (int)(e / per_var);
+    long r = e - vi * per_var;
+    const int ci = (int)(r % a.CI);
+    r /= a.CI;
+    const int co = (int)(r % a.CO);
+    r /= a.CO;
+    const int kws = (int)(r % a.KWs), khs = (int)(r / a.KWs);
+    // variant = (row parity rh, col parity rw) of the OUTPUT position (one variant when S == 1);
+    // ph = (r + PL) % S is the residue of the kernel taps that reach it, taken in descending order
+    const int rh = vi / a.S, rw = vi % a.S;
+    const int kh = (rh + a.PLh) % a.S + a.S * (a.KHs - 1 - khs);
+    const int kw = (rw + a.PLw) % a.S + a.S * (a.KWs - 1 - kws);
+    a.wt[(long)k * a.wt_stride + e] = a.wbase[k][a.w_off + ((long)(kh * a.KW + kw) * a.CI + ci) * a.CO + co];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -679,86 +737,12 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// conv data gradient (+ ReLU mask of the layer below)
+// conv data gradient (+ ReLU mask of the layer below): NOT a kernel of its own.
 //   din[ih][iw][ci][b] = relu'(act_in) * sum_{kh,kw,co} W[kh][kw][ci][co] * dout[oh][ow][co][b],
-//   oh = (ih + PLh - kh) / S for the kh with (ih + PLh - kh) % S == 0 (zero-bordered dout covers oh = -1 ..)
-// item = (head, batch block, input position, 32-wide ci tile)
+//   oh = (ih + PL - kh) / S for the kh with (ih + PL - kh) % S == 0
+// is a stride-1 forward convolution over the zero-bordered dout buffer with flipped / transposed weights
+// (per output parity when S > 1), so it runs on k_conv_fwd (epilogue 1) after k_wt_build -- see cnn_backward.
 // --------------------------------------------------------------------------------------------
-struct ConvDgradArgs {
-    const float* dout;    // [K][nb][gd.block]   zero-bordered
-    const float* act_in;  // [2K][nb][gm.block]  forward activation of this conv's INPUT (online nets first)
-    float* din;           // [K][nb][gi.block]
-    const float* const* wbase;
-    long w_off, n_items;
-    int K, nb, n_cit, KH, KW, S, PLh, PLw, CI, CO, IH, IW;
-    ActGeom gd, gm, gi;
-};
-
-__global__ __launch_bounds__(256) void k_conv_dgrad(ConvDgradArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;
-    const int cit = (int)(item % a.n_cit);
-    item /= a.n_cit;
-    const int pos = (int)(item % (a.IH * a.IW));
-    item /= (a.IH * a.IW);
-    const int bb = (int)(item % a.nb);
-    const int k = (int)(item / a.nb);
-    const int ih = pos / a.IW, iw = pos - ih * a.IW;
-    const float* W = a.wbase[k] + a.w_off + (long)(cit * 32 + bl) * a.CO + 16 * h;
-    const float* D = a.dout + ((long)k * a.nb + bb) * a.gd.block + (long)(16 * h) * 32 + bl;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // chunks = (valid kh) x (valid kw) x (32-wide co chunk); 16 k-steps each, double-buffered
-    const int kh0 = (ih + a.PLh) % a.S, kw0 = (iw + a.PLw) % a.S;
-    const int nkh = (a.KH - kh0 + a.S - 1) / a.S, nkw = (a.KW - kw0 + a.S - 1) / a.S, ncc = a.CO / 32;
-    const int NC = nkh * nkw * ncc;
-    float4 wv[2][4];
-    float dv[2][16];
-#define CDG_LOAD(c, s)                                                                          \
-    {                                                                                           \
-        const int tap_ = (c) / ncc, cc_ = (c) - tap_ * ncc;                                     \
-        const int ikh_ = tap_ / nkw, ikw_ = tap_ - ikh_ * nkw;                                  \
-        const int kh_ = kh0 + ikh_ * a.S, kw_ = kw0 + ikw_ * a.S;                               \
-        const int ohp_ = (ih + a.PLh - kh_) / a.S + a.gd.lo_h, owp_ = (iw + a.PLw - kw_) / a.S + a.gd.lo_w; \
-        const float* wt_ = W + (long)(kh_ * a.KW + kw_) * a.CI * a.CO + cc_ * 32;               \
-        const float* d_ = D + (((long)ohp_ * a.gd.Wp + owp_) * a.CO + cc_ * 32) * 32;           \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
-            wv[s][u] = *reinterpret_cast<const float4*>(wt_ + 4 * u);                           \
-        _Pragma("unroll") for (int t = 0; t < 16; ++t) dv[s][t] = d_[t * 32];                   \
-    }
-#define CDG_MMA(s)                                                    \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                   \
-        acc = mfma32(wv[s][u].x, dv[s][4 * u + 0], acc);              \
-        acc = mfma32(wv[s][u].y, dv[s][4 * u + 1], acc);              \
-        acc = mfma32(wv[s][u].z, dv[s][4 * u + 2], acc);              \
-        acc = mfma32(wv[s][u].w, dv[s][4 * u + 3], acc);              \
-    }
-    CDG_LOAD(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < NC; c += 2) {
-        CDG_LOAD(min(c + 1, NC - 1), 1)
-        __builtin_amdgcn_sched_barrier(0);
-        CDG_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        CDG_LOAD(min(c + 2, NC - 1), 0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NC) CDG_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef CDG_LOAD
-#undef CDG_MMA
-    const float* M = a.act_in + ((long)k * a.nb + bb) * a.gm.block +
-                     (((long)(ih + a.gm.lo_h) * a.gm.Wp + (iw + a.gm.lo_w)) * a.CI + cit * 32) * 32 + bl;
-    float* O = a.din + ((long)k * a.nb + bb) * a.gi.block +
-               (((long)(ih + a.gi.lo_h) * a.gi.Wp + (iw + a.gi.lo_w)) * a.CI + cit * 32) * 32 + bl;
-    float mk[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mk[r] = M[mfma_row(r, h) * 32];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[mfma_row(r, h) * 32] = mk[r] > 0.f ? acc[r] : 0.f;
-}
 
 // --------------------------------------------------------------------------------------------
 // conv weight gradient: partial slabs over chunks of output positions

@@ -154,6 +154,8 @@ struct idqn_handle_s {
     NetSet train, infer;
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
+    float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
+    long wt_stride[3] = {0, 0, 0};
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
     int head_lds = 0;
@@ -260,6 +262,12 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
     if ((rc = alloc_zero(&h->hbuf, (long)2 * K * nb * h->J * 32, h, "h"))) return rc;
     if ((rc = alloc_zero(&h->qpart, (long)2 * K * nb * (h->J / 32) * 32 * 32, h, "qpart"))) return rc;
+    for (int i = 1; i < 3; ++i) {
+        const ConvL& cl = h->conv[i];
+        IDQN_REQUIRE(cl.K % cl.S == 0, "conv %d: kernel %d not a multiple of stride %d", i, cl.K, cl.S);
+        h->wt_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + 63) / 64 * 64;
+        if ((rc = alloc_zero(&h->wt[i], (long)K * h->wt_stride[i], h, i == 1 ? "wt1" : "wt2"))) return rc;
+    }
     // weight-gradient slabs: one per workgroup chunk of 16 output positions; one region per conv layer
     long slab_total = 0;
     for (int i = 0; i < 3; ++i) {
@@ -315,17 +323,20 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     for (int i = 0; i < 3; ++i) {
         const ConvL& l = h->conv[i];
         ConvFwdArgs a;
-        a.in = ins[i]; a.out = outs[i]; a.wbase = s.wbase; a.in_set = (i == 0) ? s.in_set : s.ident;
-        a.w_off = l.w_off; a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
-        a.n_nets = s.n_nets; a.nb = nb;
+        memset(&a, 0, sizeof(a));
+        a.in = ins[i]; a.out = outs[i]; a.wbase = s.wbase; a.wt_base = nullptr; a.in_set = (i == 0) ? s.in_set : s.ident;
+        a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
+        a.n_nets = s.n_nets; a.nb = nb; a.n_var = 1; a.epilogue = 0;
         a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
-        a.OH = l.OH; a.OW = l.OW; a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
-        a.n_ct = l.CO / 32;
+        a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
         IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
-        const int npw = (a.n_ct == 1) ? 4 : 2;  // positions per workgroup (one per wave x position subsets)
+        const int npw = (l.CO == 32) ? 4 : 2;  // positions per workgroup
+        ConvVariant& v = a.var[0];
+        v.w_off = l.w_off; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
+        v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0; v.pg_begin = 0;
         a.npg = cdiv(l.OH * l.OW, npw);
         a.n_items = (long)s.n_nets * nb * a.npg;
-        if (a.n_ct == 1)
+        if (l.CO == 32)
             hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
         else
             hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
@@ -395,15 +406,45 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const ActGeom* gact[3] = {&h->gx, &h->ga1, &h->ga2};
     float* dins[3] = {nullptr, h->da1, h->da2};
     const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
+    // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
     for (int i = 2; i >= 1; --i) {
-        ConvDgradArgs a;
-        a.dout = douts[i]; a.act_in = acts_in[i]; a.din = dins[i]; a.wbase = s.wbase; a.w_off = cl[i]->w_off;
-        a.K = K; a.nb = nb; a.n_cit = cl[i]->CI / 32; a.KH = cl[i]->K; a.KW = cl[i]->K; a.S = cl[i]->S;
-        a.PLh = cl[i]->PLh; a.PLw = cl[i]->PLw; a.CI = cl[i]->CI; a.CO = cl[i]->CO; a.IH = cl[i]->IH; a.IW = cl[i]->IW;
-        a.gd = *gdo[i]; a.gm = *gact[i]; a.gi = *gdi[i];
-        a.n_items = (long)K * nb * a.IH * a.IW * a.n_cit;
-        hipLaunchKernelGGL(k_conv_dgrad, dim3(cdiv(a.n_items, 4)), dim3(256), 0, q, a);
-        // weight gradient of layer i can run as soon as its dout exists (it does: douts[i])
+        const ConvL& l = *cl[i];
+        const int KHs = l.K / l.S, nvar = l.S * l.S;
+        WtBuildArgs wb;
+        wb.wbase = s.wbase; wb.wt = h->wt[i]; wb.w_off = l.w_off; wb.wt_stride = h->wt_stride[i];
+        wb.K = K; wb.KH = l.K; wb.KW = l.K; wb.CI = l.CI; wb.CO = l.CO; wb.S = l.S; wb.PLh = l.PLh; wb.PLw = l.PLw;
+        wb.n_var = nvar; wb.KHs = KHs; wb.KWs = KHs;
+        hipLaunchKernelGGL(k_wt_build, dim3(cdiv((long)l.K * l.K * l.CI * l.CO, 256), K), dim3(256), 0, q, wb);
+        ConvFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = douts[i]; a.out = dins[i]; a.wbase = s.wbase; a.wt_base = h->wt[i]; a.wt_stride = h->wt_stride[i];
+        a.in_set = s.ident; a.mask = acts_in[i];
+        a.in_block = gdo[i]->block; a.out_block = gdi[i]->block; a.mask_block = gact[i]->block;
+        a.n_nets = K; a.nb = nb; a.n_var = nvar; a.epilogue = 1;
+        a.KH = KHs; a.KWCI = KHs * l.CO; a.S = 1; a.CI = l.CO; a.CO = l.CI; a.IWp = gdo[i]->Wp;
+        a.out_Wp = gdi[i]->Wp; a.out_lo_h = gdi[i]->lo_h; a.out_lo_w = gdi[i]->lo_w;
+        a.mask_Wp = gact[i]->Wp; a.mask_lo_h = gact[i]->lo_h; a.mask_lo_w = gact[i]->lo_w;
+        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d dgrad: %d rows per kernel row is not a multiple of 32", i, a.KWCI);
+        const int npw = (l.CI == 32) ? 4 : 2;
+        int pg = 0;
+        for (int vi = 0; vi < nvar; ++vi) {
+            const int rh = vi / l.S, rw = vi % l.S;
+            const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
+            ConvVariant& v = a.var[vi];
+            v.w_off = (long)vi * KHs * KHs * l.CO * l.CI;
+            v.in_off_h = (rh + l.PLh - ph) / l.S + gdo[i]->lo_h - KHs + 1;
+            v.in_off_w = (rw + l.PLw - pw) / l.S + gdo[i]->lo_w - KHs + 1;
+            v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
+            v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw; v.pg_begin = pg;
+            IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
+            pg += cdiv(v.OH * v.OW, npw);
+        }
+        a.npg = pg;
+        a.n_items = (long)K * nb * a.npg;
+        if (l.CI == 32)
+            hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+        else
+            hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
     }
     // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
     SlabReduceArgs r;
