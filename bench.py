@@ -105,6 +105,7 @@ def main():
 
     from slimdqn import _hip
     from slimdqn.networks.idqn import iDQN
+    from slimdqn.networks.parallel import data_parallel_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,11 +132,7 @@ def main():
         if not dp:
             agent._learn(batch, flags=(_hip.F_PROFILE if profile else 0) | extra)
         else:
-            agent._learn(batch, flags=_hip.F_GRADS_ONLY | (_hip.F_PROFILE if profile else 0) | extra,
-                         mean_divisor=global_batch)
-            dist.all_reduce(agent._grad)       # sum of shard gradients == gradient of the 32*N batch
-            dist.all_reduce(agent._losses)
-            agent._apply_adam()
+            data_parallel_step(agent, batch, global_batch, extra_flags=(_hip.F_PROFILE if profile else 0) | extra)
 
     for _ in range(args.warmup):
         step(False)
@@ -170,6 +167,13 @@ def main():
         per_head = (6 if fused else 1) * P_w0 * 4 + 7744 * 32 * 4 + 512 * 32 * 4
         alg_bytes = K_HEADS * per_head
         achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), fused kernel only
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            if fused:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "i-DQN grad-steps/sec, Nature-CNN K=5 batch=32",
             "value": args.steps * world / elapsed,
@@ -190,7 +194,7 @@ def main():
                        "parallelism": f"dp{world}" if dp else "single"},
             "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes},
         "final_losses": [float(x) for x in losses],
         }

@@ -264,3 +264,26 @@ def test_dqn_is_the_k1_case():
     assert updated and logs["loss"] == pytest.approx(want / 200, rel=1e-5)
     for n, v in agent._flat(agent._target).items():
         np.testing.assert_array_equal(v, agent._flat(agent._online)[n])
+
+
+@pytest.mark.parametrize("env_name", ["lunar_lander", "atari"])
+def test_entry_points_train_end_to_end(env_name, tmp_path):
+    """experiments/{lunar_lander,atari}/idqn.py counterpart: collect -> update_online -> update_target on the HIP path."""
+    import pickle
+
+    if env_name == "lunar_lander":
+        from experiments.lunar_lander.idqn import run
+
+        argv = ["-en", "t", "-s", "1", "-ne", "1", "-ntspe", "120", "-nis", "40", "-rbc", "200", "-nn", "3",
+                "-tuf", "20", "-tsf", "5", "-f", "32", "32", "-horizon", "30"]
+    else:
+        from experiments.atari.idqn import run
+
+        argv = ["-en", "t", "-s", "1", "-ne", "1", "-ntspe", "80", "-nis", "40", "-rbc", "100", "-nn", "2", "-at", "cnn",
+                "-tuf", "20", "-tsf", "5", "-f", "32", "64", "64", "128", "-horizon", "30", "-bs", "32"]
+    p, agent = run(argv, save_root=str(tmp_path))
+    logs = [r for r in p["wandb"].records if "loss" in r]
+    assert logs and all(np.isfinite(r["loss"]) and f"networks/{agent.n_networks - 1}_loss" in r for r in logs)
+    assert int(agent._count[0].item()) >= 40
+    model = pickle.load(open(os.path.join(p["save_path"], "models", "1"), "rb"))
+    assert set(model) == {"params"} and all(np.isfinite(v).all() for m in model["params"].values() for v in m.values())
