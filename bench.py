@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -110,11 +112,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_dp:
+        os.environ.setdefault("MASTER_PORT", "29533")
         assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
 
@@ -123,7 +126,7 @@ def main():
     # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
     batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i))) for i in range(8)]
     it = [0]
-    dp = world > 1
+    dp = world > 1 or args.force_dp
     global_batch = BATCH * world
 
     def step(profile, extra=0):

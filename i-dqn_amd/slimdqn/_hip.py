@@ -64,6 +64,10 @@ def lib():
     """Loads the extension (once).  Raises HipExtensionError if it was not built."""
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles the HIP runtime (libamdhip64) the process must share -- loading
+        # libidqn_hip.so before torch would bring in a second runtime and the later one finds no device
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise HipExtensionError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
