@@ -620,8 +620,7 @@ __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
 
 // --------------------------------------------------------------------------------------------
 // Dense_0 weight gradient (+ optionally fused Adam): g[f][j] = sum_b a3[f][b] * dh[j][b]
-// item = (head, 32-row f tile, 128-col j tile).  HBM-bound: the output (and, fused, theta/m/v) is
-// the 15.9 MB/head matrix; MFMA work is ~10 % of the streaming time.
+// HBM-bound: the output (and, fused, theta/m/v) is the 15.9 MB/head matrix; MFMA work is ~10 % of the time.
 // --------------------------------------------------------------------------------------------
 struct AdamConsts {
     float lr_neg, b1, b2, omb1, omb2, eps;
@@ -653,87 +652,89 @@ struct DenseWgradArgs {
     int K, nb, n_ft, n_jt, F, J;
 };
 
-template <bool FUSE_ADAM>
+// Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
+// on the MFMA (2 accumulators, k = the 32 samples per batch block) and parks it in LDS.  Phase 2: all 256
+// threads stream the tile row by row -- every wave-instruction moves one whole 1 KB row segment of theta / m / v
+// (16 B per lane), the gradient comes from LDS -- exactly the access pattern of the plain Adam kernel, which
+// reaches 6.9 TB/s on MI355X.  The first version kept the tile in accumulators and ran Adam from the MFMA
+// layout at 2 waves/SIMD (5.3 TB/s); this one needs ~100 registers and 32 KB of LDS (4-5 workgroups per CU).
+template <bool FUSE_ADAM, int NQ>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;
-    const int jt = (int)(item % a.n_jt);
+    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
+    __shared__ __attribute__((aligned(16))) float gs[32 * JT];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    int item = blockIdx.x;
+    const int jt = item % a.n_jt;
     item /= a.n_jt;
-    const int ft = (int)(item % a.n_ft);
-    const int k = (int)(item / a.n_ft);
-    const int f0 = ft * 32, j0 = jt * 128;
-    f32x16 acc[4];
+    const int ft = item % a.n_ft;
+    const int k = item / a.n_ft;
+    const int f0 = ft * 32, j0 = jt * JT, jw = wave * (32 * NQ);
+    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
+    // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
+    const int prow = wave * (64 / LPR) + lane / LPR, pcol = (lane % LPR) * 4;
+    const long o0 = base + (long)prow * a.J + pcol;
+    float4 th[2], mm[2], vv[2];
+    if (FUSE_ADAM) {  // the rows of iteration 0 are requested before the MFMA phase
+        th[0] = *reinterpret_cast<const float4*>(a.theta + o0);
+        mm[0] = *reinterpret_cast<const float4*>(a.mu + o0);
+        vv[0] = *reinterpret_cast<const float4*>(a.nu + o0);
+    }
+    f32x16 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0 + 4 * bl;
-    // Fused Adam streams theta / m / v of this 32 x 128 tile: 16 rows x 3 arrays x 16 B per lane.  Loads
-    // are issued a group of 4 rows AHEAD of the stores of the previous group (a load behind a may-alias
-    // store would otherwise wait for it), and group 0 is requested before the MFMA phase.
-    float4 th[2][4], mm[2][4], vv[2][4];
-#define WG_LOADG(g, s)                                                                   \
-    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                      \
-        const long o_ = base + (long)mfma_row(4 * (g) + x, h) * a.J;                     \
-        th[s][x] = *reinterpret_cast<const float4*>(a.theta + o_);                       \
-        mm[s][x] = *reinterpret_cast<const float4*>(a.mu + o_);                          \
-        vv[s][x] = *reinterpret_cast<const float4*>(a.nu + o_);                          \
-    }
-    if (FUSE_ADAM) {
-        WG_LOADG(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-    }
     for (int bb = 0; bb < a.nb; ++bb) {
         const float* Ap = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
         float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
         float4 x2 = *reinterpret_cast<const float4*>(Ap + 8), x3 = *reinterpret_cast<const float4*>(Ap + 12);
         const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
                               x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-        const float* Dp = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(j0 + 4 * bl) * 32 + 16 * h;
+        const float* Dp = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(j0 + jw + bl) * 32 + 16 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* dq = Dp + q * 32;
+        for (int q = 0; q < NQ; ++q) {
+            const float* dq = Dp + (long)q * 32 * 32;  // columns jw + 32 q + bl
             float4 y0 = *reinterpret_cast<const float4*>(dq), y1 = *reinterpret_cast<const float4*>(dq + 4);
             float4 y2 = *reinterpret_cast<const float4*>(dq + 8), y3 = *reinterpret_cast<const float4*>(dq + 12);
             const float bv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
                                   y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[q] = mfma32(av[t], bv[t], acc[q]);
+            for (int u = 0; u < 16; ++u) acc[q] = mfma32(av[u], bv[u], acc[q]);
         }
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gs[mfma_row(r, h) * JT + jw + 32 * q + bl] = acc[q][r];
+    __syncthreads();
     if (FUSE_ADAM) {
         const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int s = g & 1;
-            if (g + 1 < 4) {
-                if (s == 0) { WG_LOADG(g + 1, 1) } else { WG_LOADG(g + 1, 0) }
+        for (int i = 0; i < NIT; ++i) {
+            const int s = i & 1;
+            if (i + 1 < NIT) {  // next rows' state is requested before this row's (may-alias) stores
+                const long on = o0 + (long)(RPI * (i + 1)) * a.J;
+                th[s ^ 1] = *reinterpret_cast<const float4*>(a.theta + on);
+                mm[s ^ 1] = *reinterpret_cast<const float4*>(a.mu + on);
+                vv[s ^ 1] = *reinterpret_cast<const float4*>(a.nu + on);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int r = 4 * g + x;
-                const long o = base + (long)mfma_row(r, h) * a.J;
-                float4 t4 = th[s][x], m4 = mm[s][x], v4 = vv[s][x];
-                adam_elem(a.ad, bc1, bc2, acc[0][r], t4.x, m4.x, v4.x);
-                adam_elem(a.ad, bc1, bc2, acc[1][r], t4.y, m4.y, v4.y);
-                adam_elem(a.ad, bc1, bc2, acc[2][r], t4.z, m4.z, v4.z);
-                adam_elem(a.ad, bc1, bc2, acc[3][r], t4.w, m4.w, v4.w);
-                *reinterpret_cast<float4*>(a.theta + o) = t4;
-                *reinterpret_cast<float4*>(a.mu + o) = m4;
-                *reinterpret_cast<float4*>(a.nu + o) = v4;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            const float4 g = *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
+            float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
+            adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
+            adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
+            adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
+            adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
+            const long o = o0 + (long)(RPI * i) * a.J;
+            *reinterpret_cast<float4*>(a.theta + o) = t4;
+            *reinterpret_cast<float4*>(a.mu + o) = m4;
+            *reinterpret_cast<float4*>(a.nu + o) = v4;
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long o = base + (long)mfma_row(r, h) * a.J;
-            *reinterpret_cast<float4*>(a.grad + o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-        }
+        for (int i = 0; i < NIT; ++i)
+            *reinterpret_cast<float4*>(a.grad + o0 + (long)(RPI * i) * a.J) =
+                *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
-#undef WG_LOADG
 }
 
 // --------------------------------------------------------------------------------------------
@@ -747,8 +748,7 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
 // --------------------------------------------------------------------------------------------
 // conv weight gradient: partial slabs over chunks of output positions
 //   gW[kh][kw][ci][co] = sum_{b, oh, ow} in[oh*S+kh][ow*S+kw][ci][b] * dout[oh][ow][co][b]
-// workgroup = (head, kh, kw, position chunk), its 4 waves take every 4th position and reduce through LDS;
-// NIT x NOT accumulator tiles of 32x32 ([ci tile][co tile]) per wave.
+// workgroup = (head, kh, kw, position chunk); NIT x NOT tiles of 32x32 ([ci tile][co tile]), one per wave.
 // Conv_0 (CI = 4) runs the same code with the 32 rows (kw, ci) of one kernel row as its "ci tile".
 // --------------------------------------------------------------------------------------------
 struct ConvWgradArgs {
@@ -761,127 +761,114 @@ struct ConvWgradArgs {
     ActGeom gin, gd;
 };
 
+// v3: operands through LDS.  The k index (sample) is the contiguous one of both operands, so an MFMA lane
+// needs 16 floats of ITS OWN row; loading those straight from memory makes every lane touch its own cache
+// line (32 lines per dwordx4 instruction: the kernel was bound by the texture-address path, MFMA util 21-26 %).
+// Now the 256 threads copy whole 32-row blocks (4 KB, contiguous) with coalesced 16-B loads into an LDS image
+// whose rows are padded to 36 floats, and each lane reads its row with 4 x ds_read_b128: with stride 36 the 16
+// lanes of a ds_read_b128 group hit 16 distinct 4-bank slots (36 r mod 64 = 4 (9 r mod 16)) -- conflict-free.
+// The 4 waves are (tile pair) x (position slot): <2,2> = 4 tile pairs x 1 position, <1,2> = 2 x 2, <1,1> = 1 x 4.
 template <int NIT, int NOT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
-    // waves 1..3 park their accumulators here; wave 0 adds them in wave order and writes the slab
-    __shared__ float red[3][NIT * NOT * 16 + NOT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    int item = blockIdx.x;  // workgroup = (head, kh, kw, chunk of output positions); waves interleave positions
+    constexpr int NTP = NIT * NOT, PS = 4 / NTP, RPS = (NIT + NOT) * 32, ROWS = PS * RPS, NLD = ROWS / 32;
+    constexpr int LDR = 36;  // padded row stride (floats)
+    static_assert(NTP == 1 || NTP == 2 || NTP == 4, "4 waves = tile pairs x position slots");
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * LDR];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    int item = blockIdx.x;  // workgroup = (head, kh, kw, chunk of output positions)
     const int pc = item % a.npc;
     item /= a.npc;
     const int kw = item % a.KWe;
     item /= a.KWe;
     const int kh = item % a.KH;
     const int k = item / a.KH;
-    f32x16 acc[NIT][NOT];
+    const int tp = wave % NTP, slot = wave / NTP, it = tp / NOT, ot = tp % NOT;
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i)
-#pragma unroll
-        for (int o = 0; o < NOT; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][o][r] = 0.f;
-    float bsum[NOT];
-#pragma unroll
-    for (int o = 0; o < NOT; ++o) bsum[o] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
     const int npos = a.OH * a.OW;
-    const int p0 = pc * a.pos_per_chunk + wave, p1 = min(npos, pc * a.pos_per_chunk + a.pos_per_chunk);
-    // work list of this wave = (batch block, every 4th output position of the chunk); 16 k-steps (the 32
-    // samples) each, register double-buffered
-    const int npp = p1 > p0 ? (p1 - p0 + 3) / 4 : 0, NE = a.nb * npp;
-    const float* IN0 = a.in + (long)k * a.in_net_stride + (long)bl * 32 + 16 * h;
-    const float* DO0 = a.dout + (long)k * a.nb * a.gd.block + (long)bl * 32 + 16 * h;
-    float4 av[2][NIT][4], bv[2][NOT][4];
-#define CWG_LOAD(e, s)                                                                              \
-    {                                                                                               \
-        const int bb_ = (e) / npp, pos_ = p0 + 4 * ((e) - bb_ * npp);                               \
-        const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;                                       \
-        const float* ip_ = IN0 + (long)bb_ * a.gin.block +                                          \
-                           (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32;  \
-        const float* dp_ = DO0 + (long)bb_ * a.gd.block +                                           \
-                           (((long)(oh_ + a.gd.lo_h) * a.gd.Wp + (ow_ + a.gd.lo_w)) * a.CO) * 32;   \
-        _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                           \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
-                bv[s][o][u] = *reinterpret_cast<const float4*>(dp_ + (long)o * 1024 + 4 * u);       \
-        }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                           \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
-                av[s][i][u] = *reinterpret_cast<const float4*>(ip_ + (long)i * 1024 + 4 * u);       \
-        }                                                                                           \
+    const int p0 = pc * a.pos_per_chunk, p1 = min(npos, p0 + a.pos_per_chunk);
+    const int nrp = (p1 - p0 + PS - 1) / PS, NR = a.nb * nrp;  // rounds: PS positions each
+    const float* IN0 = a.in + (long)k * a.in_net_stride + t * 4;
+    const float* DO0 = a.dout + (long)k * a.nb * a.gd.block + t * 4;
+    const int wrow = (t >> 3) * LDR + (t & 7) * 4;  // where this thread's float4 of a 32-row block lands
+    float4 rg[NLD];
+#define CW_GLOAD(e)                                                                                   \
+    {                                                                                                 \
+        const int bb_ = (e) / nrp, pr_ = (e) - bb_ * nrp;                                             \
+        _Pragma("unroll") for (int s_ = 0; s_ < PS; ++s_) {                                           \
+            const int pos_ = p0 + pr_ * PS + s_;                                                      \
+            const bool ok_ = pos_ < p1;                                                               \
+            const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;                                     \
+            const float* ip_ = IN0 + (long)bb_ * a.gin.block +                                        \
+                               (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32; \
+            const float* dp_ = DO0 + (long)bb_ * a.gd.block +                                         \
+                               (((long)(oh_ + a.gd.lo_h) * a.gd.Wp + (ow_ + a.gd.lo_w)) * a.CO) * 32; \
+            _Pragma("unroll") for (int i_ = 0; i_ < NIT; ++i_)                                        \
+                rg[s_ * (NIT + NOT) + i_] = ok_ ? *reinterpret_cast<const float4*>(ip_ + i_ * 1024)   \
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);                    \
+            _Pragma("unroll") for (int o_ = 0; o_ < NOT; ++o_)                                        \
+                rg[s_ * (NIT + NOT) + NIT + o_] = ok_ ? *reinterpret_cast<const float4*>(dp_ + o_ * 1024) \
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);              \
+        }                                                                                             \
     }
-#define CWG_MMA(s)                                                                                  \
-    {                                                                                               \
-        _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                           \
-            float sb_ = 0.f;                                                                        \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                           \
-                sb_ += (bv[s][o][u].x + bv[s][o][u].y) + (bv[s][o][u].z + bv[s][o][u].w);           \
-            bsum[o] += sb_;                                                                         \
-        }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                           \
-            _Pragma("unroll") for (int o = 0; o < NOT; ++o) {                                       \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                     \
-                    acc[i][o] = mfma32(av[s][i][u].x, bv[s][o][u].x, acc[i][o]);                    \
-                    acc[i][o] = mfma32(av[s][i][u].y, bv[s][o][u].y, acc[i][o]);                    \
-                    acc[i][o] = mfma32(av[s][i][u].z, bv[s][o][u].z, acc[i][o]);                    \
-                    acc[i][o] = mfma32(av[s][i][u].w, bv[s][o][u].w, acc[i][o]);                    \
-                }                                                                                   \
-            }                                                                                       \
-        }                                                                                           \
-    }
-    if (NE > 0) {
-        CWG_LOAD(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        for (int e = 0; e < NE; e += 2) {
-            CWG_LOAD(min(e + 1, NE - 1), 1)
-            __builtin_amdgcn_sched_barrier(0);
-            CWG_MMA(0)
-            __builtin_amdgcn_sched_barrier(0);
-            CWG_LOAD(min(e + 2, NE - 1), 0)
-            __builtin_amdgcn_sched_barrier(0);
-            if (e + 1 < NE) CWG_MMA(1)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef CWG_LOAD
-#undef CWG_MMA
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i)
-#pragma unroll
-            for (int o = 0; o < NOT; ++o)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][(i * NOT + o) * 16 + r][lane] = acc[i][o][r];
-#pragma unroll
-        for (int o = 0; o < NOT; ++o) red[wave - 1][NIT * NOT * 16 + o][lane] = bsum[o];
+#define CW_LSTORE(buf)                                                                                \
+    _Pragma("unroll") for (int b_ = 0; b_ < NLD; ++b_)                                                \
+        *reinterpret_cast<float4*>(&lds[(buf) * ROWS * LDR + b_ * 32 * LDR + wrow]) = rg[b_];
+    if (NR > 0) {
+        CW_GLOAD(0)
+        CW_LSTORE(0)
     }
     __syncthreads();
-    if (wave > 0) return;
+    const int arow = (slot * RPS + it * 32 + bl) * LDR + 16 * h;
+    const int brow = (slot * RPS + NIT * 32 + ot * 32 + bl) * LDR + 16 * h;
+    for (int e = 0; e < NR; ++e) {
+        const int buf = e & 1;
+        CW_GLOAD(min(e + 1, NR - 1))
+        const float* L = &lds[buf * ROWS * LDR];
+        float4 av[4], bv[4];
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+        for (int u = 0; u < 4; ++u) {
+            av[u] = *reinterpret_cast<const float4*>(L + arow + 4 * u);
+            bv[u] = *reinterpret_cast<const float4*>(L + brow + 4 * u);
+        }
 #pragma unroll
-        for (int i = 0; i < NIT; ++i)
+        for (int u = 0; u < 4; ++u) {
+            bsum += (bv[u].x + bv[u].y) + (bv[u].z + bv[u].w);
+            acc = mfma32(av[u].x, bv[u].x, acc);
+            acc = mfma32(av[u].y, bv[u].y, acc);
+            acc = mfma32(av[u].z, bv[u].z, acc);
+            acc = mfma32(av[u].w, bv[u].w, acc);
+        }
+        CW_LSTORE(buf ^ 1)  // the last (redundant) copy lands in the buffer nobody reads any more
+        __syncthreads();
+    }
+#undef CW_GLOAD
+#undef CW_LSTORE
+    // position slots > 0 park their tile in LDS (free now); slot 0 adds them in slot order and writes the slab
+    float* red = lds;  // [PS - 1][NTP][17][64]
+    if (slot > 0) {
 #pragma unroll
-            for (int o = 0; o < NOT; ++o)
+        for (int r = 0; r < 16; ++r) red[(((slot - 1) * NTP + tp) * 17 + r) * 64 + lane] = acc[r];
+        red[(((slot - 1) * NTP + tp) * 17 + 16) * 64 + lane] = bsum;
+    }
+    __syncthreads();
+    if (slot > 0) return;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][o][r] += red[w][(i * NOT + o) * 16 + r][lane];
+    for (int s2 = 1; s2 < PS; ++s2) {
 #pragma unroll
-        for (int o = 0; o < NOT; ++o) bsum[o] += red[w][NIT * NOT * 16 + o][lane];
+        for (int r = 0; r < 16; ++r) acc[r] += red[(((s2 - 1) * NTP + tp) * 17 + r) * 64 + lane];
+        bsum += red[(((s2 - 1) * NTP + tp) * 17 + 16) * 64 + lane];
     }
     float* S = a.slab + ((long)pc * a.K + k) * a.slab_stride;
-    const long wrow0 = (long)(kh * a.KWe + kw) * a.CIe;
+    const long wrow0 = (long)(kh * a.KWe + kw) * a.CIe + it * 32;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i)
-#pragma unroll
-        for (int o = 0; o < NOT; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                S[(wrow0 + i * 32 + mfma_row(r, h)) * a.CO + o * 32 + bl] = acc[i][o][r];
-    if (kh == 0 && kw == 0) {
+    for (int r = 0; r < 16; ++r) S[(wrow0 + mfma_row(r, h)) * a.CO + ot * 32 + bl] = acc[r];
+    if (kh == 0 && kw == 0 && it == 0) {
         const long wsize = (long)a.KH * a.KWe * a.CIe * a.CO;
-#pragma unroll
-        for (int o = 0; o < NOT; ++o) {
-            float s = bsum[o] + __shfl_xor(bsum[o], 32);
-            if (h == 0) S[wsize + o * 32 + bl] = s;
-        }
+        const float sb = bsum + __shfl_xor(bsum, 32);
+        if (h == 0) S[wsize + ot * 32 + bl] = sb;
     }
 }
 

@@ -387,13 +387,15 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     DenseWgradArgs dw;
     dw.a3 = s.a3; dw.dh = h->dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
     dw.bcinv = h->bcinv; dw.ad = h->ad; dw.w_off = h->off_w0; dw.P = h->L.head_stride;
-    dw.K = K; dw.nb = nb; dw.n_ft = h->F / 32; dw.n_jt = h->J / 128; dw.F = h->F; dw.J = h->J;
-    dw.n_items = (long)K * dw.n_ft * dw.n_jt;
+    const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
+    dw.K = K; dw.nb = nb; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq); dw.F = h->F; dw.J = h->J;
+    dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
     if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
-    if (fuse_adam)
-        hipLaunchKernelGGL(k_dense0_wgrad<true>, dim3(cdiv(dw.n_items, 4)), dim3(256), 0, q, dw);
-    else
-        hipLaunchKernelGGL(k_dense0_wgrad<false>, dim3(cdiv(dw.n_items, 4)), dim3(256), 0, q, dw);
+    const dim3 wgrid((unsigned)dw.n_items);
+    if (fuse_adam && nq == 2) hipLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, dw);
+    else if (fuse_adam) hipLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, dw);
+    else if (nq == 2) hipLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, dw);
+    else hipLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, dw);
     if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
         IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
         h->ev_used += 2;
