@@ -50,12 +50,22 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
     {
         const int b = t >> 3, c = t & 7;
         const int bg = bb * 32 + b;
+        const long e8 = e0 + c * 8;
+        if (bg < a.B && e8 + 8 <= a.E && (((uintptr_t)src + (long)bg * a.E + e8) & 7) == 0) {
+            const uint2 w = *reinterpret_cast<const uint2*>(src + (long)bg * a.E + e8);  // 8 pixels per load
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            long e = e0 + c * 8 + i;
-            float v = 0.f;
-            if (bg < a.B && e < a.E) v = (float)src[(long)bg * a.E + e] / 255.0f;
-            tile[c * 8 + i][b] = v;
+            for (int i = 0; i < 8; ++i) {
+                const unsigned u = ((i < 4 ? w.x : w.y) >> (8 * (i & 3))) & 0xffu;
+                tile[c * 8 + i][b] = (float)u / 255.0f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                long e = e8 + i;
+                float v = 0.f;
+                if (bg < a.B && e < a.E) v = (float)src[(long)bg * a.E + e] / 255.0f;
+                tile[c * 8 + i][b] = v;
+            }
         }
     }
     __syncthreads();
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
     constexpr int A_FL = KC * CO, B_FL = KC * 32, BUF_FL = A_FL + NPW * B_FL;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FL];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    int item = blockIdx.x;
+    int item = xcd_contiguous_id();  // an XCD walks consecutive position groups of one net: halo rows hit its L2
     int pg = item % a.npg;
     item /= a.npg;
     const int bb = item % a.nb;
@@ -205,13 +215,18 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
 // Transformed weights for the data gradients-as-forward-convolutions:
 //   wt[net][variant][kh'][kw'][co][ci] = W[net][kh(kh', variant)][kw(kw', variant)][ci][co]
 // with kh = (r + PL) % S + S * (K/S - 1 - kh') for output parity r (a plain flip when S == 1).  <= 150 KB/head.
+struct WtLayer {
+    float* wt;  // [K][wt_stride]
+    long w_off, wt_stride;
+    int KH, KW, CI, CO, S, PLh, PLw, n_var, KHs, KWs;  // KHs x KWs taps per variant
+};
 struct WtBuildArgs {
     const float* const* wbase;  // [K] online parameter bases
-    float* wt;                  // [K][wt_stride]
-    long w_off, wt_stride;
-    int K, KH, KW, CI, CO, S, PLh, PLw, n_var, KHs, KWs;  // KHs x KWs taps per variant
+    WtLayer layer[2];           // blockIdx.z selects the layer
+    int K;
 };
-__global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs a) {
+__global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs args) {
+    const WtLayer& a = args.layer[blockIdx.z];
     const long per_var = (long)a.KHs * a.KWs * a.CO * a.CI;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs a) {
     const int rh = vi / a.S, rw = vi % a.S;
     const int kh = (rh + a.PLh) % a.S + a.S * (a.KHs - 1 - khs);
     const int kw = (rw + a.PLw) % a.S + a.S * (a.KWs - 1 - kws);
-    a.wt[(long)k * a.wt_stride + e] = a.wbase[k][a.w_off + ((long)(kh * a.KW + kw) * a.CI + ci) * a.CO + co];
+    a.wt[(long)k * a.wt_stride + e] = args.wbase[k][a.w_off + ((long)(kh * a.KW + kw) * a.CI + ci) * a.CO + co];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -385,9 +400,12 @@ struct TdArgs {
     float* q_dbg;   // [2K][nb][32][32]
     float* grad;    // [K][P]
     float* losses;  // [K]
-    const int32_t* count;  // [K] optax step counter (pre-increment)
+    int32_t* count;        // [K] optax step counter (pre-increment)
     float* bcinv;          // [K][2] out: reciprocal Adam bias corrections of THIS step
     float b1, b2;          // Adam decay rates (f32, as folded by the host)
+    double* cum;           // [K] running f64 sum of the per-head losses (idqn.py:72)
+    int finish_step;       // 1: this launch also does count += 1 and cum += loss (every later kernel of the step
+                           //    reads bcinv, not count); 0: two-phase step, idqn_apply_adam's epilogue does it
 };
 
 __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
@@ -494,6 +512,10 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
             const double tt = (double)(a.count[k] + 1);
             a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
             a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+            if (a.finish_step) {
+                a.count[k] += 1;
+                a.cum[k] = a.cum[k] + (double)(loss_acc / (float)a.Bdiv);
+            }
         }
     }
 }
@@ -564,7 +586,7 @@ __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dlds[];  // [J][32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     const int n_wg_ft = (a.n_ft + 3) / 4;
-    int item = blockIdx.x;
+    int item = xcd_contiguous_id();  // an XCD keeps to (mostly) one head: its dh stays in that L2
     const int fg = item % n_wg_ft;
     item /= n_wg_ft;
     const int bb = item % a.nb;
@@ -775,13 +797,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     static_assert(NTP == 1 || NTP == 2 || NTP == 4, "4 waves = tile pairs x position slots");
     __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * LDR];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    int item = blockIdx.x;  // workgroup = (head, kh, kw, chunk of output positions)
-    const int pc = item % a.npc;
-    item /= a.npc;
+    // workgroup = (head, chunk of output positions, kh, kw) with the TAP fastest, on an XCD-contiguous index:
+    // the KH*KW workgroups that re-read one chunk's rows run back to back on one XCD (its L2 serves the re-reads;
+    // with the taps spread over all XCDs every L2 fetched every row: ~9x the traffic, 1.4 us per 16 KB round)
+    int item = xcd_contiguous_id();
     const int kw = item % a.KWe;
     item /= a.KWe;
     const int kh = item % a.KH;
-    const int k = item / a.KH;
+    item /= a.KH;
+    const int pc = item % a.npc;
+    const int k = item / a.npc;
     const int tp = wave % NTP, slot = wave / NTP, it = tp / NOT, ot = tp % NOT;
     f32x16 acc;
 #pragma unroll
@@ -793,57 +818,73 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     const float* IN0 = a.in + (long)k * a.in_net_stride + t * 4;
     const float* DO0 = a.dout + (long)k * a.nb * a.gd.block + t * 4;
     const int wrow = (t >> 3) * LDR + (t & 7) * 4;  // where this thread's float4 of a 32-row block lands
-    float4 rg[NLD];
-#define CW_GLOAD(e)                                                                                   \
-    {                                                                                                 \
-        const int bb_ = (e) / nrp, pr_ = (e) - bb_ * nrp;                                             \
-        _Pragma("unroll") for (int s_ = 0; s_ < PS; ++s_) {                                           \
-            const int pos_ = p0 + pr_ * PS + s_;                                                      \
-            const bool ok_ = pos_ < p1;                                                               \
-            const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;                                     \
-            const float* ip_ = IN0 + (long)bb_ * a.gin.block +                                        \
-                               (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32; \
-            const float* dp_ = DO0 + (long)bb_ * a.gd.block +                                         \
-                               (((long)(oh_ + a.gd.lo_h) * a.gd.Wp + (ow_ + a.gd.lo_w)) * a.CO) * 32; \
-            _Pragma("unroll") for (int i_ = 0; i_ < NIT; ++i_)                                        \
-                rg[s_ * (NIT + NOT) + i_] = ok_ ? *reinterpret_cast<const float4*>(ip_ + i_ * 1024)   \
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);                    \
-            _Pragma("unroll") for (int o_ = 0; o_ < NOT; ++o_)                                        \
-                rg[s_ * (NIT + NOT) + NIT + o_] = ok_ ? *reinterpret_cast<const float4*>(dp_ + o_ * 1024) \
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);              \
-        }                                                                                             \
-    }
-#define CW_LSTORE(buf)                                                                                \
-    _Pragma("unroll") for (int b_ = 0; b_ < NLD; ++b_)                                                \
-        *reinterpret_cast<float4*>(&lds[(buf) * ROWS * LDR + b_ * 32 * LDR + wrow]) = rg[b_];
-    if (NR > 0) {
-        CW_GLOAD(0)
-        CW_LSTORE(0)
-    }
-    __syncthreads();
+    // Global loads run THREE rounds ahead in a register ring (a workgroup is a serial chain of rounds of only
+    // ~0.5 us of MFMA work each, and few workgroups share a CU: with one round of lookahead every round paid
+    // a full load latency).  The ring is 3 x 8 NAMED float4 registers: as arrays hipcc demoted it to scratch.
     const int arow = (slot * RPS + it * 32 + bl) * LDR + 16 * h;
     const int brow = (slot * RPS + NIT * 32 + ot * 32 + bl) * LDR + 16 * h;
-    for (int e = 0; e < NR; ++e) {
-        const int buf = e & 1;
-        CW_GLOAD(min(e + 1, NR - 1))
-        const float* L = &lds[buf * ROWS * LDR];
-        float4 av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            av[u] = *reinterpret_cast<const float4*>(L + arow + 4 * u);
-            bv[u] = *reinterpret_cast<const float4*>(L + brow + 4 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bsum += (bv[u].x + bv[u].y) + (bv[u].z + bv[u].w);
-            acc = mfma32(av[u].x, bv[u].x, acc);
-            acc = mfma32(av[u].y, bv[u].y, acc);
-            acc = mfma32(av[u].z, bv[u].z, acc);
-            acc = mfma32(av[u].w, bv[u].w, acc);
-        }
-        CW_LSTORE(buf ^ 1)  // the last (redundant) copy lands in the buffer nobody reads any more
-        __syncthreads();
+    // source of block b (b-th 32-row block of a round: [slot][in tiles..., out tiles...]) of round e; branch-free
+    // (positions clamped; a slot past the chunk end is skipped at compute time)
+    auto src = [&](int e, int b) -> const float* {
+        const int bb_ = e / nrp, pr_ = e - bb_ * nrp;
+        const int s_ = b / (NIT + NOT), x_ = b - s_ * (NIT + NOT);
+        const int pos_ = min(p0 + pr_ * PS + s_, p1 - 1);
+        const int oh_ = pos_ / a.OW, ow_ = pos_ - oh_ * a.OW;
+        return x_ < NIT ? IN0 + (long)bb_ * a.gin.block +
+                              (((long)(oh_ * a.S + kh) * a.gin.Wp + (ow_ * a.S + kw)) * a.in_C) * 32 + x_ * 1024
+                        : DO0 + (long)bb_ * a.gd.block +
+                              (((long)(oh_ + a.gd.lo_h) * a.gd.Wp + (ow_ + a.gd.lo_w)) * a.CO) * 32 + (x_ - NIT) * 1024;
+    };
+    float4 A0, A1, A2, A3, A4, A5, A6, A7, B0, B1, B2, B3, B4, B5, B6, B7, C0, C1, C2, C3, C4, C5, C6, C7;
+#define CW_L1(R, b, e) if (b < NLD) R##b = *reinterpret_cast<const float4*>(src(e, b));
+#define CW_GLOAD(e, R) { CW_L1(R, 0, e) CW_L1(R, 1, e) CW_L1(R, 2, e) CW_L1(R, 3, e) CW_L1(R, 4, e) CW_L1(R, 5, e) CW_L1(R, 6, e) CW_L1(R, 7, e) }
+#define CW_S1(R, b, buf) if (b < NLD) *reinterpret_cast<float4*>(&lds[(buf) * ROWS * LDR + b * 32 * LDR + wrow]) = R##b;
+#define CW_LSTORE(buf, R) { CW_S1(R, 0, buf) CW_S1(R, 1, buf) CW_S1(R, 2, buf) CW_S1(R, 3, buf) CW_S1(R, 4, buf) CW_S1(R, 5, buf) CW_S1(R, 6, buf) CW_S1(R, 7, buf) }
+#define CW_COMPUTE(buf, e)                                                                            \
+    if ((e) < NR && p0 + ((e) % nrp) * PS + slot < p1) { /* wave-uniform: a real round and position */ \
+        const float* L = &lds[(buf) * ROWS * LDR];                                                    \
+        float4 av[4], bv[4];                                                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+            av[u] = *reinterpret_cast<const float4*>(L + arow + 4 * u);                               \
+            bv[u] = *reinterpret_cast<const float4*>(L + brow + 4 * u);                               \
+        }                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+            bsum += (bv[u].x + bv[u].y) + (bv[u].z + bv[u].w);                                        \
+            acc = mfma32(av[u].x, bv[u].x, acc);                                                      \
+            acc = mfma32(av[u].y, bv[u].y, acc);                                                      \
+            acc = mfma32(av[u].z, bv[u].z, acc);                                                      \
+            acc = mfma32(av[u].w, bv[u].w, acc);                                                      \
+        }                                                                                             \
     }
+    {
+        const int last = NR - 1;  // NR >= 1: every chunk holds at least one position
+        CW_GLOAD(0, A)
+        CW_GLOAD(min(1, last), B)
+        CW_GLOAD(min(2, last), C)
+        CW_LSTORE(0, A)
+        lds_barrier();
+        // every step: request round e+3 into the ring slot just freed, compute round e from LDS, park round
+        // e+1 (loaded two steps ago) in the other LDS buffer.  Loads, stores and barriers are unconditional
+        // (clamped indices; copies past the last round are redundant) -- only the MFMA block is guarded.
+        for (int e = 0; e < NR; e += 3) {
+            const int buf = e & 1;  // 3 steps per trip: the parity of the trip's first buffer alternates
+            CW_GLOAD(min(e + 3, last), A)
+            CW_COMPUTE(buf, e)
+            CW_LSTORE(buf ^ 1, B)
+            lds_barrier();
+            CW_GLOAD(min(e + 4, last), B)
+            CW_COMPUTE(buf ^ 1, e + 1)
+            CW_LSTORE(buf, C)
+            lds_barrier();
+            CW_GLOAD(min(e + 5, last), C)
+            CW_COMPUTE(buf, e + 2)
+            CW_LSTORE(buf ^ 1, A)
+            lds_barrier();
+        }
+    }
+#undef CW_L1
+#undef CW_S1
+#undef CW_COMPUTE
 #undef CW_GLOAD
 #undef CW_LSTORE
     // position slots > 0 park their tile in LDS (free now); slot 0 adds them in slot order and writes the slab
@@ -915,8 +956,10 @@ struct AdamArgs {
     const float* grad;
     const float* bcinv;  // [K][2]
     AdamConsts ad;
-    long P, begin, end;  // element range inside a head, multiples of 4
+    long P, begin, end;         // element range inside a head, multiples of 4
     long skip_begin, skip_end;  // sub-range already updated by a fused kernel (empty when begin==end)
+    int K, n_seg;               // n_seg > 0: the conv leaves' gradients are still per-chunk slabs (fused path):
+    SlabSeg seg[3];             // sum them here (fixed chunk order) instead of a separate reduce launch
 };
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int k = blockIdx.y;
@@ -926,6 +969,34 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const long o = (long)k * a.P + e;
     float4 g = *reinterpret_cast<const float4*>(a.grad + o);
+#pragma unroll
+    for (int si = 0; si < 3; ++si) {
+        if (si >= a.n_seg) break;
+        const SlabSeg& sg = a.seg[si];
+        long se = -1;  // element index inside the slab (weights, then bias); leaves are 4-aligned
+        if (e >= sg.w_off && e < sg.w_off + sg.wsize) se = e - sg.w_off;
+        else if (e >= sg.b_off && e < sg.b_off + sg.bsize) se = sg.wsize + (e - sg.b_off);
+        if (se >= 0) {
+            const float* sp = sg.slab + (long)k * sg.slab_stride + se;
+            const long pstride = (long)a.K * sg.slab_stride;
+            g = make_float4(0.f, 0.f, 0.f, 0.f);
+            int pc = 0;
+            for (; pc + 4 <= sg.npc; pc += 4) {  // 4 independent loads in flight, added in chunk order
+                const float4 x0 = *reinterpret_cast<const float4*>(sp + (pc + 0) * pstride);
+                const float4 x1 = *reinterpret_cast<const float4*>(sp + (pc + 1) * pstride);
+                const float4 x2 = *reinterpret_cast<const float4*>(sp + (pc + 2) * pstride);
+                const float4 x3 = *reinterpret_cast<const float4*>(sp + (pc + 3) * pstride);
+                g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
+                g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
+                g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
+                g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
+            }
+            for (; pc < sg.npc; ++pc) {
+                const float4 x = *reinterpret_cast<const float4*>(sp + pc * pstride);
+                g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+            }
+        }
+    }
     float4 th = *reinterpret_cast<float4*>(a.theta + o);
     float4 m = *reinterpret_cast<float4*>(a.mu + o);
     float4 v = *reinterpret_cast<float4*>(a.nu + o);

@@ -24,6 +24,24 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// XCD-aware work mapping (speed only, never correctness): consecutive blockIdx values are dealt round-robin
+// over the 8 XCDs, each with its own 4 MB L2.  This returns a logical work index such that every XCD walks a
+// CONTIGUOUS slice of [0, gridDim.x): neighbouring work items (the taps of one position chunk, adjacent output
+// positions of one net, the f tiles of one head) then re-read each other's operands from the same L2 instead of
+// every L2 fetching everything.  Bijective for any grid size (cdna_hip_programming.md, T1).
+__device__ __forceinline__ int xcd_contiguous_id() {
+    const int n = (int)gridDim.x, b = (int)blockIdx.x;
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// Workgroup barrier that orders LDS traffic only: wait for this wave's LDS operations, then s_barrier.
+// Unlike __syncthreads() it does NOT drain vmcnt, so global loads prefetched for later rounds stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 void idqn_set_error(const char* fmt, ...);
 
 #define IDQN_HIP_CHECK(expr)                                                                   \

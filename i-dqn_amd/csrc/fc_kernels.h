@@ -35,9 +35,11 @@ struct FcArgs {
     float* ws;            // [K][ (L+1) * B * dmax (online acts) + 2 * B * dmax (target ping-pong / deltas) + 2*B ]
     float* losses;        // [K]
     float* q_dbg;         // [2K][B][A]
-    const int32_t* count; // [K] optax step counter (pre-increment)
+    int32_t* count;       // [K] optax step counter (pre-increment)
     float* bcinv;         // [K][2] out: reciprocal Adam bias corrections of this step
     float adam_b1, adam_b2;
+    double* cum;          // [K] running f64 loss sum (idqn.py:72)
+    int finish_step;      // 1: also count += 1, cum += loss here (the Adam kernel reads bcinv, not count)
 };
 
 // out[b][o] = (relu?)(bias[o] + sum_i in[b][i] * W[i][o])
@@ -110,6 +112,10 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
         const double tt = (double)(a.count[k] + 1);
         a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.adam_b1, tt));
         a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.adam_b2, tt));
+        if (a.finish_step) {
+            a.count[k] += 1;
+            a.cum[k] = a.cum[k] + (double)(s / (float)a.Bdiv);
+        }
     }
     // ---- backward
     float* dprev = tB;

@@ -158,6 +158,7 @@ struct idqn_handle_s {
     long wt_stride[3] = {0, 0, 0};
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
+    SlabSeg segs[3];  // slab descriptors of the last backward (consumed by the fused Adam launch)
     int head_lds = 0;
     // fc
     FcNet fc;
@@ -273,7 +274,19 @@ int cnn_setup(idqn_handle_s* h) {
     for (int i = 0; i < 3; ++i) {
         const ConvL& cl = h->conv[i];
         int npos = cl.OH * cl.OW;
-        h->pos_per_chunk[i] = 16;
+        // Grid balance: the launch has K * taps * npc workgroups of equal work and a CU runs them at MFMA
+        // speed, so pick the chunk size (4..32 positions) whose workgroup count best fills whole multiples of
+        // the 256 CUs (360 workgroups = 1.4 per CU ran at 70 % balance).
+        {
+            const int taps = (i == 0) ? cl.K : cl.K * cl.K;
+            double best = 1e9;
+            for (int ppc = 4; ppc <= 32; ++ppc) {
+                const int npc = (npos + ppc - 1) / ppc;
+                const long wgs = (long)K * taps * npc;
+                const double waste = (double)((wgs + 255) / 256 * 256) / (double)wgs + 0.002 * npc;  // mild bias to fewer slabs
+                if (waste < best) { best = waste; h->pos_per_chunk[i] = ppc; }
+            }
+        }
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
         h->slab_off[i] = slab_total;
@@ -351,10 +364,12 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     return IDQN_OK;
 }
 
-int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, hipStream_t q) {
+int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, hipStream_t q) {
     AdamArgs a;
     a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
     a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
+    a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
+    for (int i = 0; i < 3; ++i) a.seg[i] = h->segs[i];
     hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
@@ -376,6 +391,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
     ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
+    ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
@@ -409,14 +425,23 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     float* dins[3] = {nullptr, h->da1, h->da2};
     const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
     // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
+    {
+        WtBuildArgs wb;
+        wb.wbase = s.wbase; wb.K = K;
+        long maxe = 0;
+        for (int i = 1; i <= 2; ++i) {
+            const ConvL& l = *cl[i];
+            WtLayer& w = wb.layer[i - 1];
+            w.wt = h->wt[i]; w.w_off = l.w_off; w.wt_stride = h->wt_stride[i];
+            w.KH = l.K; w.KW = l.K; w.CI = l.CI; w.CO = l.CO; w.S = l.S; w.PLh = l.PLh; w.PLw = l.PLw;
+            w.n_var = l.S * l.S; w.KHs = l.K / l.S; w.KWs = l.K / l.S;
+            maxe = std::max(maxe, (long)l.K * l.K * l.CI * l.CO);
+        }
+        hipLaunchKernelGGL(k_wt_build, dim3(cdiv(maxe, 256), K, 2), dim3(256), 0, q, wb);
+    }
     for (int i = 2; i >= 1; --i) {
         const ConvL& l = *cl[i];
         const int KHs = l.K / l.S, nvar = l.S * l.S;
-        WtBuildArgs wb;
-        wb.wbase = s.wbase; wb.wt = h->wt[i]; wb.w_off = l.w_off; wb.wt_stride = h->wt_stride[i];
-        wb.K = K; wb.KH = l.K; wb.KW = l.K; wb.CI = l.CI; wb.CO = l.CO; wb.S = l.S; wb.PLh = l.PLh; wb.PLw = l.PLw;
-        wb.n_var = nvar; wb.KHs = KHs; wb.KWs = KHs;
-        hipLaunchKernelGGL(k_wt_build, dim3(cdiv((long)l.K * l.K * l.CI * l.CO, 256), K), dim3(256), 0, q, wb);
         ConvFwdArgs a;
         memset(&a, 0, sizeof(a));
         a.in = douts[i]; a.out = dins[i]; a.wbase = s.wbase; a.wt_base = h->wt[i]; a.wt_stride = h->wt_stride[i];
@@ -474,7 +499,9 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         g.first_block = nblk;
         nblk += cdiv(g.wsize + g.bsize, 256);
     }
-    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)nblk, K), dim3(256), 0, q, r);
+    for (int i = 0; i < 3; ++i) h->segs[i] = r.seg[i];
+    if (!fuse_adam)  // two-phase step: the gradient arena must be complete (it gets all-reduced); the fused
+        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)nblk, K), dim3(256), 0, q, r);  // path sums in k_adam
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -562,7 +589,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         if (!grads_only) {
             // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
             const long w0_b = h->off_w0, w0_e = h->off_b0;
-            if ((rc = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, q))) return rc;
+            if ((rc = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, q))) return rc;
         }
     } else {
         FcArgs a;
@@ -571,6 +598,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         a.terminal = terminal_dev; a.gamma_n = h->gamma_n; a.B = batch; a.Bdiv = batch_mean_divisor; a.K = h->cfg.n_heads;
         a.ws = h->fc_ws; a.losses = h->losses; a.q_dbg = h->qdbg;
         a.count = h->count; a.bcinv = h->bcinv; a.adam_b1 = h->ad.b1; a.adam_b2 = h->ad.b2;
+        a.cum = h->cum; a.finish_step = grads_only ? 0 : 1;
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
         hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
@@ -578,15 +606,14 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             h->ev_used += 2;
         }
         IDQN_HIP_CHECK(hipGetLastError());
-        if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, q))) return rc;
+        if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
     }
-    if (!grads_only) return step_epilogue(h, true, q);
-    return IDQN_OK;
+    return IDQN_OK;  // count += 1 and cum_losses += losses already happened in k_td_dh / k_fc_step (fused path)
 }
 
 extern "C" int idqn_apply_adam(idqn_handle_t h, void* stream) {
     IDQN_REQUIRE(h, "idqn_apply_adam: null handle");
-    int rc = launch_adam(h, 0, h->L.head_stride, 0, 0, (hipStream_t)stream);
+    int rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, (hipStream_t)stream);
     if (rc) return rc;
     return step_epilogue(h, true, (hipStream_t)stream);
 }
