@@ -296,16 +296,16 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
         acc[2] = mfma32(wv[s][u].z, xv[s][u], acc[2]);              \
         acc[3] = mfma32(wv[s][u].w, xv[s][u], acc[3]);              \
     }
-    D0F_LOAD(0, 0)  // NC is even and >= 2 (host-checked)
+    D0F_LOAD(0, 0)
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < NC; c += 2) {
-        D0F_LOAD(c + 1, 1)
+    for (int c = 0; c < NC; c += 2) {  // NC >= 1 (splits are whole multiples of 2U rows); an odd tail is guarded
+        D0F_LOAD(min(c + 1, NC - 1), 1)
         __builtin_amdgcn_sched_barrier(0);
         D0F_MMA(0)
         __builtin_amdgcn_sched_barrier(0);
         D0F_LOAD(min(c + 2, NC - 1), 0)
         __builtin_amdgcn_sched_barrier(0);
-        D0F_MMA(1)
+        if (c + 1 < NC) D0F_MMA(1)
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef D0F_LOAD

@@ -236,6 +236,7 @@ int cnn_setup(idqn_handle_s* h) {
     {
         const int units = h->F / 32;
         int best_ns = 1, best_waste = 1 << 30;
+        // ~16-24 splits (measured: 49 splits = 1960 waves ran slower, 46 vs 40 us, and slowed k_hidden)
         for (int ns = 12; ns <= 24; ++ns) {
             int per = (units + ns - 1) / ns, real_ns = (units + per - 1) / per;
             int waste = real_ns * per - units;

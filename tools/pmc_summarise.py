@@ -12,8 +12,12 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_*/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
+import os
+for d in glob.glob("gpurun_out/pmc_*/"):
+    files = sorted(glob.glob(d + "*/*counter_collection.csv"), key=os.path.getmtime)
+    if not files:
+        continue
+    for r in csv.DictReader(open(files[-1])):  # newest pass only (older merges may linger in gpurun_out/)
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in agg.items():
@@ -32,7 +36,7 @@ for k, c in agg.items():
         e["lds_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
     out[k] = e
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
-dom = [k for k in out if "k_dense0_wgrad<true>" in k]
+dom = [k for k in out if "k_dense0_wgrad<true" in k]
 if dom:
     json.dump({"kernel": dom[0], "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
                "read": out[dom[0]]["hbm_read_bytes"], "write": out[dom[0]]["hbm_write_bytes"],
