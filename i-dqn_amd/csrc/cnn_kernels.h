@@ -3,21 +3,19 @@
 // Data layout in HBM (one choice drives every kernel): activations are BATCH-MINOR,
 //     act[net][batch_block][row = (h, w, c)][32 samples]            (f32)
 // i.e. a "row" is one (pixel, channel) for a block of 32 samples = 128 B.  With the batch on the
-// 32-wide side of v_mfma_f32_32x32x2_f32, both operands of every contraction are plain 128-byte
-// rows (weights [k][out] row-major, activations [k][32]), so MFMA fragments load straight from
-// L2/HBM fully coalesced, results store as whole rows, and nothing needs an LDS transpose:
+// 32-wide side of v_mfma_f32_32x32x2_f32, the operands of the forward / data-gradient contractions are
+// plain 128-byte rows (weights [k][out] row-major, activations [k][32]) and results store as whole rows:
 //   forward      D[i = out channel][j = sample] += W[k][i] * act[k][j]          (rows of W, rows of act)
-//   weight grad  D[i = in  row   ][j = out row] += act[i][b] * dout[j][b]       (k = sample, in registers)
-//   data grad    D[i = in channel][j = sample] += W[i][k] * dout[k][j]          (k = out channel)
-// Where the reduced index is the contiguous one (weight grad: the sample; data grad: the out
-// channel of W[.][k]) each lane loads 16 consecutive floats of ITS row with 4 dwordx4 and feeds
-// register t to MFMA step t; the matching operand uses the same k-permutation (k = 16*half + t).
+//   data grad    the same kernel on the zero-bordered dout buffer with flipped / transposed weights
+//   weight grad  D[i = in  row   ][j = out row] += act[i][b] * dout[j][b]       (k = sample: each lane needs
+//                16 floats of ITS OWN row -> rows go through an LDS image padded to 36 floats per row)
 // Spatial SAME padding (flax default, architectures/dqn.py:43-51) is materialised as zero borders of
 // the activation buffers, so no kernel has a bounds branch in its k-loop.
 //
-// Every kernel: 256-thread workgroups = 4 independent waves, one work item per wave, no LDS and no
-// barrier in the MFMA kernels (k_head / k_prep use LDS).  f32 MFMA is 64 FLOP/clk/SIMD: one
-// dword of each operand per 64-cycle instruction, so L2 operand traffic is far below its limit.
+// 256-thread workgroups (4 waves).  Conv forward / data gradient: LDS-DMA staged k-chunks shared by the 4
+// waves.  Dense_0: weight-streaming kernels (forward: registers, double-buffered; data gradient: dh staged in
+// LDS; weight gradient + Adam: MFMA tile parked in LDS, then whole-row streaming of theta / m / v).
+// f32 MFMA is 64 FLOP/clk/SIMD: one dword of each operand per 64-cycle instruction.
 #pragma once
 #include "common.h"
 
