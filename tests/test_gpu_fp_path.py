@@ -287,3 +287,75 @@ def test_entry_points_train_end_to_end(env_name, tmp_path):
     assert int(agent._count[0].item()) >= 40
     model = pickle.load(open(os.path.join(p["save_path"], "models", "1"), "rb"))
     assert set(model) == {"params"} and all(np.isfinite(v).all() for m in model["params"].values() for v in m.values())
+
+
+@pytest.mark.parametrize("arch,obs,feats,A,K,B", [
+    ("cnn", (20, 20, 4), [32, 32, 32, 128], 5, 2, 20),     # ragged: one partly filled 32-sample block
+    ("cnn", (20, 20, 4), [32, 64, 32, 256], 3, 3, 50),     # ragged second block, mixed channel widths, J = 256
+    ("cnn", (36, 28, 4), [64, 32, 64, 128], 18, 1, 33),    # non-square frames, 18 actions, one sample in block 2
+    ("fc", 8, [100, 100], 4, 3, 7),
+    ("fc", (6, 1), [50], 2, 9, 64),
+])
+def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B):
+    """Edge cases of the batch / shape handling: live oracle comparison of losses, gradients and one Adam step."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn import _hip
+    from slimdqn.networks.idqn import iDQN
+
+    p = Q.init_params(3, arch, obs, A, feats, K)
+    pt = Q.init_params(4, arch, obs, A, feats, K)
+    rng = np.random.default_rng(5)
+    for n in p:
+        if n.endswith("bias"):
+            p[n] = (0.05 * rng.standard_normal(p[n].shape)).astype(np.float32)
+    batch = list(Q.synthetic_batch(6, B, obs, A, arch))
+    batch[4][B // 2] = True
+    agent = iDQN(0, obs, A, K, feats, arch, 1e-3, 0.97, 3, 1, 10**9, 10**9, adam_eps=1e-6)
+    agent._load_flat(agent._online, p)
+    agent._load_flat(agent._target, pt)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    losses = agent._learn(Batch(*batch), flags=_hip.F_GRADS_ONLY).cpu().numpy()
+    G = agent._flat(agent._grad)
+    gamma_n = 0.97 ** 3
+    for k in range(K):
+        loss, grads, _ = Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), tuple(batch), arch, gamma_n)
+        assert abs(losses[k] - loss) <= LOSS_ATOL, (k, losses[k], loss)
+        for leaf, g in grads.items():
+            assert _relerr(G[leaf][k], g) < 2e-5, (k, leaf, _relerr(G[leaf][k], g))
+    agent._apply_adam()
+    zeros = {n: np.zeros(v.shape, np.float64) for n, v in p.items()}
+    want, _, _, _, _ = Q.learn_on_batch({n: v.astype(np.float64) for n, v in p.items()}, pt, zeros, zeros,
+                                        np.zeros(K, np.int64), tuple(batch), arch, gamma_n, 1e-3, 1e-6)
+    got = agent._flat(agent._online)
+    for leaf in want:
+        # first Adam step moves every element by ~lr * g / (|g| + eps): elements with |g| ~ eps amplify the fp32
+        # gradient error, so compare at 2 % of one update
+        assert np.abs(got[leaf] - want[leaf]).max() <= 2e-5, leaf
+
+
+def test_dqn_cnn_and_many_heads():
+    """K = 1 without the head axis on the cnn, and K = 12 (more nets than the Atari config) in one launch set."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.dqn import DQN
+    from slimdqn.networks.idqn import iDQN
+
+    arch, obs, feats, A, B = "cnn", (20, 20, 4), [32, 32, 32, 128], 4, 32
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    batch = Q.synthetic_batch(1, B, obs, A, arch)
+    for K, cls in ((1, DQN), (12, iDQN)):
+        p = Q.init_params(7, arch, obs, A, feats, K)
+        pt = Q.init_params(8, arch, obs, A, feats, K)
+        if K == 1:
+            agent = cls(0, obs, A, feats, arch, 1e-4, 0.99, 1, 1, 200, adam_eps=1e-8)
+            assert agent.params["params"]["Conv_0"]["kernel"].shape == (8, 8, 4, 32)
+        else:
+            agent = cls(0, obs, A, K, feats, arch, 1e-4, 0.99, 1, 1, 200, 10, adam_eps=1e-8)
+        agent._load_flat(agent._online, p)
+        agent._load_flat(agent._target, pt)
+        losses = agent._learn(Batch(*batch)).cpu().numpy()
+        want = [Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), batch, arch, 0.99)[0] for k in range(K)]
+        assert np.abs(losses - np.asarray(want)).max() <= LOSS_ATOL
