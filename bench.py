@@ -9,9 +9,12 @@ A "step" is one pass of the hot path (iDQN.learn_on_batch, reference slimdqn/net
 that is already resident in HBM (K=5, B=32, uint8 84x84x4, A=6, features [32,64,64,512]).
 
 N = 1: the fused path (Dense_0 weight gradient + Adam in one kernel).
-N > 1: data-parallel, weak scaling: every rank takes its own 32-sample shard of a global batch of 32*N,
-       gradients are summed with ONE RCCL all-reduce of the [K][P] fp32 arena, then Adam runs on every
-       rank.  `value` counts 32-sample gradient steps: N per global step (units all ranks processed / time).
+N > 1: data-parallel, weak scaling: every rank takes its own 32-sample shard of a global batch of 32*N.
+       Default ("factored", slimdqn/networks/parallel.py): the Dense_0 gradient factors a3 / dh (5.3 MB per rank)
+       are all-gathered over RCCL while the conv backward runs, the 1.6 MB of small-leaf gradients are
+       all-reduced, and every rank runs the fused Dense_0 weight-gradient + Adam kernel over the gathered global
+       batch.  IDQN_DP_MODE=allreduce all-reduces the 80.9 MB gradient arena instead.
+       `value` counts 32-sample gradient steps: N per global step (units all ranks processed / time).
 
 roofline: the dominant kernel (k_dense0_wgrad, HBM-bound) timed with hipEvents on its own stream inside
 the timed region; cpu_baseline: the oracle's torch-CPU fp32 restatement of the same step, timed on this
@@ -100,6 +103,11 @@ def main():
                     help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
     args = ap.parse_args()
 
+    # Everything except the final JSON line goes to stderr -- including what native libraries print on fd 1
+    # (RCCL writes a version banner to stdout at communicator creation).
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -164,16 +172,19 @@ def main():
     assert np.isfinite(losses).all(), losses
     if rank == 0:
         P_w0 = 7744 * 512
-        fused = not dp
+        dp_mode = os.environ.get("IDQN_DP_MODE", "factored") if dp else "single"
+        fused = dp_mode != "allreduce"
         # algorithmic HBM bytes of one launch of the dominant kernel:
         # fused: theta, m, v of Dense_0/kernel read + written; unfused: gradient written; + a3 and dh read once
-        per_head = (6 if fused else 1) * P_w0 * 4 + 7744 * 32 * 4 + 512 * 32 * 4
+        # (factored data-parallel: the factors of all `world` ranks)
+        n_blocks = world if dp_mode == "factored" else 1
+        per_head = (6 if fused else 1) * P_w0 * 4 + n_blocks * (7744 * 32 * 4 + 512 * 32 * 4)
         alg_bytes = K_HEADS * per_head
         achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
         traffic = None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), fused kernel only
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            if fused:
+            if not dp:
                 traffic = pmc["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -192,7 +203,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Atari synthetic 84x84x4 uint8, i-DQN K=5 Nature-CNN [32,64,64,512] A=6, "
                                    f"batch 32 per GPU (global {global_batch}), "
-                                   + ("fused wgrad+Adam" if fused else "grad all-reduce (RCCL) then Adam"),
+                                   + {"single": "fused wgrad+Adam",
+                                      "factored": "Dense_0 factors all-gathered (RCCL), fused wgrad+Adam over the "
+                                                  "global batch, small leaves all-reduced",
+                                      "allreduce": "grad all-reduce (RCCL) then Adam"}[dp_mode],
                        "heads": K_HEADS, "batch_per_gpu": BATCH, "global_batch": global_batch,
                        "parallelism": f"dp{world}" if dp else "single"},
             "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
@@ -204,7 +218,7 @@ def main():
         if not dp and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()
 

@@ -389,6 +389,7 @@ struct TdArgs {
     const float* qpart;
     const float* const* wbase;
     long b0_off, w1_off, b1_off, P;
+    long gP, g_b0_off, g_w1_off, g_b1_off;  // gradient arena: per-head stride and leaf offsets (see GradLayout)
     int K, nb, J, A, B, Bdiv;
     const int32_t* action;
     const float* reward;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
     const float* po = a.wbase[k];
     const float* pt = a.wbase[a.K + k];
     const float* w1 = po + a.w1_off;
-    float* G = a.grad + (long)k * a.P;
+    float* G = a.grad + (long)k * a.gP;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f, loss_acc = 0.f;
     for (int bb = 0; bb < a.nb; ++bb) {
         const long so = (long)k * a.nb + bb, st = (long)(a.K + k) * a.nb + bb;
@@ -497,14 +498,14 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (b == 0) G[a.b0_off + jc * 32 + jj + 8 * i] = gb0[i];
+        if (b == 0) G[a.g_b0_off + jc * 32 + jj + 8 * i] = gb0[i];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int o = t + 256 * m;
-        if (o < 32 * a.A) G[a.w1_off + (long)jc * 32 * a.A + o] = gw[m];
+        if (o < 32 * a.A) G[a.g_w1_off + (long)jc * 32 * a.A + o] = gw[m];
     }
     if (jc == 0) {
-        if (t < a.A) G[a.b1_off + t] = gb1;
+        if (t < a.A) G[a.g_b1_off + t] = gb1;
         if (t == 0) {
             a.losses[k] = loss_acc / (float)a.Bdiv;
             const double tt = (double)(a.count[k] + 1);
@@ -669,7 +670,10 @@ struct DenseWgradArgs {
     const float* bcinv;  // [K][2]
     AdamConsts ad;
     long w_off, P, n_items;
-    int K, nb, n_ft, n_jt, F, J;
+    long g_w0_base, g_w0_stride;  // unfused output: grad + g_w0_base + k * g_w0_stride (contiguous over heads)
+    // sample block bb of head k: base + (bb / nb_inner) * outer + k * head + (bb % nb_inner) * inner   (floats)
+    long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
+    int K, nb, nb_inner, n_ft, n_jt, F, J;
 };
 
 // Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
@@ -705,12 +709,13 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     for (int bb = 0; bb < a.nb; ++bb) {
-        const float* Ap = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
+        const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
+        const float* Ap = a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner + (long)(f0 + bl) * 32 + 16 * h;
         float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
         float4 x2 = *reinterpret_cast<const float4*>(Ap + 8), x3 = *reinterpret_cast<const float4*>(Ap + 12);
         const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
                               x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-        const float* Dp = a.dh + ((long)k * a.nb + bb) * a.J * 32 + (long)(j0 + jw + bl) * 32 + 16 * h;
+        const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + bl) * 32 + 16 * h;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const float* dq = Dp + (long)q * 32 * 32;  // columns jw + 32 q + bl
@@ -750,9 +755,10 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
             *reinterpret_cast<float4*>(a.nu + o) = v4;
         }
     } else {
+        const long g0 = a.g_w0_base + (long)k * a.g_w0_stride + (long)(f0 + prow) * a.J + j0 + pcol;
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
-            *reinterpret_cast<float4*>(a.grad + o0 + (long)(RPI * i) * a.J) =
+            *reinterpret_cast<float4*>(a.grad + g0 + (long)(RPI * i) * a.J) =
                 *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
 }
@@ -921,7 +927,7 @@ struct SlabSeg {
 struct SlabReduceArgs {
     SlabSeg seg[3];
     float* grad;
-    long P;
+    long gP;  // per-head stride of the gradient arena's small-leaf region (conv leaves sit before Dense_0/kernel)
     int K, n_seg;
 };
 __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs a) {
@@ -943,7 +949,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs a) {
     }
     for (; pc < g.npc; ++pc) s += sp[pc * pstride];
     const long o = e < g.wsize ? g.w_off + e : g.b_off + (e - g.wsize);
-    a.grad[(long)k * a.P + o] = s;
+    a.grad[(long)k * a.gP + o] = s;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -956,6 +962,7 @@ struct AdamArgs {
     AdamConsts ad;
     long P, begin, end;         // element range inside a head, multiples of 4
     long skip_begin, skip_end;  // sub-range already updated by a fused kernel (empty when begin==end)
+    long gP, w0_begin, w0_end, g_w0_base;  // gradient arena layout (GradLayout in qnet.hip)
     int K, n_seg;               // n_seg > 0: the conv leaves' gradients are still per-chunk slabs (fused path):
     SlabSeg seg[3];             // sum them here (fixed chunk order) instead of a separate reduce launch
 };
@@ -966,7 +973,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     if (e >= a.skip_begin && e < a.skip_end) return;
     const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const long o = (long)k * a.P + e;
-    float4 g = *reinterpret_cast<const float4*>(a.grad + o);
+    const long w0n = a.w0_end - a.w0_begin;
+    const long go = e < a.w0_begin ? (long)k * a.gP + e
+                    : (e < a.w0_end ? a.g_w0_base + (long)k * w0n + (e - a.w0_begin) : (long)k * a.gP + e - w0n);
+    float4 g = *reinterpret_cast<const float4*>(a.grad + go);
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
         if (si >= a.n_seg) break;

@@ -167,6 +167,13 @@ struct idqn_handle_s {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     const char* dominant = "";
+    // Gradient arena layout: [K][gP] small leaves (every leaf but the cnn's Dense_0/kernel, same order, per-head
+    // stride gP = P - w0n), 64 floats reserved for the caller (losses), then [K][w0n] Dense_0/kernel gradients.
+    // Two contiguous regions = two collectives in the data-parallel step.  fc: w0n = 0, gP = P.
+    long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
+    bool pend_profile = false;
+    int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
+    int pend_B = 0;  // batch of a backward stopped after Dense_0 (idqn_backward_rest resumes it); 0 = none
     std::vector<void*> owned;
     std::vector<std::pair<std::string, std::pair<void*, long>>> dbg;
 };
@@ -370,42 +377,29 @@ int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e
     a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
     a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
     a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
+    a.gP = h->gP; a.w0_begin = h->g_w0_begin; a.w0_end = h->g_w0_end; a.g_w0_base = h->g_w0_base;
     for (int i = 0; i < 3; ++i) a.seg[i] = h->segs[i];
     hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
 
-int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, const uint8_t* terminal, int B,
-                 int Bdiv, bool fuse_adam, bool profile, hipStream_t q) {
-    const int K = h->cfg.n_heads, nb = cdiv(B, 32);
-    NetSet& s = h->train;
-    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
-    // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
-    HiddenArgs hi;
-    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = h->NS;
-    hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
-    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
-    TdArgs ta;
-    ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
-    ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K; ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
-    ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
-    ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
-    ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
-    ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
-    hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
-    // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
-    DenseDgradArgs dd;
-    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
-    dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
-    dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
-    hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
-    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
+
+// Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
+int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
+                        long a3_head, long a3_inner, long dh_outer, long dh_head, long dh_inner, bool fuse_adam,
+                        bool profile, hipStream_t q) {
+    const int K = h->cfg.n_heads;
     DenseWgradArgs dw;
-    dw.a3 = s.a3; dw.dh = h->dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
-    dw.bcinv = h->bcinv; dw.ad = h->ad; dw.w_off = h->off_w0; dw.P = h->L.head_stride;
+    dw.a3 = a3; dw.dh = dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
+    dw.bcinv = h->bcinv; dw.ad = h->ad; dw.g_w0_base = h->g_w0_base; dw.g_w0_stride = h->g_w0_end - h->g_w0_begin;
+    dw.w_off = h->off_w0; dw.P = h->L.head_stride;
+    dw.a3_outer = a3_outer; dw.a3_head = a3_head; dw.a3_inner = a3_inner;
+    dw.dh_outer = dh_outer; dw.dh_head = dh_head; dw.dh_inner = dh_inner;
     const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
-    dw.K = K; dw.nb = nb; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq); dw.F = h->F; dw.J = h->J;
+    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
+    dw.F = h->F; dw.J = h->J;
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
     if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
     const dim3 wgrid((unsigned)dw.n_items);
@@ -417,6 +411,60 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
         h->ev_used += 2;
     }
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, const uint8_t* terminal, int B,
+                 int Bdiv, bool fuse_adam, bool profile, bool stop_after_dense0, bool stop_before_dense0_wgrad,
+                 hipStream_t q) {
+    const int K = h->cfg.n_heads, nb = cdiv(B, 32);
+    NetSet& s = h->train;
+    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
+    // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
+    HiddenArgs hi;
+    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = h->NS;
+    hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
+    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
+    TdArgs ta;
+    ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
+    ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K;
+    {
+        const long w0n = h->g_w0_end - h->g_w0_begin;
+        ta.gP = h->gP; ta.g_b0_off = h->off_b0 - w0n; ta.g_w1_off = h->off_w1 - w0n; ta.g_b1_off = h->off_b1 - w0n;
+    } ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
+    ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
+    ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
+    ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
+    ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
+    hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
+    // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
+    DenseDgradArgs dd;
+    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+    dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
+    dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
+    hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+    if (stop_before_dense0_wgrad) {
+        h->pend_B = B; h->pend_stage = 1; h->pend_profile = profile;
+        IDQN_HIP_CHECK(hipGetLastError());
+        return IDQN_OK;
+    }
+    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
+    int rcw = launch_dense0_wgrad(h, s.a3, h->dh, nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
+                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q);
+    if (rcw) return rcw;
+    if (stop_after_dense0) {
+        h->pend_B = B; h->pend_stage = 2;
+        IDQN_HIP_CHECK(hipGetLastError());
+        return IDQN_OK;
+    }
+    return cnn_backward_rest(h, B, fuse_adam, q);
+}
+
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
+    const int K = h->cfg.n_heads, nb = cdiv(B, 32);
+    NetSet& s = h->train;
+    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
     // conv data gradients
     const ConvL* cl[3] = {c0, c1, c2};
     const float* douts[3] = {h->da1, h->da2, h->da3};
@@ -476,7 +524,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     }
     // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
     SlabReduceArgs r;
-    r.grad = h->grad; r.P = h->L.head_stride; r.K = K; r.n_seg = 3;
+    r.grad = h->grad; r.gP = h->gP; r.K = K; r.n_seg = 3;
     long nblk = 0;
     for (int i = 2; i >= 0; --i) {
         ConvWgradArgs a;
@@ -553,6 +601,12 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
     h->ad.eps = (float)cfg->adam_eps;
     h->gamma_n = (float)cfg->gamma_n;
     h->nb_max = cdiv(cfg->max_batch, 32);
+    h->gP = h->L.head_stride;
+    if (cfg->arch == IDQN_ARCH_CNN) {
+        h->g_w0_begin = h->L.leaves[6].offset; h->g_w0_end = h->L.leaves[7].offset;  // Dense_0/kernel .. Dense_0/bias
+        h->gP = h->L.head_stride - (h->g_w0_end - h->g_w0_begin);
+    }
+    h->g_w0_base = (long)cfg->n_heads * h->gP + 64;
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
     if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
     if (rc) { idqn_destroy(h); return rc; }
@@ -581,11 +635,14 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
     IDQN_REQUIRE(batch >= 1 && batch <= h->cfg.max_batch, "idqn_learn_on_batch: batch %d not in [1, %d]", batch, h->cfg.max_batch);
     IDQN_REQUIRE(batch_mean_divisor >= batch, "idqn_learn_on_batch: mean divisor %d < batch %d", batch_mean_divisor, batch);
     hipStream_t q = (hipStream_t)stream;
-    const bool grads_only = flags & IDQN_F_GRADS_ONLY, profile = flags & IDQN_F_PROFILE;
+    const bool stop0 = flags & IDQN_F_STOP_AFTER_DENSE0, stopb = flags & IDQN_F_STOP_BEFORE_DENSE0_WGRAD;
+    const bool grads_only = (flags & IDQN_F_GRADS_ONLY) || stop0 || stopb, profile = flags & IDQN_F_PROFILE;
+    IDQN_REQUIRE(!(stop0 || stopb) || h->cfg.arch == IDQN_ARCH_CNN, "the IDQN_F_STOP_* flags belong to the cnn path");
+    h->pend_B = 0; h->pend_stage = 0;
     int rc;
     if (h->cfg.arch == IDQN_ARCH_CNN) {
         if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q))) return rc;
-        if ((rc = cnn_backward(h, action_dev, reward_dev, terminal_dev, batch, batch_mean_divisor, !grads_only, profile, q)))
+        if ((rc = cnn_backward(h, action_dev, reward_dev, terminal_dev, batch, batch_mean_divisor, !grads_only, profile, stop0, stopb, q)))
             return rc;
         if (!grads_only) {
             // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
@@ -610,6 +667,39 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
     }
     return IDQN_OK;  // count += 1 and cum_losses += losses already happened in k_td_dh / k_fc_step (fused path)
+}
+
+extern "C" int idqn_backward_rest(idqn_handle_t h, void* stream) {
+    IDQN_REQUIRE(h && h->pend_B > 0, "idqn_backward_rest: no backward pass is waiting (IDQN_F_STOP_* first)");
+    const int B = h->pend_B;
+    if (h->pend_stage == 2) h->pend_B = 0;  // stage 1 keeps B for idqn_export / idqn_finish_step_factored
+    return cnn_backward_rest(h, B, false, (hipStream_t)stream);
+}
+
+extern "C" int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, float* dh_out_dev, void* stream) {
+    IDQN_REQUIRE(h && a3_out_dev && dh_out_dev, "idqn_export_dense0_factors: null pointer");
+    IDQN_REQUIRE(h->pend_stage == 1 && h->pend_B > 0, "idqn_export_dense0_factors: needs IDQN_F_STOP_BEFORE_DENSE0_WGRAD first");
+    const long nb = cdiv(h->pend_B, 32), K = h->cfg.n_heads;
+    // the online nets are the first K * nb slots of the activation buffer
+    IDQN_HIP_CHECK(hipMemcpyAsync(a3_out_dev, h->train.a3, (size_t)K * nb * h->F * 32 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    IDQN_HIP_CHECK(hipMemcpyAsync(dh_out_dev, h->dh, (size_t)K * nb * h->J * 32 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return IDQN_OK;
+}
+
+extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const float* dh_all_dev,
+                                         int32_t nb_total, int32_t nb_inner, int64_t a3_outer, int64_t a3_head,
+                                         int64_t a3_inner, int64_t dh_outer, int64_t dh_head, int64_t dh_inner,
+                                         void* stream) {
+    IDQN_REQUIRE(h && a3_all_dev && dh_all_dev, "idqn_finish_step_factored: null pointer");
+    IDQN_REQUIRE(h->pend_stage == 1, "idqn_finish_step_factored: needs IDQN_F_STOP_BEFORE_DENSE0_WGRAD first");
+    IDQN_REQUIRE(nb_total >= 1 && nb_inner >= 1 && nb_total % nb_inner == 0, "idqn_finish_step_factored: bad block counts");
+    hipStream_t q = (hipStream_t)stream;
+    h->pend_stage = 0; h->pend_B = 0;
+    int rc = launch_dense0_wgrad(h, a3_all_dev, dh_all_dev, nb_total, nb_inner, a3_outer, a3_head, a3_inner, dh_outer,
+                                 dh_head, dh_inner, true, h->pend_profile, q);
+    if (rc) return rc;
+    if ((rc = launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q))) return rc;  // every other leaf, from grad_dev
+    return step_epilogue(h, true, q);
 }
 
 extern "C" int idqn_apply_adam(idqn_handle_t h, void* stream) {

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libidqn_hip.so")
 
 IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
 IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24
-F_GRADS_ONLY, F_PROFILE = 1, 2
+F_GRADS_ONLY, F_PROFILE, F_STOP_AFTER_DENSE0, F_STOP_BEFORE_DENSE0_WGRAD = 1, 2, 4, 8
 E_INVALID, E_HIP, E_RANGE, E_ASSERT = -1, -2, -3, -4
 
 
@@ -44,6 +44,9 @@ SYMBOLS = {
     "idqn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "idqn_destroy": (C.c_int, [_P]),
     "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "idqn_backward_rest": (C.c_int, [_P, _P]),
+    "idqn_export_dense0_factors": (C.c_int, [_P, _P, _P, _P]),
+    "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [_P]),
     "idqn_apply_adam": (C.c_int, [_P, _P]),
     "idqn_target_update": (C.c_int, [_P, _P]),
     "idqn_target_sync": (C.c_int, [_P, _P]),

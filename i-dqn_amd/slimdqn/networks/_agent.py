@@ -45,9 +45,20 @@ class DeviceAgent:
         self._target = torch.zeros((K, P), dtype=torch.float32, device=dev)
         self._mu = torch.zeros((K, P), dtype=torch.float32, device=dev)
         self._nu = torch.zeros((K, P), dtype=torch.float32, device=dev)
-        self._grad = torch.zeros((K, P), dtype=torch.float32, device=dev)
+        # gradient arena (include/idqn_hip.h): [K][gP] small leaves | 64 reserved floats (the K losses live there, so
+        # that one collective covers them) | [K][w0n] Dense_0/kernel gradients of the cnn
+        names = [n for n, _, _ in self._leaves]
+        self._w0 = (0, 0)
+        if architecture_type == "cnn":
+            i = names.index("Dense_0/kernel")
+            self._w0 = (self._leaves[i][1], self._leaves[i + 1][1])
+        self._gP = P - (self._w0[1] - self._w0[0])
+        self._grad = torch.zeros(K * P + 64, dtype=torch.float32, device=dev)
+        self._grad_small = self._grad[: K * self._gP + 64]
+        self._grad_w0 = self._grad[K * self._gP + 64 :]
+        self._losses = self._grad[K * self._gP : K * self._gP + K]
+        self._losses_in_grad = True
         self._count = torch.zeros(K, dtype=torch.int32, device=dev)
-        self._losses = torch.zeros(K, dtype=torch.float32, device=dev)
         self._cum = torch.zeros(K, dtype=torch.float64, device=dev)
         self._handle, self._handle_batch = None, 0
         self._q_out = torch.zeros((32, n_actions), dtype=torch.float32, device=dev)
@@ -171,6 +182,22 @@ class DeviceAgent:
         host = arena.cpu().numpy()
         return {name: host[:, off : off + int(np.prod(shape))].reshape((self._K,) + tuple(shape)).copy()
                 for name, off, shape in self._leaves}
+
+    def _flat_grad(self):
+        """{"Conv_0/kernel": array [K, ...]} read from the two-region gradient arena (tests)."""
+        host = self._grad.cpu().numpy()
+        K, gP, (w0b, w0e) = self._K, self._gP, self._w0
+        out = {}
+        for name, off, shape in self._leaves:
+            n = int(np.prod(shape))
+            if w0e > w0b and off == w0b:
+                base = K * gP + 64
+                v = np.stack([host[base + k * (w0e - w0b) : base + k * (w0e - w0b) + n] for k in range(K)])
+            else:
+                o = off if off < w0b or w0e == w0b else off - (w0e - w0b)
+                v = np.stack([host[k * gP + o : k * gP + o + n] for k in range(K)])
+            out[name] = v.reshape((K,) + tuple(shape)).copy()
+        return out
 
     def get_model(self):
         """Picklable ``{"params": pytree of numpy arrays}`` (idqn.py:133-134, experiments/base/utils.py:134)."""

@@ -2,22 +2,89 @@
 
 The reference is single-device; the loss is a plain mean over the minibatch (``slimdqn/networks/idqn.py:111-112``),
 so the gradient of a global batch of ``B * world`` samples is the SUM of the shard gradients when every shard
-divides by the global batch size.  One all-reduce of the ``[K][head_stride]`` f32 gradient arena (80.9 MB at K=5)
-plus the K per-head losses, then the identical Adam update on every rank keeps the replicas bit-identical.
-``torch.distributed`` is plumbing here: backend "nccl" is RCCL on ROCm; the CPU tests drive the same function
-over "gloo".
+divides by the global batch size.  The gradients are all-reduced, then the identical Adam update runs on every
+rank, which keeps the replicas bit-identical.  ``torch.distributed`` is plumbing here: backend "nccl" is RCCL on
+ROCm; the CPU tests drive the same function over "gloo".
+
+Overlap (GPU, cnn path): 98 % of the 80.9 MB of gradients is Dense_0/kernel, and the backward pass produces it
+FIRST.  The step is therefore issued as two C calls: ``idqn_learn_on_batch(..., IDQN_F_STOP_AFTER_DENSE0)`` queues
+everything up to the Dense_0 weight gradient, the K contiguous Dense_0 slices are all-reduced asynchronously (RCCL
+runs them on its own stream, ordered behind that point of the compute stream), and ``idqn_backward_rest`` queues
+the conv backward, which then runs concurrently with the collective.  The gradient arena is laid out as two
+contiguous regions for exactly this: ``[all heads' small leaves + the K losses][all heads' Dense_0 slices]`` -- two
+collectives per step, no packing.  xGMI is point-to-point (7 links per GPU), so a few large collectives beat many
+small ones.  ``IDQN_DP_OVERLAP=0`` falls back to one all-reduce of the whole arena after the backward pass.
+
+Factored mode (GPU, cnn path, the default): the Dense_0/kernel gradient is the outer product ``a3^T . dh`` over the
+samples, i.e. of rank <= global batch, far below its 7744 x 512 shape.  Ranks therefore ALL-GATHER the two factors
+(``a3``: K x 7744 x 32 floats, ``dh``: K x 512 x 32 floats -- 5.3 MB per rank at K=5) instead of all-reducing the
+79.3 MB product, and every rank runs the fused weight-gradient + Adam kernel over the gathered global batch: 4x
+(8 ranks) to 15x (2 ranks) fewer bytes over xGMI, the gradient is never materialised, and Adam stays fused.  The
+gathers run while ``idqn_backward_rest`` computes the conv backward; the 1.6 MB of small leaves (and the K losses)
+are all-reduced as before.  Every rank sums the same blocks in the same order, so replicas stay bit-identical.
+``IDQN_DP_MODE=allreduce`` selects the all-reduce variants above.
 """
+import os
+
 import torch.distributed as dist
 
 from slimdqn import _hip
 
 
-def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags: int = 0):
+def _factored_step(agent, shard, global_batch, group, extra_flags):
+    import torch
+
+    lib, q = _hip.lib(), _hip.current_stream
+    world = dist.get_world_size(group)
+    K = agent._K
+    F, J = next(shape for name, _, shape in agent._leaves if name == "Dense_0/kernel")
+    nb = -(-len(shard.action) // 32)  # 32-sample blocks of this rank's shard
+    X, Y = F * 32, J * 32
+    n_a3, n_dh = K * nb * X, K * nb * Y
+    key = (world, nb)
+    if getattr(agent, "_factor_key", None) != key:  # exchange buffers, allocated once per (world, shard blocks)
+        dev = agent._grad.device
+        agent._fact_send = torch.empty(n_a3 + n_dh, dtype=torch.float32, device=dev)  # [a3 | dh] of this rank
+        agent._fact_all = torch.empty(world * (n_a3 + n_dh), dtype=torch.float32, device=dev)  # [rank][a3 | dh]
+        agent._factor_key = key
+    send, gathered = agent._fact_send, agent._fact_all
+    agent._learn(shard, flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD | extra_flags, mean_divisor=global_batch)
+    _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()),
+               "idqn_export_dense0_factors")
+    work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)  # ONE collective for both factors
+    _hip.check(lib.idqn_backward_rest(agent._handle, q()), "idqn_backward_rest")  # conv backward, under the gather
+    dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group)  # small leaves + the K losses
+    work.wait()
+    _hip.check(lib.idqn_finish_step_factored(agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]),
+                                             world * nb, nb, n_a3 + n_dh, nb * X, X, n_a3 + n_dh, nb * Y, Y, q()),
+               "idqn_finish_step_factored")
+    return agent._losses
+
+
+def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags: int = 0, overlap=None, mode=None):
     """One global gradient step; ``shard`` is this rank's ReplayElement-like slice of the global batch."""
-    agent._learn(shard, flags=_hip.F_GRADS_ONLY | extra_flags, mean_divisor=global_batch)  # gradients + loss share
-    dist.all_reduce(agent._grad, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(agent._losses, op=dist.ReduceOp.SUM, group=group)
-    agent._apply_adam()  # Adam from the summed gradient, count += 1, cumulated_losses += losses
+    on_gpu_cnn = agent._grad.is_cuda and getattr(agent, "_arch", "") == "cnn"
+    if mode is None:
+        mode = os.environ.get("IDQN_DP_MODE", "factored")
+    if mode == "factored" and on_gpu_cnn and overlap is None:
+        return _factored_step(agent, shard, global_batch, group, extra_flags)
+    if overlap is None:
+        overlap = (os.environ.get("IDQN_DP_OVERLAP", "1") != "0" and agent._grad.is_cuda
+                   and getattr(agent, "_arch", "") == "cnn")
+    if not overlap:
+        agent._learn(shard, flags=_hip.F_GRADS_ONLY | extra_flags, mean_divisor=global_batch)
+        dist.all_reduce(agent._grad, op=dist.ReduceOp.SUM, group=group)  # the whole arena in one collective
+        if not getattr(agent, "_losses_in_grad", False):  # the device agent keeps its losses inside the arena
+            dist.all_reduce(agent._losses, op=dist.ReduceOp.SUM, group=group)
+        agent._apply_adam()  # Adam from the summed gradient, count += 1, cumulated_losses += losses
+        return agent._losses
+    # forward, head, Dense_0 data + weight gradient are queued; the conv backward is not yet
+    agent._learn(shard, flags=_hip.F_STOP_AFTER_DENSE0 | extra_flags, mean_divisor=global_batch)
+    big = dist.all_reduce(agent._grad_w0, op=dist.ReduceOp.SUM, group=group, async_op=True)  # 79.3 MB, 98 %
+    _hip.check(_hip.lib().idqn_backward_rest(agent._handle, _hip.current_stream()), "idqn_backward_rest")
+    dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group)  # 1.6 MB of small leaves + the K losses
+    big.wait()  # the compute stream waits for the Dense_0 region
+    agent._apply_adam()
     return agent._losses
 
 

@@ -58,8 +58,12 @@ typedef struct idqn_leaf {
     int64_t shape[4];     /* per-head shape (HWIO for conv kernels, [in,out] for dense)          */
 } idqn_leaf_t;
 
-/* Arena layout: every parameter-like array (online, target, mu, nu, grad) is [K][head_stride]
- * floats; head k, leaf l lives at arena + k*head_stride + leaf[l].offset.                        */
+/* Arena layout: every parameter-like array (online, target, mu, nu) is [K][head_stride] floats; head k, leaf l
+ * lives at arena + k*head_stride + leaf[l].offset.
+ * The GRADIENT arena has K*head_stride + 64 floats arranged as two contiguous regions (two collectives in the
+ * data-parallel step): [K][gP] all leaves except the cnn's Dense_0/kernel (same order; gP = head_stride - its padded
+ * size), 64 floats reserved for the caller (the Python mirror keeps the K losses there), then [K][Dense_0/kernel].
+ * For the fc architecture the second region is empty and gP = head_stride.                                       */
 int idqn_layout(const idqn_config_t* cfg, int32_t* n_leaves, idqn_leaf_t* leaves /*[IDQN_MAX_LEAVES]*/,
                 int64_t* head_stride);
 
@@ -77,6 +81,8 @@ int idqn_destroy(idqn_handle_t h);
 /* flags for idqn_learn_on_batch */
 #define IDQN_F_GRADS_ONLY 1u   /* stop after the gradients are in grad_dev (data-parallel: all-reduce, then idqn_apply_adam) */
 #define IDQN_F_PROFILE 2u      /* bracket the dominant kernel with hipEvents (see idqn_profile_read) */
+#define IDQN_F_STOP_AFTER_DENSE0 4u  /* two-call backward, see idqn_backward_rest */
+#define IDQN_F_STOP_BEFORE_DENSE0_WGRAD 8u  /* factored data-parallel step, see idqn_finish_step_factored */
 
 /* iDQN.learn_on_batch (idqn.py:96-109) == DQN.learn_on_batch (dqn.py:60-73) for K == 1:
  * 2K forwards, TD target (idqn.py:120-124), squared loss mean over the batch (idqn.py:111-118),
@@ -88,6 +94,26 @@ int idqn_destroy(idqn_handle_t h);
 int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
                         const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
                         int32_t batch, int32_t batch_mean_divisor, uint32_t flags, void* stream);
+/* Data-parallel overlap: with IDQN_F_STOP_AFTER_DENSE0 (implies gradients only) idqn_learn_on_batch returns
+ * once the Dense_0 weight gradient -- 98 % of the gradient bytes, produced first in the backward pass -- is queued;
+ * the caller starts all-reducing that slice (RCCL, async) and calls idqn_backward_rest for the conv backward,
+ * which then runs concurrently with the collective.                                                               */
+int idqn_backward_rest(idqn_handle_t h, void* stream);
+/* Factored data-parallel step.  The Dense_0/kernel gradient (98 % of all gradient bytes) is the outer product
+ * a3^T . dh over the samples -- rank <= global batch -- so ranks exchange the FACTORS (K x F x 32 + K x J x 32 floats
+ * per 32-sample block, ~5.3 MB at K=5) instead of all-reducing the 79 MB product, and every rank runs the fused
+ * weight-gradient + Adam kernel over the global batch:
+ *   idqn_learn_on_batch(.., IDQN_F_STOP_BEFORE_DENSE0_WGRAD)   forward, head, Dense_0 data gradient
+ *   idqn_export_dense0_factors   async copies of this rank's a3 [K][nb][F*32] and dh [K][nb][J*32]
+ *   (all-gather both; meanwhile idqn_backward_rest = conv backward; all-reduce the small-leaf gradient region)
+ *   idqn_finish_step_factored    fused Dense_0 update from the gathered factors, Adam on every other leaf from
+ *                                grad_dev, count += 1, cum_losses += losses.
+ * Block bb of the gathered buffers lives at (bb / nb_inner) * outer + head * head_stride + (bb % nb_inner) * inner
+ * (strides in floats); a plain all_gather of the exported buffers gives outer = K*nb*X, head = nb*X, inner = X.   */
+int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, float* dh_out_dev, void* stream);
+int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const float* dh_all_dev, int32_t nb_total,
+                              int32_t nb_inner, int64_t a3_outer, int64_t a3_head, int64_t a3_inner,
+                              int64_t dh_outer, int64_t dh_head, int64_t dh_inner, void* stream);
 /* Second half of the data-parallel step: Adam from grad_dev, count += 1. */
 int idqn_apply_adam(idqn_handle_t h, void* stream);
 

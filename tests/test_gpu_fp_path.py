@@ -120,7 +120,7 @@ def test_cnn_every_stage_against_oracle(name):
         got = _unpack_act(agent._debug("da1"), K * nb, k * nb, g0["OH"], g0["OW"], g0["CO"], 0, 0, g0["OH"], g0["OW"])
         errs[f"h{k}_da1"] = _relerr(got[: min(B, 32)], aux["trace"]["d_conv0"][:32])
         # leaf gradients
-        G = agent._flat(agent._grad)
+        G = agent._flat_grad()
         for leaf in grads:
             errs[f"h{k}_grad_{leaf}"] = _relerr(G[leaf][k], grads[leaf])
     print("\nstage relative errors (max |got - want| / max |want|):")
@@ -164,7 +164,7 @@ def test_two_phase_path_gradients_and_adam(name):
     step = rec["steps"][0]
     losses = agent._learn(bs[0], flags=_hip.F_GRADS_ONLY).cpu().numpy()
     assert np.abs(losses - np.asarray(step["losses"])).max() <= LOSS_ATOL
-    G = agent._flat(agent._grad)
+    G = agent._flat_grad()
     for leaf, d in step["leaves"].items():
         flat = G[leaf].reshape(K, -1)
         scale = np.asarray(d["grad_absmax"])[:, None]
@@ -317,7 +317,7 @@ def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B):
     agent._load_flat(agent._target, pt)
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
     losses = agent._learn(Batch(*batch), flags=_hip.F_GRADS_ONLY).cpu().numpy()
-    G = agent._flat(agent._grad)
+    G = agent._flat_grad()
     gamma_n = 0.97 ** 3
     for k in range(K):
         loss, grads, _ = Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), tuple(batch), arch, gamma_n)
@@ -359,3 +359,88 @@ def test_dqn_cnn_and_many_heads():
         losses = agent._learn(Batch(*batch)).cpu().numpy()
         want = [Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), batch, arch, 0.99)[0] for k in range(K)]
         assert np.abs(losses - np.asarray(want)).max() <= LOSS_ATOL
+
+
+@pytest.fixture(scope="module")
+def rccl_single_rank():
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _dp_steps_match_golden(name, **kw):
+    from slimdqn.networks.parallel import data_parallel_step
+
+    agent, bs, rec, _ = _agent(name)
+    K = agent._K
+    for s, batch in enumerate(bs):
+        losses = data_parallel_step(agent, batch, len(batch.action), **kw).cpu().numpy()
+        assert np.abs(losses - np.asarray(rec["steps"][s]["losses"])).max() <= LOSS_ATOL, (kw, s)
+    flat = agent._flat(agent._online)
+    last = rec["steps"][len(bs) - 1]["leaves"]
+    for leaf, d in last.items():
+        err = np.abs(flat[leaf].reshape(K, -1)[:, d["idx"]] - np.asarray(d["param"]))
+        if len(bs) == 1:
+            assert err.max() <= 3e-7, (kw, leaf)
+        assert (err <= 3e-7).mean() >= 0.98 and err.max() <= 2 * rec["hyper"]["lr"] * len(bs), (kw, leaf)
+    assert agent._count.cpu().numpy().tolist() == [len(bs)] * K
+    cum = agent._cum.cpu().numpy()
+    want = np.sum([st["losses"] for st in rec["steps"][: len(bs)]], axis=0)
+    assert np.abs(cum - want).max() <= LOSS_ATOL * len(bs)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_allreduce_data_parallel_step_single_rank(rccl_single_rank, overlap):
+    """The all-reduce variants of the RCCL path end to end on one rank (world_size 1): two-call backward with the
+    async all-reduce of the Dense_0 region, all-reduce of the small-leaf region, two-phase Adam == the golden steps."""
+    _dp_steps_match_golden("cnn_atari_k5", mode="allreduce", overlap=overlap)
+
+
+@pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5", "cnn_atari_a18_b64"])
+def test_factored_data_parallel_step_single_rank(rccl_single_rank, name):
+    """The factored step (all-gather of the Dense_0 factors a3 / dh through RCCL, fused weight-gradient + Adam over
+    the gathered blocks, small leaves all-reduced) on one rank == the golden steps; b64 covers two blocks per rank."""
+    _dp_steps_match_golden(name, mode="factored")
+
+
+def test_factored_step_sums_blocks_of_several_ranks():
+    """What N ranks compute, on one GPU: split a 64-sample global batch into two 32-sample shards, run the first
+    half of the step on each (mean divisor 64), concatenate the exported factors the way all_gather lays them out
+    ([rank][head][block]) and finish from them -- the update must equal the single-device step on the 64 samples."""
+    import torch
+
+    from slimdqn import _hip
+
+    lib = _hip.lib()
+    agent, bs, rec, _ = _agent("cnn_atari_a18_b64")
+    batch = bs[0]
+    K = agent._K
+    F, J = next(shape for n, _, shape in agent._leaves if n == "Dense_0/kernel")
+    X, Y = F * 32, J * 32
+    a3_all = torch.empty(2 * K * X, dtype=torch.float32, device="cuda")
+    dh_all = torch.empty(2 * K * Y, dtype=torch.float32, device="cuda")
+    small = torch.zeros_like(agent._grad_small)
+    Shard = type(batch)
+    q = _hip.current_stream
+    for r in range(2):
+        shard = Shard(*[np.asarray(f)[32 * r : 32 * (r + 1)] for f in batch])
+        agent._learn(shard, flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD, mean_divisor=64)
+        _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(a3_all[r * K * X :]),
+                                                  _hip.ptr(dh_all[r * K * Y :]), q()), "export")
+        _hip.check(lib.idqn_backward_rest(agent._handle, q()), "rest")
+        small += agent._grad_small  # what the all-reduce of the small-leaf region does
+    agent._grad_small.copy_(small)
+    _hip.check(lib.idqn_finish_step_factored(agent._handle, _hip.ptr(a3_all), _hip.ptr(dh_all), 2, 1, K * X, X, X,
+                                             K * Y, Y, Y, q()), "finish")
+    st = rec["steps"][0]
+    assert np.abs(agent._losses.cpu().numpy() - np.asarray(st["losses"])).max() <= LOSS_ATOL
+    flat = agent._flat(agent._online)
+    for leaf, d in st["leaves"].items():
+        err = np.abs(flat[leaf].reshape(K, -1)[:, d["idx"]] - np.asarray(d["param"]))
+        assert err.max() <= 3e-7, (leaf, err.max())
+    assert agent._count.cpu().numpy().tolist() == [1] * K
