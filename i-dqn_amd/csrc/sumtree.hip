@@ -86,23 +86,24 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
         if (s < n) sdelta[s] = dl[q];
     }
     __syncthreads();
-    // 4. one pass per level: the head of each run of equal node indices accumulates its run in order
-    for (int level = 0; level < depth; ++level) {
-        for (int s = tid; s < n; s += ST_THREADS) {
-            unsigned int node = cur[s];
-            if (s == 0 || cur[s - 1] != node) {
-                double x = nodes[node];
-                int e = s;
-                do {
-                    x = x + sdelta[e];
-                    ++e;
-                } while (e < n && cur[e] == node);
-                nodes[node] = x;
-            }
+    // 4. every (level, run of equal ancestors) pair at once: a node belongs to exactly one level, so the levels are
+    //    independent and all their read-modify-writes are in flight together (one memory round trip instead of
+    //    `depth` dependent ones); the head of each run accumulates its run in ascending leaf order, which is the
+    //    order np.add.at applies the sorted deltas in (sum_tree.py:39-47).  cur[] holds the sorted leaf nodes; the
+    //    ancestor `level` levels up of 0-based heap node x is ((x + 1) >> level) - 1.
+    const int pairs = n * depth;
+    for (int pr = tid; pr < pairs; pr += ST_THREADS) {
+        const int s0 = pr / depth, level = pr - s0 * depth;  // the long runs near the root land on different lanes
+        const unsigned int node = ((cur[s0] + 1u) >> level) - 1u;
+        if (s0 == 0 || ((cur[s0 - 1] + 1u) >> level) - 1u != node) {
+            double x = nodes[node];
+            int e = s0;
+            do {
+                x = x + sdelta[e];
+                ++e;
+            } while (e < n && ((cur[e] + 1u) >> level) - 1u == node);
+            nodes[node] = x;
         }
-        __syncthreads();
-        for (int s = tid; s < n; s += ST_THREADS) cur[s] = (cur[s] - 1u) >> 1;  // parent; unused after the root
-        __syncthreads();
     }
 }
 
@@ -137,6 +138,51 @@ __global__ void k_sumtree_query(const double* __restrict__ nodes, int depth, con
     if (bad) atomicOr(status, bad);
 }
 
+// Latency-oriented variant for minibatch-sized queries: ONE WAVE PER QUERY.  The 2^(s+1)-1 nodes of the s <= 5
+// levels below the current node are fetched by the 64 lanes in one round trip, then the wave descends those levels
+// out of registers (shuffles): depth 21 costs 4 dependent memory round trips instead of 20.  Same comparisons and
+// the same `t -= left_sum` sequence as the scalar walk, so the result is bit-identical.
+__global__ __launch_bounds__(256) void k_sumtree_query_wave(const double* __restrict__ nodes, int depth,
+                                                            const double* __restrict__ targets, int n,
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;  // wave-uniform
+    const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
+    double t = targets[i];
+    int bad = 0;
+    if (!(t >= 0.0 && t < nodes[0])) bad |= 1;
+    unsigned int node = 0;
+    int level = 0;
+    const int h = lane + 1;                 // 1-based heap number inside the sub-tree; lane 63 idles
+    const int j = 31 - __clz(h);            // its level inside the sub-tree
+    const unsigned int p = h - (1u << j);  // its position in that level
+    while (level < depth - 1) {
+        const int s = min(5, depth - 1 - level);
+        double v = 0.0;
+        if (j <= s && lane < 63) v = nodes[(size_t)(node + 1u) * (1u << j) + p - 1u];
+        int cur = 1;
+        for (int step = 0; step < s; ++step) {
+            const double here = __shfl(v, cur - 1);
+            const double ls = __shfl(v, 2 * cur - 1);
+            if (!(t < here)) bad |= 2;
+            if (t < ls) {
+                cur = 2 * cur;
+            } else {
+                t = t - ls;
+                cur = 2 * cur + 1;
+            }
+        }
+        const int jj = 31 - __clz(cur);
+        node = (node + 1u) * (1u << jj) + (cur - (1u << jj)) - 1u;
+        level += s;
+    }
+    if (lane == 0) {
+        out[i] = (int32_t)(node - first_leaf);
+        if (bad) atomicOr(status, bad);
+    }
+}
+
 extern "C" int sumtree_set(double* nodes_dev, int32_t depth, const int32_t* indices_dev, const double* values_dev,
                            int32_t n, void* scratch_dev, void* stream) {
     IDQN_REQUIRE(nodes_dev && indices_dev && values_dev && scratch_dev, "sumtree_set: null pointer");
@@ -163,8 +209,12 @@ extern "C" int sumtree_query(const double* nodes_dev, int32_t depth, const doubl
                              int32_t* out_dev, int32_t* status_dev, void* stream) {
     IDQN_REQUIRE(nodes_dev && targets_dev && out_dev && status_dev && n >= 1, "sumtree_query: bad arguments");
     IDQN_REQUIRE(depth >= 1 && depth <= 31, "sumtree_query: depth %d out of range", depth);
-    hipLaunchKernelGGL(k_sumtree_query, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, nodes_dev, depth,
-                       targets_dev, n, out_dev, status_dev);
+    if (n <= 2048)  // minibatch-sized: latency matters, one wave per query
+        hipLaunchKernelGGL(k_sumtree_query_wave, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, nodes_dev, depth,
+                           targets_dev, n, out_dev, status_dev);
+    else
+        hipLaunchKernelGGL(k_sumtree_query, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, nodes_dev, depth,
+                           targets_dev, n, out_dev, status_dev);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }

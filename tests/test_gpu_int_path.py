@@ -86,3 +86,30 @@ def test_replay_with_prioritized_sampler_matches_oracle():
         a.update(keys, priorities=pr)
         b.update(keys, priorities=pr)
     np.testing.assert_array_equal(a._sampling_distribution._sum_tree._nodes, b.sampler.tree.nodes)
+
+
+@pytest.mark.parametrize("capacity", [1, 2, 5, 33, 1000, 1 << 16, (1 << 20) - 3])
+def test_sumtree_query_paths_agree_with_the_oracle(capacity):
+    """Minibatch-sized queries take the one-wave-per-query descent (up to 5 levels per memory round trip), larger
+    ones the thread-per-query walk: both must give the oracle's leaves bit for bit, for every depth 1..21, and for
+    targets on exact prefix-sum boundaries (where `t < left` flips)."""
+    from oracle.sumtree_ref import SumTreeRef
+
+    rng = np.random.default_rng(capacity)
+    a, b = _classes()[0](capacity), SumTreeRef(capacity)
+    for lo in range(0, capacity, 4096):
+        idx = np.arange(lo, min(lo + 4096, capacity), dtype=np.int32)
+        val = rng.integers(0, 4, idx.size).astype(np.float64) * 0.25  # exact sums, many zero-priority leaves
+        if lo == 0:
+            val[0] = 0.5
+        a.set(idx, val)
+        b.set(idx, val)
+    np.testing.assert_array_equal(a._nodes, b.nodes)
+    root = b.root
+    for n in (1, 32, 2048, 5000):
+        t = rng.uniform(0, root, n)
+        t[: n // 2] = np.floor(t[: n // 2] * 4) / 4  # multiples of 0.25: exactly on leaf boundaries
+        t = np.minimum(t, np.nextafter(root, 0))
+        np.testing.assert_array_equal(np.asarray(a.query(t)), b.query(t))
+    with pytest.raises(ValueError):
+        a.query(np.asarray([root]))
