@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--heads-per-gpu", type=int, default=0,
+                    help="head-parallel mode (BASELINE config 5, not the headline metric): K = this x gpus heads, every "
+                         "rank steps its own window of heads on the same minibatch, no per-step collective; a T-step "
+                         "and a D-step (neighbour exchange) are timed separately")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
     args = ap.parse_args()
@@ -120,7 +124,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or args.force_dp:
+    if args.gpus > 1 or args.force_dp or args.heads_per_gpu:
         os.environ.setdefault("MASTER_PORT", "29533")
         assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -129,8 +133,10 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    agent = iDQN(0, OBS, N_ACTIONS, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    if args.heads_per_gpu:
+        return head_parallel_bench(args, rank, world, json_fd, Batch)
+    agent = iDQN(0, OBS, N_ACTIONS, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
     batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i))) for i in range(8)]
     it = [0]
@@ -221,6 +227,49 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()
+
+
+def head_parallel_bench(args, rank, world, json_fd, Batch):
+    """BASELINE config 5: K = heads_per_gpu x world heads, the same minibatch on every rank, no per-step collective."""
+    import torch
+    import torch.distributed as dist
+
+    from slimdqn.networks.head_parallel import HeadShardedIDQN
+
+    K = args.heads_per_gpu * world
+    agent = HeadShardedIDQN(0, OBS, N_ACTIONS, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i))) for i in range(8)]  # same on all ranks
+
+    def timed(fn, n):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
+    for i in range(args.warmup):
+        agent._learn(batches[i % 8])
+    step_s = timed(lambda i: agent._learn(batches[i % 8]), args.steps)
+    agent._target_update()
+    agent._target_sync()
+    t_s = timed(lambda i: agent._target_update(), 20)
+    d_s = timed(lambda i: agent._target_sync(), 20)
+    assert np.isfinite(agent._losses.cpu().numpy()).all()
+    if rank == 0:
+        out = {"metric": "i-DQN head-gradient-steps/sec, Nature-CNN batch=32, head-parallel (BASELINE config 5)",
+               "value": K / step_s, "unit": "head-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"i-DQN K={K} ({args.heads_per_gpu} heads per GPU), batch 32 replicated, "
+                                      "no per-step collective", "heads": K, "parallelism": f"hp{world}"},
+               "target_update_ms": t_s * 1e3, "target_sync_ms": d_s * 1e3}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def _obs_triplet(observation_dim, arch):
 
 class DeviceAgent:
     def __init__(self, key, observation_dim, n_actions, n_heads, features, architecture_type, learning_rate, gamma,
-                 update_horizon, adam_eps, stacked):
+                 update_horizon, adam_eps, stacked, init_heads=None):
         self.network = DQNNet(features, architecture_type, n_actions)
         self._K = int(n_heads)
         self._stacked = stacked  # iDQN leaves carry a leading K axis, DQN leaves do not
@@ -64,9 +64,13 @@ class DeviceAgent:
         self._q_out = torch.zeros((32, n_actions), dtype=torch.float32, device=dev)
         # initial parameters (idqn.py:48-50 / dqn.py:29); target starts equal to online (idqn.py:56)
         rng = prng.generator(key)
+        # init_heads = (K_global, first): this agent holds heads [first, first + K) of a K_global-head i-DQN and must
+        # start from exactly the parameters the single-device agent gives those heads (head-parallel mode)
+        k_all, first = init_heads if init_heads is not None else (K, 0)
         host = np.zeros((K, P), np.float32)
         for name, off, shape in self._leaves:
-            host[:, off : off + int(np.prod(shape))] = self.network.init_leaf(rng, name, shape, K).reshape(K, -1)
+            leaf = self.network.init_leaf(rng, name, shape, k_all).reshape(k_all, -1)
+            host[:, off : off + int(np.prod(shape))] = leaf[first : first + K]
         self._online.copy_(torch.from_numpy(host))
         self._target.copy_(self._online)
         self.params = self._tree(self._online)
@@ -136,6 +140,16 @@ class DeviceAgent:
                                                   _hip.ptr(t), B, int(mean_divisor or B), int(flags),
                                                   _hip.current_stream()), "idqn_learn_on_batch")
         return self._losses
+
+    def _local_target_update(self):
+        """target <- online (real copy), then online[k] <- online[k+1] over THIS agent's heads (idqn.py:78-80)."""
+        self._ensure_handle(32)
+        _hip.check(_hip.lib().idqn_target_update(self._handle, _hip.current_stream()), "idqn_target_update")
+
+    def _local_target_sync(self):
+        """target[k] <- online[k-1], k >= 1, over THIS agent's heads (idqn.py:20-24)."""
+        self._ensure_handle(32)
+        _hip.check(_hip.lib().idqn_target_sync(self._handle, _hip.current_stream()), "idqn_target_sync")
 
     def _apply_adam(self):
         _hip.check(_hip.lib().idqn_apply_adam(self._handle, _hip.current_stream()), "idqn_apply_adam")

@@ -17,10 +17,12 @@ from slimdqn.networks._agent import DeviceAgent
 class iDQN(DeviceAgent):
     def __init__(self, key, observation_dim, n_actions, n_networks: int, features: list, architecture_type: str,
                  learning_rate: float, gamma: float, update_horizon: int, update_to_data: int,
-                 target_update_frequency: int, target_sync_frequency: int, adam_eps: float = 1e-8):
+                 target_update_frequency: int, target_sync_frequency: int, adam_eps: float = 1e-8, _local_heads=None):
         self.n_networks = n_networks
-        super().__init__(key, observation_dim, n_actions, n_networks, features, architecture_type, learning_rate,
-                         gamma, update_horizon, adam_eps, stacked=True)
+        # _local_heads = (first, count): hold only that window of the n_networks heads (head-parallel mode)
+        first, count = _local_heads if _local_heads is not None else (0, n_networks)
+        super().__init__(key, observation_dim, n_actions, count, features, architecture_type, learning_rate,
+                         gamma, update_horizon, adam_eps, stacked=True, init_heads=(n_networks, first))
         self.update_to_data = update_to_data
         self.target_update_frequency = target_update_frequency
         self.target_sync_frequency = target_sync_frequency
@@ -50,9 +52,8 @@ class iDQN(DeviceAgent):
     def update_target_params(self, step: int):
         if step % self.target_update_frequency == 0:
             # target <- online (real copy), then window shift: idqn.py:78-80
-            self._ensure_handle(32)
-            _hip.check(_hip.lib().idqn_target_update(self._handle, _hip.current_stream()), "idqn_target_update")
-            cum = self.cumulated_losses
+            self._target_update()
+            cum = self._all_cumulated_losses()
             denom = self.target_update_frequency / self.update_to_data
             logs = {"loss": np.mean(cum) / denom}
             for idx_network in range(self.n_networks):
@@ -60,9 +61,18 @@ class iDQN(DeviceAgent):
             self._cum.zero_()
             return True, logs
         if step % self.target_sync_frequency == 0:  # skipped on T-steps by the early return (idqn.py:89-92)
-            self._ensure_handle(32)
-            _hip.check(_hip.lib().idqn_target_sync(self._handle, _hip.current_stream()), "idqn_target_sync")
+            self._target_sync()
         return False, {}
+
+    # the three hooks the head-parallel agent (slimdqn/networks/head_parallel.py) overrides
+    def _target_update(self) -> None:
+        self._local_target_update()
+
+    def _target_sync(self) -> None:
+        self._local_target_sync()
+
+    def _all_cumulated_losses(self) -> np.ndarray:
+        return self.cumulated_losses
 
     def q_values(self, params, state, idx_params: int):
         """``network.apply(params[idx_params], state)`` (idqn.py:131): device tensor [n, A]."""

@@ -444,3 +444,70 @@ def test_factored_step_sums_blocks_of_several_ranks():
         err = np.abs(flat[leaf].reshape(K, -1)[:, d["idx"]] - np.asarray(d["param"]))
         assert err.max() <= 3e-7, (leaf, err.max())
     assert agent._count.cpu().numpy().tolist() == [1] * K
+
+
+def test_head_window_agent_equals_rows_of_the_full_agent():
+    """Head-parallel mode: an agent holding heads [first, first + count) of a K-head i-DQN
+    starts from the same parameters as those rows of the single-device agent and, fed the same minibatches, follows
+    them to fp32 accumulation accuracy (the heads are independent inside a step; the split-K chunking of the kernels
+    depends on the number of local heads, so sums are re-associated, not bit-identical)."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.idqn import iDQN
+
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    obs, A, feats, K = (20, 20, 4), 5, [32, 32, 32, 128], 6
+    args = (obs, A, K, feats, "cnn", 1e-3, 0.99, 1, 1, 10**9, 10**9)
+    full = iDQN(3, *args)
+    windows = [iDQN(3, *args, _local_heads=(first, 2)) for first in (0, 2, 4)]
+    for step in range(3):
+        batch = Batch(*Q.synthetic_batch(40 + step, 32, obs, A, "cnn"))
+        want = full._learn(batch).cpu().numpy().copy()
+        for w, first in zip(windows, (0, 2, 4)):
+            got = w._learn(batch).cpu().numpy()
+            np.testing.assert_allclose(got, want[first : first + 2], rtol=2e-6)
+        if step == 0:
+            for w, first in zip(windows, (0, 2, 4)):
+                np.testing.assert_array_equal(w._target.cpu().numpy(), full._target[first : first + 2].cpu().numpy())
+    for w, first in zip(windows, (0, 2, 4)):
+        assert w.n_networks == K and w._K == 2
+        err = np.abs(w._online.cpu().numpy() - full._online[first : first + 2].cpu().numpy())
+        assert (err <= 1e-6).mean() >= 0.999 and err.max() <= 2 * 1e-3 * 3, (first, err.max())
+
+
+def test_head_sharded_agent_on_one_rank_is_the_plain_agent(rccl_single_rank):
+    """HeadShardedIDQN over RCCL with world_size 1: same steps, T-step logs, shift and sync as iDQN."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.head_parallel import HeadShardedIDQN
+    from slimdqn.networks.idqn import iDQN
+    from slimdqn import prng
+
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    obs, A, feats, K = (20, 20, 4), 5, [32, 32, 32, 128], 4
+    args = (obs, A, K, feats, "cnn", 1e-3, 0.99, 1, 1, 4, 2)  # T = 4, D = 2
+
+    class OneBatch:
+        def __init__(self):
+            self.i = 0
+
+        def sample(self):
+            self.i += 1
+            return Batch(*Q.synthetic_batch(70 + self.i, 32, obs, A, "cnn"))
+
+    a, b, ra, rb = iDQN(9, *args), HeadShardedIDQN(9, *args), OneBatch(), OneBatch()
+    for step in range(1, 10):
+        a.update_online_params(step, ra)
+        b.update_online_params(step, rb)
+        la, lb = a.update_target_params(step), b.update_target_params(step)
+        assert la[0] == lb[0] and la[1].keys() == lb[1].keys()
+        for k in la[1]:
+            assert la[1][k] == lb[1][k], (step, k)
+    np.testing.assert_array_equal(a._online.cpu().numpy(), b._online.cpu().numpy())
+    np.testing.assert_array_equal(a._target.cpu().numpy(), b._target.cpu().numpy())
+    state = Q.synthetic_batch(1, 1, obs, A, "cnn")[0][0]
+    key = prng.PRNGKey(4)
+    assert int(a.best_action(a.params, state, key)) == int(b.best_action(b.params, state, key))
+    assert b.get_model()["heads"] == (0, K, K)
