@@ -56,6 +56,8 @@ SYMBOLS = {
     "sumtree_set": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "sumtree_get": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P]),
     "sumtree_query": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    "replay_gather_stacked": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P,
+                                       _P, _P]),
     "replay_gather": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P]),
     "replay_gather_scalars": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
 }

@@ -1,18 +1,21 @@
-"""Replay buffer whose elements live uncompressed in HBM.
+"""Replay buffer whose frames live in HBM, written once each.
 
 Drop-in for the reference's ``slimdqn/sample_collection/replay_buffer.py`` (same constructor and
 ``add`` / ``sample`` / ``update``, ``add_count``, ``_memory``, ``_sampling_distribution``,
-``_clipping``).  Differences are storage only:
+``_clipping``).  What differs is storage:
 
-* the reference keeps snappy-compressed elements in a host ``OrderedDict`` keyed by ``add_count``
-  and evicts FIFO (``:202-213``); here element ``key`` occupies slot ``key % max_capacity`` of a
-  device array ``[capacity][2][obs_bytes]`` (state, next_state) -- the same FIFO, no dictionary;
-  ``compress`` is accepted and ignored (56 KB/slot x 1 M slots = 56 GB fits 288 GB of HBM3E);
-* ``sample()`` (``:215-230``) gathers on the device (``csrc/replay.hip``) and returns a
-  ``ReplayElement`` of device arrays; ``np.asarray(field)`` copies back when a test wants to look.
+* the reference materialises every element's two frame stacks on the host, snappy-compresses them and keeps them in
+  an ``OrderedDict`` keyed by ``add_count`` with FIFO eviction (``:119-137,202-213``).  Here each environment frame
+  goes to HBM ONCE -- ring slot ``transition index % n_frames`` of ``[n_frames][frame_bytes]`` -- and an element is
+  a row of 8 int32 (which frames its stacks end at, how many are valid, action, reward, terminal) at slot
+  ``key % max_capacity``: the same FIFO, 1/8 of the bytes (7 KB instead of 56 KB per Atari element: a 1 M buffer is
+  7 GB of the 288 GB), and one 7 KB host-to-device copy per environment step.  ``compress`` is accepted and ignored;
+* ``sample()`` (``:215-230``) assembles the stacks on the device (``replay_gather_stacked`` in ``csrc/replay.hip``:
+  gather + zero padding before the episode start + ``np.stack`` in one launch) and returns a ``ReplayElement`` of
+  device arrays; ``np.asarray(field)`` copies back when a test wants to look.
 
-The n-step / frame-stack accumulator (``:103-200``) is host logic here as in the reference
-(``TrajectoryAccumulator``, pure Python, no GPU needed).
+The n-step / frame-stack window logic (``:103-200``) is host integer logic (``TrajectoryAccumulator``): it decides
+WHICH frames and rewards make an element; it never touches pixel data in the buffer's path.
 """
 import collections
 import typing
@@ -42,6 +45,17 @@ class ReplayElement(typing.NamedTuple):
     episode_end: Any
 
 
+class ElementPlan(typing.NamedTuple):
+    """An element as window positions: its stacks end at ``last_s`` / ``last_n`` (older positions fill the earlier
+    channels, positions < 0 are zero frames), ``reward`` is the discounted n-step sum."""
+
+    last_s: int
+    last_n: int
+    action: Any
+    reward: float
+    done: bool
+
+
 class DevArray:
     """A device tensor that numpy can look at (``np.asarray`` copies to the host)."""
 
@@ -62,50 +76,66 @@ class DevArray:
 
 
 class TrajectoryAccumulator:
-    """n-step + frame-stack window -> replay elements (reference ``:103-200``); host only."""
+    """n-step + frame-stack window -> replay elements (reference ``:103-200``); host only.
+
+    ``plan`` yields ``(ElementPlan, window size)`` -- positions, not pixels; ``push`` materialises the stacks from the
+    observations held in the window (used by host-side tests and anyone who wants the reference's element)."""
 
     def __init__(self, stack_size: int, update_horizon: int, gamma: float) -> None:
         self.stack_size, self.n, self.gamma = stack_size, update_horizon, gamma
         self.window = collections.deque(maxlen=update_horizon + stack_size)
 
-    def _emit(self):
+    def _plan(self):
         w = self.window
         size, tail = len(w), w[-1]
         if not (size > self.n or (size > 1 and tail.is_terminal)):
             return None
         # a terminal that arrives early shortens the horizon (":114-117")
         horizon = size - 1 if (tail.is_terminal and size <= self.n) else self.n
-        frame = np.asarray(tail.observation)
-        state = np.zeros(frame.shape + (self.stack_size,), frame.dtype)
-        nxt = np.zeros_like(state)
         last_s = size - horizon - 1  # window position of the newest frame of `state`
         last_n = size - 1
         reward = 0.0
         for t, tr in enumerate(w):
             if last_s <= t <= last_s + self.n - 1:
                 reward += tr.reward * (self.gamma ** (t - last_s))
-            ch = t - (last_s - self.stack_size + 1)
+        return ElementPlan(last_s, last_n, w[last_s].action, reward, w[last_n].is_terminal)
+
+    def _materialise(self, plan: ElementPlan) -> ReplayElement:
+        w = self.window
+        frame = np.asarray(w[-1].observation)
+        state = np.zeros(frame.shape + (self.stack_size,), frame.dtype)
+        nxt = np.zeros_like(state)
+        for t, tr in enumerate(w):
+            ch = t - (plan.last_s - self.stack_size + 1)
             if 0 <= ch < self.stack_size:
                 state[..., ch] = tr.observation
-            ch = t - (last_n - self.stack_size + 1)
+            ch = t - (plan.last_n - self.stack_size + 1)
             if 0 <= ch < self.stack_size:
                 nxt[..., ch] = tr.observation
-        done = w[last_n].is_terminal
-        return ReplayElement(state, w[last_s].action, reward, nxt, done, done)  # episode_end := is_terminal (":146")
+        # episode_end := is_terminal (":146")
+        return ReplayElement(state, plan.action, plan.reward, nxt, plan.done, plan.done)
 
-    def push(self, transition: TransitionElement):
+    def _steps(self, transition: TransitionElement, emit):
         self.window.append(transition)
         if transition.is_terminal:
-            while (el := self._emit()) is not None:
-                yield el
+            while (plan := self._plan()) is not None:
+                yield emit(plan)
                 self.window.popleft()
             self.window.clear()
             return
-        el = self._emit()
-        if el is not None:
-            yield el
+        plan = self._plan()
+        if plan is not None:
+            yield emit(plan)
         if transition.episode_end:
             self.window.clear()
+
+    def push(self, transition: TransitionElement):
+        """Yields the reference's ReplayElements (materialised stacks)."""
+        return self._steps(transition, self._materialise)
+
+    def plan(self, transition: TransitionElement):
+        """Yields ``(ElementPlan, window size when it was made)``; the window's newest entry is the pushed transition."""
+        return self._steps(transition, lambda p: (p, len(self.window)))
 
 
 class _MemoryView:
@@ -129,14 +159,14 @@ class _MemoryView:
             raise KeyError(key)
         rb = self._rb
         slot = key % rb._max_capacity
-        frames = rb._store[slot].cpu().numpy()
-        s = np.frombuffer(frames[0].tobytes(), dtype=rb._obs_dtype).reshape(rb._obs_shape)
-        n = np.frombuffer(frames[1].tobytes(), dtype=rb._obs_dtype).reshape(rb._obs_shape)
-        return ReplayElement(s, int(rb._action[slot]), float(rb._reward64[slot]), n,
-                             bool(rb._terminal[slot]), bool(rb._terminal[slot]))
+        el = rb._gather(np.asarray([slot], np.int32))
+        return ReplayElement(np.asarray(el.state)[0], int(rb._action[slot]), float(rb._reward64[slot]),
+                             np.asarray(el.next_state)[0], bool(rb._meta[slot, 6]), bool(rb._meta[slot, 6]))
 
 
 class ReplayBuffer:
+    STAGING = 32  # pinned host frames in flight towards the ring
+
     def __init__(self, sampling_distribution, batch_size: int, max_capacity: int, stack_size: int = 4,
                  update_horizon: int = 1, gamma: float = 0.99, checkpoint_duration: int = 4, compress: bool = True,
                  clipping: callable = None):
@@ -149,50 +179,121 @@ class ReplayBuffer:
         self._stack_size, self._update_horizon, self._gamma = stack_size, update_horizon, gamma
         self._clipping = clipping
         self._accumulator = TrajectoryAccumulator(stack_size, update_horizon, gamma)
-        self._store = None  # device [capacity][2][obs_bytes] uint8, allocated at the first add
+        self._frames = None  # device [n_frames][frame_bytes] uint8, allocated at the first add
         self._memory = _MemoryView(self)
         self._stage = {}
+        self._t = 0  # transitions pushed so far == index of the next frame
+        self._flushed = 0  # elements whose metadata row is already on the device
 
     # ---- storage -------------------------------------------------------------------------------
-    def _allocate(self, state: np.ndarray) -> None:
+    def _allocate(self, frame: np.ndarray) -> None:
         import torch
 
         from slimdqn import _hip
 
         _hip.lib()  # no extension -> no replay buffer (there is no host store to fall back to)
-        self._obs_shape, self._obs_dtype = state.shape, state.dtype
-        self._obs_bytes = int(state.nbytes)
+        self._frame_shape, self._obs_dtype = tuple(frame.shape), frame.dtype
+        self._frame_elems, self._itemsize = int(frame.size), int(frame.dtype.itemsize)
+        self._frame_bytes = self._frame_elems * self._itemsize
+        self._obs_shape = self._frame_shape + (self._stack_size,)
         cap = self._max_capacity
-        self._store = torch.empty((cap, 2, self._obs_bytes), dtype=torch.uint8, device="cuda")
-        self._action_dev = torch.zeros(cap, dtype=torch.int32, device="cuda")
-        self._reward_dev = torch.zeros(cap, dtype=torch.float32, device="cuda")
-        self._terminal_dev = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        # Every alive element's frames must still be in the ring.  An element is made per transition except for the
+        # few transitions before a truncated (non-terminal) episode end, so capacity + window + slack frames cover
+        # capacity elements; `_upload_frame` grows the ring in the rare case the slack runs out.
+        self._n_frames = cap + self._update_horizon + self._stack_size + max(64, cap // 16)
+        self._frames = torch.empty((self._n_frames, self._frame_bytes), dtype=torch.uint8, device="cuda")
+        self._meta = np.zeros((cap, 8), np.int32)  # host copy of the element rows (see replay_gather_stacked)
+        self._meta_dev = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
+        self._first_frame = np.zeros(cap, np.int64)  # oldest frame (transition index) an element refers to
         # host mirrors of the scalars (cheap; `_memory[key]` and logging read them)
-        self._action = np.zeros(cap, np.int32)
+        self._action = np.zeros(cap, np.int64)
         self._reward64 = np.zeros(cap, np.float64)
-        self._terminal = np.zeros(cap, np.uint8)
-        self._pin = torch.empty((2, self._obs_bytes), dtype=torch.uint8).pin_memory()
+        self._pin = torch.empty((self.STAGING, self._frame_bytes), dtype=torch.uint8).pin_memory()
+        self._pin_np = self._pin.numpy()
+        self._pin_events = [None] * self.STAGING
 
-    def _write(self, key: int, el: ReplayElement) -> None:
+    def _grow_ring(self, oldest_needed: int) -> None:
+        """Doubles the frame ring, keeping frames [oldest_needed, _t) (transition indices) in place modulo the new size."""
         import torch
 
-        if self._store is None:
-            self._allocate(el.state)
+        new_n = 2 * self._n_frames
+        new = torch.empty((new_n, self._frame_bytes), dtype=torch.uint8, device="cuda")
+        live = torch.arange(oldest_needed, self._t, dtype=torch.int64, device="cuda")
+        if live.numel():
+            new[live % new_n] = self._frames[live % self._n_frames]
+        # frame slots are stored in the element rows: re-derive them for the alive elements
+        for key in self._memory.keys():
+            slot = key % self._max_capacity
+            first_s = int(self._first_frame[slot])
+            newest_s = first_s + int(self._meta[slot, 1]) - 1
+            horizon = (int(self._meta[slot, 2]) - int(self._meta[slot, 0])) % self._n_frames
+            self._meta[slot, 0] = newest_s % new_n
+            self._meta[slot, 2] = (newest_s + horizon) % new_n
+        self._frames, self._n_frames = new, new_n
+        self._flushed = max(0, self.add_count - self._max_capacity)  # every alive row goes to the device again
+
+    def _upload_frame(self, observation) -> int:
+        """The newest frame goes to ring slot ``t % n_frames`` (async copy from a pinned staging slot); returns t."""
+        import torch
+
+        frame = np.ascontiguousarray(observation)
+        if self._frames is None:
+            self._allocate(frame)
+        assert frame.shape == self._frame_shape and frame.dtype == self._obs_dtype, "observation shape / dtype changed"
+        t = self._t
+        if self.add_count:
+            oldest_key = max(0, self.add_count - self._max_capacity)
+            oldest_needed = int(self._first_frame[oldest_key % self._max_capacity])
+            if t - oldest_needed >= self._n_frames:  # the slot still holds a frame an alive element needs
+                self._grow_ring(oldest_needed)
+        i = t % self.STAGING
+        if self._pin_events[i] is not None:
+            self._pin_events[i].synchronize()  # that staging slot's previous copy has long finished
+        self._pin_np[i] = frame.view(np.uint8).reshape(-1)
+        self._frames[t % self._n_frames].copy_(self._pin[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_events[i] = ev
+        self._t = t + 1
+        return t
+
+    def _write(self, key: int, plan: ElementPlan, window_size: int, t_now: int) -> None:
         slot = key % self._max_capacity
-        torch.cuda.current_stream().synchronize()  # the pinned staging buffer may still be in flight
-        self._pin[0].copy_(torch.from_numpy(np.ascontiguousarray(el.state).view(np.uint8).reshape(-1)))
-        self._pin[1].copy_(torch.from_numpy(np.ascontiguousarray(el.next_state).view(np.uint8).reshape(-1)))
-        self._store[slot].copy_(self._pin, non_blocking=True)
-        self._action[slot], self._reward64[slot], self._terminal[slot] = el.action, el.reward, el.is_terminal
-        self._action_dev[slot] = int(el.action)
-        self._reward_dev[slot] = float(el.reward)  # f64 -> f32, the downcast jit applies to batch.reward
-        self._terminal_dev[slot] = int(bool(el.is_terminal))
+        to_t = lambda pos: t_now - (window_size - 1 - pos)  # window position -> transition index
+        valid_s, valid_n = min(self._stack_size, plan.last_s + 1), min(self._stack_size, plan.last_n + 1)
+        row = self._meta[slot]
+        row[0], row[1] = to_t(plan.last_s) % self._n_frames, valid_s
+        row[2], row[3] = to_t(plan.last_n) % self._n_frames, valid_n
+        row[4] = int(plan.action)
+        row[5] = np.float32(plan.reward).view(np.int32)  # f64 -> f32, the downcast jit applies to batch.reward
+        row[6] = int(bool(plan.done))
+        self._first_frame[slot] = to_t(plan.last_s) - valid_s + 1
+        self._action[slot], self._reward64[slot] = plan.action, plan.reward
+
+    def _flush_meta(self) -> None:
+        """Element rows written since the last sample go to the device: FIFO slots are contiguous modulo capacity."""
+        import torch
+
+        lo, hi, cap = self._flushed, self.add_count, self._max_capacity
+        if hi - lo >= cap:
+            self._meta_dev.copy_(torch.from_numpy(self._meta))
+        elif hi > lo:
+            a, b = lo % cap, hi % cap
+            if a < b:
+                self._meta_dev[a:b].copy_(torch.from_numpy(self._meta[a:b]))
+            else:
+                self._meta_dev[a:].copy_(torch.from_numpy(self._meta[a:]))
+                if b:
+                    self._meta_dev[:b].copy_(torch.from_numpy(self._meta[:b]))
+        self._flushed = hi
 
     # ---- reference API -----------------------------------------------------------------------------
     def add(self, transition: TransitionElement, **kwargs: Any) -> None:
-        for el in self._accumulator.push(transition):
+        t_now = self._upload_frame(transition.observation)
+        light = transition._replace(observation=None)  # the window decides positions; pixels stay on the device
+        for plan, window_size in self._accumulator.plan(light):
             key = ReplayItemID(self.add_count)
-            self._write(key, el)
+            self._write(key, plan, window_size, t_now)
             self._sampling_distribution.add(key, **kwargs)
             self.add_count += 1
             if self.add_count > self._max_capacity:  # FIFO: the oldest key leaves (":211-213")
@@ -204,32 +305,28 @@ class ReplayBuffer:
         if size not in self._stage:
             self._stage[size] = dict(
                 slots=torch.empty(size, dtype=torch.int32, device="cuda"),
-                state=torch.empty((size, self._obs_bytes), dtype=torch.uint8, device="cuda"),
-                next_state=torch.empty((size, self._obs_bytes), dtype=torch.uint8, device="cuda"),
+                state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
+                next_state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
                 action=torch.empty(size, dtype=torch.int32, device="cuda"),
                 reward=torch.empty(size, dtype=torch.float32, device="cuda"),
                 terminal=torch.empty(size, dtype=torch.uint8, device="cuda"),
             )
         return self._stage[size]
 
-    def sample(self, size=None) -> ReplayElement:
+    def _gather(self, slots: np.ndarray) -> ReplayElement:
         import torch
 
         from slimdqn import _hip
 
-        assert self.add_count, ValueError("No samples in replay buffer!")
-        if size is None:
-            size = self._batch_size
-        keys = self._sampling_distribution.sample(size)
+        size = int(slots.size)
+        self._flush_meta()
         st = self._staging(size)
-        st["slots"].copy_(torch.from_numpy((np.asarray(keys, np.int64) % self._max_capacity).astype(np.int32)))
-        lib, q = _hip.lib(), _hip.current_stream()
-        _hip.check(lib.replay_gather(_hip.ptr(self._store), self._obs_bytes, _hip.ptr(st["slots"]), size,
-                                     _hip.ptr(st["state"]), _hip.ptr(st["next_state"]), q), "replay_gather")
-        _hip.check(lib.replay_gather_scalars(_hip.ptr(self._action_dev), _hip.ptr(self._reward_dev),
-                                             _hip.ptr(self._terminal_dev), _hip.ptr(st["slots"]), size,
-                                             _hip.ptr(st["action"]), _hip.ptr(st["reward"]), _hip.ptr(st["terminal"]), q),
-                   "replay_gather_scalars")
+        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots, np.int32)))
+        _hip.check(_hip.lib().replay_gather_stacked(
+            _hip.ptr(self._frames), self._n_frames, self._frame_elems, self._itemsize, self._stack_size,
+            _hip.ptr(self._meta_dev), _hip.ptr(st["slots"]), size, _hip.ptr(st["state"]), _hip.ptr(st["next_state"]),
+            _hip.ptr(st["action"]), _hip.ptr(st["reward"]), _hip.ptr(st["terminal"]), _hip.current_stream()),
+            "replay_gather_stacked")
         tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
                np.dtype(np.float64): torch.float64, np.dtype(np.int64): torch.int64,
                np.dtype(np.int32): torch.int32}[np.dtype(self._obs_dtype)]
@@ -242,6 +339,13 @@ class ReplayBuffer:
             is_terminal=DevArray(st["terminal"]),
             episode_end=DevArray(st["terminal"]),
         )
+
+    def sample(self, size=None) -> ReplayElement:
+        assert self.add_count, ValueError("No samples in replay buffer!")
+        if size is None:
+            size = self._batch_size
+        keys = self._sampling_distribution.sample(size)
+        return self._gather((np.asarray(keys, np.int64) % self._max_capacity).astype(np.int32))
 
     def update(self, keys, **kwargs: Any) -> None:
         self._sampling_distribution.update(keys, **kwargs)

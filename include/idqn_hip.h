@@ -157,7 +157,20 @@ int sumtree_query(const double* nodes_dev, int32_t depth, const double* targets_
  * ReplayElement's state and next_state back to back: [2][obs_bytes]; slot = key % capacity (keys
  * are the monotonically increasing add_count and eviction is FIFO, :206-213).
  * ---------------------------------------------------------------------------------------- */
-/* ReplayBuffer.sample's gather + np.stack (replay_buffer.py:223-229): copies the sampled slots'
+/* Frame-ring replay store (the layout ReplayBuffer uses): every environment frame is written to HBM once, at ring
+ * slot (transition index % n_frames) of frames_dev [n_frames][frame_elems * itemsize]; a replay element is one row
+ * of meta_dev, int32 [capacity][8] = {newest state frame slot, valid state frames, newest next_state frame slot,
+ * valid next_state frames, action, reward as f32 bits, terminal, 0}.  This call is ReplayBuffer.sample's fetch +
+ * unpack + np.stack (replay_buffer.py:223-229) fused with the accumulator's stack building (:119-137,
+ * `state[..., ch] = observation`, zero frames before the episode start): for sample i it writes
+ * state_out[i][pixel][ch] = frame[newest - (stack-1-ch)][pixel] (0 where fewer than stack frames are valid), the same
+ * for next_state, and the three scalars.  Outputs: [n][frame_elems][stack] elements of `itemsize` bytes.            */
+int replay_gather_stacked(const uint8_t* frames_dev, int64_t n_frames, int64_t frame_elems, int32_t itemsize,
+                          int32_t stack, const int32_t* meta_dev, const int32_t* slots_dev, int32_t n,
+                          uint8_t* state_out_dev, uint8_t* next_state_out_dev, int32_t* action_out_dev,
+                          float* reward_out_dev, uint8_t* terminal_out_dev, void* stream);
+/* Plain row gather of a store that keeps whole (state, next_state) pairs per slot, [capacity][2][obs_bytes]:
+ * copies the sampled slots'
  * state / next_state into contiguous [n][obs_bytes] batches.                                       */
 int replay_gather(const uint8_t* store_dev, int64_t obs_bytes, const int32_t* slots_dev, int32_t n,
                   uint8_t* state_out_dev, uint8_t* next_state_out_dev, void* stream);

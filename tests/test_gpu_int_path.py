@@ -113,3 +113,87 @@ def test_sumtree_query_paths_agree_with_the_oracle(capacity):
         np.testing.assert_array_equal(np.asarray(a.query(t)), b.query(t))
     with pytest.raises(ValueError):
         a.query(np.asarray([root]))
+
+
+def _stream(rng, i, shape, dtype, pattern):
+    """One synthetic transition; `pattern` scripts (terminal, truncated) so that runs of very short truncated episodes
+    (which make no elements at all) stretch the transitions an alive element's frames lie back."""
+    if np.issubdtype(dtype, np.integer):
+        obs = rng.integers(0, 200, size=shape).astype(dtype)
+    else:
+        obs = rng.normal(size=shape).astype(dtype)
+    term, trunc = pattern(i, rng)
+    return obs, int(rng.integers(0, 6)), float(rng.normal()), bool(term), bool(trunc)
+
+
+@pytest.mark.parametrize("shape,dtype,stack,n,cap", [
+    ((12, 12), np.uint8, 4, 3, 64),      # Atari-like: the packed uint8 x 4 path
+    ((84, 84), np.uint8, 4, 1, 40),      # the real frame size
+    ((8,), np.float32, 1, 1, 50),        # LunarLander-like: stack 1, f32 (generic path)
+    ((5, 3), np.int64, 3, 5, 16),        # odd stack depth, 8-byte elements
+    ((7, 9), np.uint8, 4, 2, 16),        # frame bytes not a multiple of 4: generic path for uint8 x 4
+])
+def test_frame_ring_buffer_equals_the_reference_elements(shape, dtype, stack, n, cap):
+    """The frame-ring store (one HBM write per frame, stacks assembled by replay_gather_stacked) must hold exactly
+    the elements the reference's accumulator materialises: zero frames before the episode start, early-terminal
+    horizons, the terminal flush, truncated episodes, FIFO eviction -- for every alive key, bit for bit."""
+    from oracle.replay_ref import ReplayRef, Transition as TRef
+    from oracle.samplers_ref import UniformRef
+
+    SumTree, Uniform, Prioritized, ReplayBuffer, Transition = _classes()
+    a = ReplayBuffer(Uniform(1), batch_size=8, max_capacity=cap, stack_size=stack, update_horizon=n, gamma=0.97)
+    b = ReplayRef(UniformRef(1), batch_size=8, max_capacity=cap, stack_size=stack, update_horizon=n, gamma=0.97)
+    rng = np.random.default_rng(17)
+    pattern = lambda i, r: (r.random() < 0.06, r.random() < 0.05)
+    for i in range(5 * cap + 37):
+        obs, act, rew, term, trunc = _stream(rng, i, shape, dtype, pattern)
+        a.add(Transition(obs, act, rew, term, trunc))
+        b.add(TRef(obs, act, rew, term, trunc))
+        if i % 61 == 0 and a.add_count:
+            x, y = a.sample(), b.sample()
+            np.testing.assert_array_equal(np.asarray(x.state), y.state)
+            np.testing.assert_array_equal(np.asarray(x.next_state), y.next_state)
+            np.testing.assert_array_equal(np.asarray(x.reward), y.reward.astype(np.float32))
+    assert a.add_count == b.add_count and list(a._memory.keys()) == list(b.memory.keys())
+    for key in b.memory:
+        got, want = a._memory[key], b.memory[key]
+        np.testing.assert_array_equal(got.state, want.state)
+        np.testing.assert_array_equal(got.next_state, want.next_state)
+        assert got.state.dtype == want.state.dtype and got.state.shape == want.state.shape
+        assert got.action == want.action and got.reward == want.reward
+        assert got.is_terminal == want.is_terminal and got.episode_end == want.episode_end
+
+
+def test_frame_ring_grows_when_elementless_transitions_pile_up():
+    """Episodes shorter than the horizon that are truncated make no elements, so alive elements can refer to frames
+    arbitrarily many transitions back; the ring must grow rather than overwrite them."""
+    from oracle.replay_ref import ReplayRef, Transition as TRef
+    from oracle.samplers_ref import UniformRef
+
+    SumTree, Uniform, Prioritized, ReplayBuffer, Transition = _classes()
+    cap, stack, n = 8, 4, 3
+    a = ReplayBuffer(Uniform(2), batch_size=4, max_capacity=cap, stack_size=stack, update_horizon=n, gamma=0.9)
+    b = ReplayRef(UniformRef(2), batch_size=4, max_capacity=cap, stack_size=stack, update_horizon=n, gamma=0.9)
+    rng = np.random.default_rng(3)
+
+    def pattern(i, r):
+        phase = i % 400
+        if phase < 40:
+            return (phase % 13 == 12, False)     # ordinary episodes: elements are made
+        return (False, phase % 3 == 2)           # 120 three-step truncated episodes: no elements at all
+
+    n0 = None
+    for i in range(1300):
+        obs, act, rew, term, trunc = _stream(rng, i, (6, 6), np.uint8, pattern)
+        a.add(Transition(obs, act, rew, term, trunc))
+        b.add(TRef(obs, act, rew, term, trunc))
+        n0 = n0 or a._n_frames
+        if i % 97 == 0:
+            for key in b.memory:
+                np.testing.assert_array_equal(a._memory[key].state, b.memory[key].state)
+                np.testing.assert_array_equal(a._memory[key].next_state, b.memory[key].next_state)
+    assert a._n_frames > n0, "the scripted stream should have exhausted the initial ring"
+    assert a.add_count == b.add_count
+    x, y = a.sample(), b.sample()
+    np.testing.assert_array_equal(np.asarray(x.state), y.state)
+    np.testing.assert_array_equal(np.asarray(x.action), y.action)

@@ -156,6 +156,41 @@ def main():
     dt = (time.perf_counter() - t0) / n
     out["sample_gather_learn"] = {"ms_per_step": dt * 1e3, "grad-steps/s": 1 / dt,
                                   "what": "PER query (cap 2^20) + gather + K=5 B=32 Nature-CNN step, wall clock"}
+    # ---- ReplayBuffer.add / sample through the Python mirror (frame ring: one 7 KB upload per environment step) ----
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    rb = ReplayBuffer(UniformSamplingDistribution(0), batch_size=32, max_capacity=100_000, stack_size=4,
+                      update_horizon=1, gamma=0.99)
+    frames = rng.integers(0, 256, size=(64, 84, 84), dtype=np.uint8)
+    for i in range(2000):
+        rb.add(TransitionElement(frames[i % 64], i % 6, 1.0, i % 500 == 499, False))
+    torch.cuda.synchronize()
+    n = 20000
+    t0 = time.perf_counter()
+    for i in range(n):
+        rb.add(TransitionElement(frames[i % 64], i % 6, 1.0, i % 500 == 499, False))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out["replay_add"] = {"us_per_add": dt * 1e6, "adds/s": 1 / dt, "bytes_uploaded_per_add": 84 * 84,
+                         "ring_frames": rb._n_frames, "store_MB": rb._frames.numel() / 1e6}
+    t0 = time.perf_counter()
+    for i in range(2000):
+        rb.sample()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2000
+    out["replay_sample_B32"] = {"us_per_sample": dt * 1e6, "what": "host PCG64 draw + key map + stacked gather launch"}
+
+    def gather_only():
+        _hip.check(lib.replay_gather_stacked(_hip.ptr(rb._frames), rb._n_frames, rb._frame_elems, 1, 4,
+                                             _hip.ptr(rb._meta_dev), _hip.ptr(rb._stage[32]["slots"]), 32,
+                                             _hip.ptr(rb._stage[32]["state"]), _hip.ptr(rb._stage[32]["next_state"]),
+                                             _hip.ptr(rb._stage[32]["action"]), _hip.ptr(rb._stage[32]["reward"]),
+                                             _hip.ptr(rb._stage[32]["terminal"]), q), "replay_gather_stacked")
+
+    dt = timed(gather_only, args.reps)
+    moved = 2 * 2 * 32 * 84 * 84 * 4
+    out["replay_gather_stacked_B32"] = {"us": dt * 1e6, "GB/s": moved / dt / 1e9, "bytes": moved}
     print(json.dumps(out, indent=1))
 
 
