@@ -405,6 +405,8 @@ struct TdArgs {
     double* cum;           // [K] running f64 sum of the per-head losses (idqn.py:72)
     int finish_step;       // 1: this launch also does count += 1 and cum += loss (every later kernel of the step
                            //    reads bcinv, not count); 0: two-phase step, idqn_apply_adam's epilogue does it
+    const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr = plain mean
+    float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
 };
 
 __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
@@ -455,11 +457,13 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
                 const float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * m;
                 td = qo[ac * 32 + bl] - tgt;
             }
+            const float wgt = (valid && a.is_weight) ? a.is_weight[bg] : 1.0f;
             if (h == 0) {
-                cs[bl] = 2.0f * td / (float)a.Bdiv;
+                cs[bl] = 2.0f * wgt * td / (float)a.Bdiv;
                 acts[bl] = ac;
+                if (jc == 0 && valid && a.td_abs) a.td_abs[(long)k * a.B + bg] = fabsf(td);
             }
-            float sq = (h == 0) ? td * td : 0.f;
+            float sq = (h == 0) ? wgt * td * td : 0.f;
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
             if (lane == 0) red[0] = sq;

@@ -40,6 +40,8 @@ struct FcArgs {
     float adam_b1, adam_b2;
     double* cum;          // [K] running f64 loss sum (idqn.py:72)
     int finish_step;      // 1: also count += 1, cum += loss here (the Adam kernel reads bcinv, not count)
+    const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr
+    float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
 };
 
 // out[b][o] = (relu?)(bias[o] + sum_i in[b][i] * W[i][o])
@@ -101,8 +103,10 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
         float tgt = a.reward[b] + (float)(1 - (int)a.terminal[b]) * a.gamma_n * qmax[b];
         int ac = a.action[b];
         float td = q[(long)b * dm + ac] - tgt;
-        sq[b] = td * td;
-        for (int o = 0; o < A; ++o) delta[(long)b * dm + o] = (o == ac) ? 2.0f * td / (float)a.Bdiv : 0.f;
+        const float wgt = a.is_weight ? a.is_weight[b] : 1.0f;
+        if (a.td_abs) a.td_abs[(long)k * B + b] = fabsf(td);
+        sq[b] = wgt * td * td;
+        for (int o = 0; o < A; ++o) delta[(long)b * dm + o] = (o == ac) ? 2.0f * wgt * td / (float)a.Bdiv : 0.f;
     }
     __syncthreads();
     if (t == 0) {

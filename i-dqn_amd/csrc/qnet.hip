@@ -171,6 +171,8 @@ struct idqn_handle_s {
     // stride gP = P - w0n), 64 floats reserved for the caller (losses), then [K][w0n] Dense_0/kernel gradients.
     // Two contiguous regions = two collectives in the data-parallel step.  fc: w0n = 0, gP = P.
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
+    const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
+    float* td_abs = nullptr;
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
     int pend_B = 0;  // batch of a backward stopped after Dense_0 (idqn_backward_rest resumes it); 0 = none
@@ -437,6 +439,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
+    ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
     hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
@@ -657,6 +660,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         a.ws = h->fc_ws; a.losses = h->losses; a.q_dbg = h->qdbg;
         a.count = h->count; a.bcinv = h->bcinv; a.adam_b1 = h->ad.b1; a.adam_b2 = h->ad.b2;
         a.cum = h->cum; a.finish_step = grads_only ? 0 : 1;
+        a.is_weight = h->is_weight; a.td_abs = h->td_abs;
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
         hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
@@ -700,6 +704,13 @@ extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_de
     if (rc) return rc;
     if ((rc = launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q))) return rc;  // every other leaf, from grad_dev
     return step_epilogue(h, true, q);
+}
+
+extern "C" int idqn_set_per_buffers(idqn_handle_t h, const float* weights_dev, float* td_abs_out_dev) {
+    IDQN_REQUIRE(h, "idqn_set_per_buffers: null handle");
+    h->is_weight = weights_dev;
+    h->td_abs = td_abs_out_dev;
+    return IDQN_OK;
 }
 
 extern "C" int idqn_apply_adam(idqn_handle_t h, void* stream) {

@@ -142,16 +142,8 @@ __global__ void k_sumtree_query(const double* __restrict__ nodes, int depth, con
 // levels below the current node are fetched by the 64 lanes in one round trip, then the wave descends those levels
 // out of registers (shuffles): depth 21 costs 4 dependent memory round trips instead of 20.  Same comparisons and
 // the same `t -= left_sum` sequence as the scalar walk, so the result is bit-identical.
-__global__ __launch_bounds__(256) void k_sumtree_query_wave(const double* __restrict__ nodes, int depth,
-                                                            const double* __restrict__ targets, int n,
-                                                            int32_t* __restrict__ out, int32_t* __restrict__ status) {
+__device__ __forceinline__ unsigned int wave_descend(const double* __restrict__ nodes, int depth, double t, int& bad) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;  // wave-uniform
-    const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
-    double t = targets[i];
-    int bad = 0;
-    if (!(t >= 0.0 && t < nodes[0])) bad |= 1;
     unsigned int node = 0;
     int level = 0;
     const int h = lane + 1;                 // 1-based heap number inside the sub-tree; lane 63 idles
@@ -177,10 +169,39 @@ __global__ __launch_bounds__(256) void k_sumtree_query_wave(const double* __rest
         node = (node + 1u) * (1u << jj) + (cur - (1u << jj)) - 1u;
         level += s;
     }
-    if (lane == 0) {
+    return node;
+}
+
+__global__ __launch_bounds__(256) void k_sumtree_query_wave(const double* __restrict__ nodes, int depth,
+                                                            const double* __restrict__ targets, int n,
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ status) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;  // wave-uniform
+    const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
+    const double t = targets[i];
+    int bad = 0;
+    if (!(t >= 0.0 && t < nodes[0])) bad |= 1;
+    const unsigned int node = wave_descend(nodes, depth, t, bad);
+    if ((threadIdx.x & 63) == 0) {
         out[i] = (int32_t)(node - first_leaf);
         if (bad) atomicOr(status, bad);
     }
+}
+
+// Extension (prioritized-replay loop without a host round trip for the root): targets are made on the device from
+// uniforms in [0, 1): u * root, or the stratified (i + u) / n * root, clamped below the root.
+__global__ __launch_bounds__(256) void k_per_sample(const double* __restrict__ nodes, int depth,
+                                                    const double* __restrict__ uniforms, int n, int stratified,
+                                                    int32_t* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
+    const double root = nodes[0];
+    double t = stratified ? ((double)i + uniforms[i]) / (double)n * root : uniforms[i] * root;
+    t = fmin(t, nextafter(root, 0.0));
+    int bad = 0;
+    const unsigned int node = (root > 0.0) ? wave_descend(nodes, depth, t, bad) : first_leaf;
+    if ((threadIdx.x & 63) == 0) out[i] = (int32_t)(node - first_leaf);
 }
 
 extern "C" int sumtree_set(double* nodes_dev, int32_t depth, const int32_t* indices_dev, const double* values_dev,
@@ -215,6 +236,106 @@ extern "C" int sumtree_query(const double* nodes_dev, int32_t depth, const doubl
     else
         hipLaunchKernelGGL(k_sumtree_query, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, nodes_dev, depth,
                            targets_dev, n, out_dev, status_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prioritized-replay EXTENSION (the reference has no write-back path: its sample() drops the keys,
+// replay_buffer.py:222-230, so there is no behaviour to match here -- parity unpinned).
+// ---------------------------------------------------------------------------------------------------
+// w_i = (n_items * p_i / root)^(-beta), normalised by the largest weight of the batch (Schaul et al. 2016, eq. 2).
+__global__ __launch_bounds__(1024) void k_per_weights(const double* __restrict__ nodes, int depth,
+                                                      const int32_t* __restrict__ leaves, int n, double n_items,
+                                                      double beta, float* __restrict__ out) {
+    __shared__ double red[1024];
+    const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
+    const double root = nodes[0];
+    double wmax = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double p = nodes[first_leaf + (unsigned int)leaves[i]];
+        const double w = (p > 0.0 && root > 0.0) ? pow(n_items * p / root, -beta) : 0.0;
+        wmax = fmax(wmax, w);
+    }
+    red[threadIdx.x] = wmax;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    wmax = red[0];
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double p = nodes[first_leaf + (unsigned int)leaves[i]];
+        const double w = (p > 0.0 && root > 0.0) ? pow(n_items * p / root, -beta) : 0.0;
+        out[i] = wmax > 0.0 ? (float)(w / wmax) : 1.0f;
+    }
+}
+
+// priority_i = (reduce_k |td[k][i]| + eps)^alpha ; reduce = mean (0) or max (1) over the K heads; also keeps the
+// running maximum priority (the reference's `max_recorded_priority`, sum_tree.py:18,32) in max_dev[0].
+__global__ void k_per_priorities(const float* __restrict__ td_abs, int K, int n, int reduce_max, double eps,
+                                 double alpha, double* __restrict__ out, double* __restrict__ max_dev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double v = (double)td_abs[(long)k * n + i];
+        acc = reduce_max ? fmax(acc, v) : acc + v;
+    }
+    if (!reduce_max) acc /= (double)K;
+    const double pr = pow(acc + eps, alpha);
+    out[i] = pr;
+    if (max_dev) atomicMax(reinterpret_cast<unsigned long long*>(max_dev), (unsigned long long)__double_as_longlong(pr));
+}
+
+// One leaf, index passed by value (no index upload): leaf <- value, every ancestor += (value - old leaf) -- exactly
+// what SumTree.set does for a single element (sum_tree.py:33-47).  value_dev, when given, overrides `value`.
+__global__ void k_sumtree_set_one(double* __restrict__ nodes, int depth, int index, double value,
+                                  const double* __restrict__ value_dev) {
+    unsigned int node = ((1u << (depth - 1)) - 1u) + (unsigned int)index;
+    const double v = value_dev ? value_dev[0] : value;
+    const double delta = v - nodes[node];
+    for (int level = 0; level < depth; ++level) {
+        nodes[node] = nodes[node] + delta;
+        node = (node - 1u) >> 1;  // unused after the root
+    }
+}
+
+extern "C" int sumtree_set_one(double* nodes_dev, int32_t depth, int32_t index, double value, const double* value_dev,
+                               void* stream) {
+    IDQN_REQUIRE(nodes_dev && depth >= 1 && depth <= 31, "sumtree_set_one: bad arguments");
+    IDQN_REQUIRE(index >= 0 && (int64_t)index < ((int64_t)1 << (depth - 1)), "sumtree_set_one: index %d out of range", index);
+    IDQN_REQUIRE(value_dev || value >= 0.0, "sumtree_set_one: negative value");
+    hipLaunchKernelGGL(k_sumtree_set_one, dim3(1), dim3(1), 0, (hipStream_t)stream, nodes_dev, depth, index, value, value_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+extern "C" int per_sample_leaves(const double* nodes_dev, int32_t depth, const double* uniforms_dev, int32_t n,
+                                 int32_t stratified, int32_t* leaves_out_dev, void* stream) {
+    IDQN_REQUIRE(nodes_dev && uniforms_dev && leaves_out_dev && n >= 1, "per_sample_leaves: bad arguments");
+    IDQN_REQUIRE(depth >= 1 && depth <= 31, "per_sample_leaves: depth %d out of range", depth);
+    hipLaunchKernelGGL(k_per_sample, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, nodes_dev, depth, uniforms_dev, n,
+                       stratified, leaves_out_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+extern "C" int per_importance_weights(const double* nodes_dev, int32_t depth, const int32_t* leaves_dev, int32_t n,
+                                      int64_t n_items, double beta, float* weights_out_dev, void* stream) {
+    IDQN_REQUIRE(nodes_dev && leaves_dev && weights_out_dev && n >= 1 && n_items >= 1, "per_importance_weights: bad arguments");
+    IDQN_REQUIRE(depth >= 1 && depth <= 31, "per_importance_weights: depth %d out of range", depth);
+    hipLaunchKernelGGL(k_per_weights, dim3(1), dim3(1024), 0, (hipStream_t)stream, nodes_dev, depth, leaves_dev, n,
+                       (double)n_items, beta, weights_out_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+extern "C" int per_priorities_from_td(const float* td_abs_dev, int32_t n_heads, int32_t n, int32_t reduce_max, double eps,
+                                      double alpha, double* priorities_out_dev, double* max_priority_dev, void* stream) {
+    IDQN_REQUIRE(td_abs_dev && priorities_out_dev && n_heads >= 1 && n >= 1, "per_priorities_from_td: bad arguments");
+    hipLaunchKernelGGL(k_per_priorities, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, td_abs_dev, n_heads, n,
+                       reduce_max, eps, alpha, priorities_out_dev, max_priority_dev);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }

@@ -48,6 +48,11 @@ SYMBOLS = {
     "idqn_export_dense0_factors": (C.c_int, [_P, _P, _P, _P]),
     "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [_P]),
     "idqn_apply_adam": (C.c_int, [_P, _P]),
+    "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
+    "sumtree_set_one": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]),
+    "per_sample_leaves": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    "per_importance_weights": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_double, _P, _P]),
+    "per_priorities_from_td": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, _P, _P]),
     "idqn_target_update": (C.c_int, [_P, _P]),
     "idqn_target_sync": (C.c_int, [_P, _P]),
     "idqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),

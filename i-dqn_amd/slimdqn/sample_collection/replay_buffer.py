@@ -316,12 +316,21 @@ class ReplayBuffer:
     def _gather(self, slots: np.ndarray) -> ReplayElement:
         import torch
 
+        st = self._staging(int(slots.size))
+        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots, np.int32)))
+        return self._gather_device(st["slots"])
+
+    def _gather_device(self, slots_dev) -> ReplayElement:
+        """Stacked gather for slots that are already on the device (int32 tensor): no host round trip."""
+        import torch
+
         from slimdqn import _hip
 
-        size = int(slots.size)
+        size = int(slots_dev.numel())
         self._flush_meta()
         st = self._staging(size)
-        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots, np.int32)))
+        if slots_dev.data_ptr() != st["slots"].data_ptr():
+            st["slots"].copy_(slots_dev)
         _hip.check(_hip.lib().replay_gather_stacked(
             _hip.ptr(self._frames), self._n_frames, self._frame_elems, self._itemsize, self._stack_size,
             _hip.ptr(self._meta_dev), _hip.ptr(st["slots"]), size, _hip.ptr(st["state"]), _hip.ptr(st["next_state"]),

@@ -153,6 +153,30 @@ int sumtree_query(const double* nodes_dev, int32_t depth, const double* targets_
                   int32_t* out_dev, int32_t* status_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Prioritized-replay write-back: an EXTENSION with no reference counterpart (the reference's sample() drops the
+ * sampled keys, replay_buffer.py:222-230, and its loss has no importance weights, idqn.py:111-112) -- SURVEY 8f-4,
+ * "design freely, parity unpinned".  Checked against the oracle's weighted loss / TD errors only.
+ * ---------------------------------------------------------------------------------------- */
+/* Per-sample loss weights (float [batch], NULL = the reference's plain mean) and an output for |TD error|
+ * (float [K][batch], NULL = none) used by every following idqn_learn_on_batch: loss_k = sum_b w_b td_kb^2 / divisor. */
+int idqn_set_per_buffers(idqn_handle_t h, const float* weights_dev, float* td_abs_out_dev);
+/* SumTree.set for ONE leaf with the index passed by value (no index upload; sum_tree.py:33-47 for n = 1); the new
+ * value is `value`, or value_dev[0] when value_dev is not NULL (e.g. the running maximum priority).                  */
+int sumtree_set_one(double* nodes_dev, int32_t depth, int32_t index, double value, const double* value_dev,
+                    void* stream);
+/* Leaves for targets made on the device from uniforms in [0, 1) (float64 [n]): u_i * root, or the stratified
+ * (i + u_i) / n * root; same descent as sumtree_query, no host read of the root.                                      */
+int per_sample_leaves(const double* nodes_dev, int32_t depth, const double* uniforms_dev, int32_t n,
+                      int32_t stratified, int32_t* leaves_out_dev, void* stream);
+/* w_i = (n_items * p_i / root)^(-beta) / max_j w_j for the sampled leaves (p from the sum tree).                     */
+int per_importance_weights(const double* nodes_dev, int32_t depth, const int32_t* leaves_dev, int32_t n,
+                           int64_t n_items, double beta, float* weights_out_dev, void* stream);
+/* priority_i = (mean_k or max_k |td[k][i]| + eps)^alpha as float64, ready for sumtree_set on the same leaves;
+ * max_priority_dev[0] (may be NULL) keeps the running maximum (sum_tree.py:18,32 `max_recorded_priority`).           */
+int per_priorities_from_td(const float* td_abs_dev, int32_t n_heads, int32_t n, int32_t reduce_max, double eps,
+                           double alpha, double* priorities_out_dev, double* max_priority_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Replay store in HBM (slimdqn/sample_collection/replay_buffer.py:202-230).  One slot holds one
  * ReplayElement's state and next_state back to back: [2][obs_bytes]; slot = key % capacity (keys
  * are the monotonically increasing add_count and eviction is FIFO, :206-213).

@@ -189,17 +189,19 @@ def td_target(q_next, reward, terminal, gamma_n, dtype=np.float64):
     return reward.astype(dtype) + (1 - terminal.astype(np.int64)).astype(dtype) * dtype(gamma_n) * q_next.max(1)
 
 
-def loss_and_grads(p_online, p_target, batch, arch, gamma_n, dtype=np.float64):
-    """One head: (loss, grads, aux) -- idqn.py:105,111-118."""
+def loss_and_grads(p_online, p_target, batch, arch, gamma_n, dtype=np.float64, weights=None):
+    """One head: (loss, grads, aux) -- idqn.py:105,111-118.  ``weights`` (per-sample loss weights, default none) is
+    NOT in the reference: it restates the prioritized-replay extension's loss  mean_b w_b * td_b**2  (SURVEY 8f-4)."""
     state, action, reward, next_state, terminal = batch
     bsz = state.shape[0]
     q, tape = forward(p_online, state, arch, dtype, keep=True)
     q_next = forward(p_target, next_state, arch, dtype)
     tgt = td_target(q_next, reward, terminal, gamma_n, dtype)
     td = q[np.arange(bsz), action] - tgt
-    loss = (td * td).mean()
+    w = np.ones(bsz, dtype) if weights is None else np.asarray(weights, dtype)
+    loss = (w * td * td).mean()
     dq = np.zeros_like(q)
-    dq[np.arange(bsz), action] = 2.0 * td / bsz
+    dq[np.arange(bsz), action] = 2.0 * w * td / bsz
     trace = {}
     grads = backward(p_online, tape, dq, dtype, trace)
     return loss, grads, {"q": q, "q_next": q_next, "target": tgt, "td": td, "tape": tape, "trace": trace}
