@@ -31,9 +31,26 @@ struct ActGeom {
 // minibatch tile is transposed in LDS so that both the HBM read and the HBM write are coalesced)
 // architectures/dqn.py:44  `jnp.array(x, ndmin=4) / 255.0`
 // --------------------------------------------------------------------------------------------
+// exact three-way bf16 split of an f32 value into a 3-plane row [plane][32] (see conv3_kernels.h)
+__device__ __forceinline__ unsigned short idqn_bf16_rne(float x) {
+    unsigned int u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void prep_store3(unsigned short* row, int col, float v) {
+    const unsigned short h0 = idqn_bf16_rne(v);
+    float r = v - __uint_as_float((unsigned int)h0 << 16);
+    const unsigned short h1 = idqn_bf16_rne(r);
+    r = r - __uint_as_float((unsigned int)h1 << 16);
+    row[col] = h0;
+    row[32 + col] = h1;
+    row[64 + col] = idqn_bf16_rne(r);
+}
+
 struct PrepArgs {
     const uint8_t* src[2];  // state, next_state  [B][E]
     float* x;               // [n_sets][nb][g.block]
+    unsigned short* x3;     // the same rows as three bf16 planes (conv3_kernels.h) or nullptr
     long E;                 // H*W*C
     int B, nb, n_sets;
     ActGeom g;
@@ -68,6 +85,7 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
     }
     __syncthreads();
     float* x = a.x + ((long)set * a.nb + bb) * a.g.block;
+    unsigned short* x3 = a.x3 ? a.x3 + ((long)set * a.nb + bb) * a.g.block * 3 : nullptr;
     const int b = t & 31;
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -79,6 +97,7 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
             int w = (int)(hw % a.g.W), h = (int)(hw / a.g.W);
             long row = ((long)(h + a.g.lo_h) * a.g.Wp + (w + a.g.lo_w)) * a.g.C + c;
             x[row * 32 + b] = tile[el][b];
+            if (x3) prep_store3(x3 + row * 96, b, tile[el][b]);
         }
     }
 }
@@ -576,6 +595,7 @@ struct DenseDgradArgs {
     const float* dh;   // [K][nb][J][32]
     const float* a3;   // [2K][nb][F*32]  (online nets first)
     float* da3;        // [K][nb][g.block]
+    unsigned short* da3_3;  // the same rows as three bf16 planes or nullptr
     const float* const* wbase;
     long w_off, n_items;
     int K, nb, n_ft, F, J, C;  // C = channels of a3 (f = pos*C + c)
@@ -641,6 +661,11 @@ __global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
     for (int r = 0; r < 16; ++r) mk[r] = A3[(long)(f0 + mfma_row(r, h)) * 32 + bl];
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[(row0 + mfma_row(r, h)) * 32 + bl] = mk[r] > 0.f ? acc[r] : 0.f;
+    if (a.da3_3) {
+        unsigned short* O3 = a.da3_3 + ((long)k * a.nb + bb) * a.g.block * 3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prep_store3(O3 + (row0 + mfma_row(r, h)) * 96, bl, mk[r] > 0.f ? acc[r] : 0.f);
+    }
 }
 
 // --------------------------------------------------------------------------------------------

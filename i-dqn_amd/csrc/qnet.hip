@@ -8,10 +8,14 @@
 // Scratch buffers are addressed compactly with the ACTIVE number of 32-sample batch blocks of a call
 // (slot = (net * nb + bb) * block); zero borders sit at fixed offsets inside every block-sized slot
 // and only interiors are ever written, so they stay zero for any nb.
+#include <cstdlib>
 #include <string>
 #include <vector>
 
-#include "cnn_kernels.h"
+#include "conv3_kernels.h"
+#ifndef C3_RING
+#define C3_RING 2
+#endif
 #include "fc_kernels.h"
 
 namespace {
@@ -133,6 +137,7 @@ struct NetSet {
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
     float *x = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *part = nullptr;
+    unsigned short *x3 = nullptr, *a1_3 = nullptr, *a2_3 = nullptr;  // 3-plane bf16 copies (conv3 path only)
 };
 
 }  // namespace
@@ -156,6 +161,11 @@ struct idqn_handle_s {
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
     long wt_stride[3] = {0, 0, 0};
+    // bf16x3 conv path (conv3_kernels.h): packed weight planes of every training net and the 3-plane dout buffers
+    bool conv3 = false;
+    unsigned short *w3 = nullptr, *da3_3 = nullptr, *da2_3 = nullptr;
+    float* c3prof = nullptr;  // debug: phase timestamps of the Conv_2 forward launch (IDQN_CONV_PROF=1)
+    long w3_stride = 0, w3_fwd[3] = {0, 0, 0}, w3_dg[3] = {0, 0, 0};
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
     SlabSeg segs[3];  // slab descriptors of the last backward (consumed by the fused Adam launch)
@@ -187,6 +197,14 @@ int alloc_zero(float** p, long n_floats, idqn_handle_s* h, const char* name) {
     IDQN_HIP_CHECK(hipMemset(*p, 0, (size_t)n_floats * 4));
     h->owned.push_back((void*)*p);
     h->dbg.push_back({name, {(void*)*p, n_floats * 4}});
+    return IDQN_OK;
+}
+
+int alloc_zero16(unsigned short** p, long n, idqn_handle_s* h, const char* name) {
+    IDQN_HIP_CHECK(hipMalloc((void**)p, (size_t)n * 2));
+    IDQN_HIP_CHECK(hipMemset(*p, 0, (size_t)n * 2));
+    h->owned.push_back((void*)*p);
+    h->dbg.push_back({name, {(void*)*p, n * 2}});
     return IDQN_OK;
 }
 
@@ -257,6 +275,26 @@ int cnn_setup(idqn_handle_s* h) {
     int rc;
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
     if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_"))) return rc;
+    if (h->conv3) {
+        NetSet& ts = h->train;
+        if ((rc = alloc_zero16(&ts.x3, (long)2 * nb * h->gx.block * 3, h, "x3"))) return rc;
+        if ((rc = alloc_zero16(&ts.a1_3, (long)2 * K * nb * h->ga1.block * 3, h, "a1_3"))) return rc;
+        if ((rc = alloc_zero16(&ts.a2_3, (long)2 * K * nb * h->ga2.block * 3, h, "a2_3"))) return rc;
+        if ((rc = alloc_zero16(&h->da3_3, (long)K * nb * h->gda3.block * 3, h, "da3_3"))) return rc;
+        if ((rc = alloc_zero16(&h->da2_3, (long)K * nb * h->gda2.block * 3, h, "da2_3"))) return rc;
+        long off = 0;
+        for (int i = 0; i < 3; ++i) {  // forward kernels, then the transformed data-gradient kernels
+            h->w3_fwd[i] = off;
+            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 3;
+        }
+        for (int i = 1; i < 3; ++i) {
+            h->w3_dg[i] = off;
+            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 3;
+        }
+        h->w3_stride = (off + 63) / 64 * 64;
+        if ((rc = alloc_zero16(&h->w3, (long)2 * K * h->w3_stride, h, "w3"))) return rc;
+        if (getenv("IDQN_CONV_PROF") && (rc = alloc_zero(&h->c3prof, 2L * 4 * 4096, h, "c3prof"))) return rc;
+    }
     std::vector<const float*> wb(2 * K);
     std::vector<int> is(2 * K);
     for (int k = 0; k < K; ++k) {
@@ -331,38 +369,125 @@ int fc_setup(idqn_handle_s* h) {
     return IDQN_OK;
 }
 
+// Conv_1 / Conv_2 kernels re-indexed for the data gradient-as-convolution (k_wt_build), f32
+int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
+    const int K = h->cfg.n_heads;
+    WtBuildArgs wb;
+    wb.wbase = h->train.wbase; wb.K = K;
+    long maxe = 0;
+    for (int i = 1; i <= 2; ++i) {
+        const ConvL& l = h->conv[i];
+        WtLayer& w = wb.layer[i - 1];
+        w.wt = h->wt[i]; w.w_off = l.w_off; w.wt_stride = h->wt_stride[i];
+        w.KH = l.K; w.KW = l.K; w.CI = l.CI; w.CO = l.CO; w.S = l.S; w.PLh = l.PLh; w.PLw = l.PLw;
+        w.n_var = l.S * l.S; w.KHs = l.K / l.S; w.KWs = l.K / l.S;
+        maxe = std::max(maxe, (long)l.K * l.K * l.CI * l.CO);
+    }
+    hipLaunchKernelGGL(k_wt_build, dim3(cdiv(maxe, 256), K, 2), dim3(256), 0, q, wb);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+// bf16x3 path: the data-gradient kernels, then every kernel of the 2K training nets as packed bf16 planes
+int build_weights3(idqn_handle_s* h, hipStream_t q) {
+    const int K = h->cfg.n_heads;
+    int rc = build_dgrad_weights(h, q);
+    if (rc) return rc;
+    W3PackArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.wbase = h->train.wbase; pa.w3 = h->w3; pa.w3_stride = h->w3_stride;
+    for (int i = 1; i < 3; ++i) { pa.wt[i] = h->wt[i]; pa.wt_stride[i] = h->wt_stride[i]; }
+    int nj = 0;
+    long maxe = 0;
+    for (int i = 0; i < 3; ++i) {
+        const ConvL& l = h->conv[i];
+        W3Job& j = pa.job[nj++];
+        j.src = 0; j.src_off = l.w_off; j.dst_off = h->w3_fwd[i]; j.n_nets = 2 * K;
+        j.KH = l.K; j.KWCI = l.K * l.CI; j.CO = l.CO;
+        maxe = std::max(maxe, (long)j.KH * j.KWCI * j.CO);
+    }
+    for (int i = 1; i < 3; ++i) {
+        const ConvL& l = h->conv[i];
+        const int KHs = l.K / l.S;
+        const long per_var = (long)KHs * KHs * l.CO * l.CI;
+        for (int vi = 0; vi < l.S * l.S; ++vi) {
+            IDQN_REQUIRE(nj < 8, "bf16x3 conv path: more than 8 weight blocks to pack");
+            W3Job& j = pa.job[nj++];
+            j.src = i; j.src_off = vi * per_var; j.dst_off = h->w3_dg[i] + vi * per_var * 3; j.n_nets = K;
+            j.KH = KHs; j.KWCI = KHs * l.CO; j.CO = l.CI;
+        }
+    }
+    hipLaunchKernelGGL(k_w3_pack, dim3(cdiv(maxe, 256), 2 * K, nj), dim3(256), 0, q, pa);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
 int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q) {
     const int nb = cdiv(B, 32);
     IDQN_REQUIRE(nb <= s.nb_cap, "batch %d exceeds the workspace (%d blocks of 32)", B, s.nb_cap);
+    const bool c3 = h->conv3 && &s == &h->train;
     PrepArgs pa;
     pa.src[0] = st; pa.src[1] = st2 ? st2 : st;
-    pa.x = s.x; pa.E = (long)h->gx.H * h->gx.W * h->gx.C; pa.B = B; pa.nb = nb; pa.n_sets = s.n_in_sets; pa.g = h->gx;
+    pa.x = s.x; pa.x3 = c3 ? s.x3 : nullptr;
+    pa.E = (long)h->gx.H * h->gx.W * h->gx.C; pa.B = B; pa.nb = nb; pa.n_sets = s.n_in_sets; pa.g = h->gx;
     hipLaunchKernelGGL(k_prep_u8, dim3(cdiv(pa.E, 64), nb, s.n_in_sets), dim3(256), 0, q, pa);
     const float* ins[3] = {s.x, s.a1, s.a2};
     float* outs[3] = {s.a1, s.a2, s.a3};
     const ActGeom* gin[3] = {&h->gx, &h->ga1, &h->ga2};
     const ActGeom* gout[3] = {&h->ga1, &h->ga2, &h->ga3};
-    for (int i = 0; i < 3; ++i) {
-        const ConvL& l = h->conv[i];
-        ConvFwdArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = ins[i]; a.out = outs[i]; a.wbase = s.wbase; a.wt_base = nullptr; a.in_set = (i == 0) ? s.in_set : s.ident;
-        a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
-        a.n_nets = s.n_nets; a.nb = nb; a.n_var = 1; a.epilogue = 0;
-        a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
-        a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
-        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
-        const int npw = (l.CO == 32) ? 4 : 2;  // positions per workgroup
-        ConvVariant& v = a.var[0];
-        v.w_off = l.w_off; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
-        v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0; v.pg_begin = 0;
-        a.npg = cdiv(l.OH * l.OW, npw);
-        a.n_items = (long)s.n_nets * nb * a.npg;
-        if (l.CO == 32)
-            hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-        else
-            hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+    if (c3) {
+        int rc3 = build_weights3(h, q);  // transformed data-gradient kernels + the packed bf16 planes of every kernel
+        if (rc3) return rc3;
+        const unsigned short* ins3[3] = {s.x3, s.a1_3, s.a2_3};
+        unsigned short* outs3[3] = {s.a1_3, s.a2_3, nullptr};
+        const int K = h->cfg.n_heads;
+        for (int i = 0; i < 3; ++i) {
+            const ConvL& l = h->conv[i];
+            Conv3Args a;
+            memset(&a, 0, sizeof(a));
+            a.in3 = ins3[i]; a.out = outs[i]; a.out3 = outs3[i]; a.wbase = s.wbase; a.w3 = h->w3; a.w3_stride = h->w3_stride;
+            a.in_split = (i == 0) ? K : 0;  // Conv_0: online nets read `state`, target nets `next_state`
+            a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
+            a.n_nets = s.n_nets; a.nb = nb; a.n_var = 1; a.epilogue = 0;
+            a.f32_nets = (i == 2) ? s.n_nets : K;  // a1 / a2 in f32 only where the backward pass reads them
+            a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
+            a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
+            IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
+            const int npw = (l.CO == 32) ? 4 : 2;
+            ConvVariant& v = a.var[0];
+            v.w_off = h->w3_fwd[i]; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
+            v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0; v.pg_begin = 0;
+            a.npg = cdiv(l.OH * l.OW, npw);
+            a.n_items = (long)s.n_nets * nb * a.npg;
+            if (i == 2 && h->c3prof && a.n_items <= 4096) a.prof = (long long*)h->c3prof;
+            if (l.CO == 32)
+                hipLaunchKernelGGL((k_conv3<1, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+            else
+                hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            const ConvL& l = h->conv[i];
+            ConvFwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = ins[i]; a.out = outs[i]; a.wbase = s.wbase; a.wt_base = nullptr; a.in_set = (i == 0) ? s.in_set : s.ident;
+            a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
+            a.n_nets = s.n_nets; a.nb = nb; a.n_var = 1; a.epilogue = 0;
+            a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
+            a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
+            IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
+            const int npw = (l.CO == 32) ? 4 : 2;  // positions per workgroup
+            ConvVariant& v = a.var[0];
+            v.w_off = l.w_off; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
+            v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0; v.pg_begin = 0;
+            a.npg = cdiv(l.OH * l.OW, npw);
+            a.n_items = (long)s.n_nets * nb * a.npg;
+            if (l.CO == 32)
+                hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+            else
+                hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+        }
     }
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
@@ -443,7 +568,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
-    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3 ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
     dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
     dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
     hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
@@ -477,21 +602,47 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     float* dins[3] = {nullptr, h->da1, h->da2};
     const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
     // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
-    {
-        WtBuildArgs wb;
-        wb.wbase = s.wbase; wb.K = K;
-        long maxe = 0;
-        for (int i = 1; i <= 2; ++i) {
-            const ConvL& l = *cl[i];
-            WtLayer& w = wb.layer[i - 1];
-            w.wt = h->wt[i]; w.w_off = l.w_off; w.wt_stride = h->wt_stride[i];
-            w.KH = l.K; w.KW = l.K; w.CI = l.CI; w.CO = l.CO; w.S = l.S; w.PLh = l.PLh; w.PLw = l.PLw;
-            w.n_var = l.S * l.S; w.KHs = l.K / l.S; w.KWs = l.K / l.S;
-            maxe = std::max(maxe, (long)l.K * l.K * l.CI * l.CO);
-        }
-        hipLaunchKernelGGL(k_wt_build, dim3(cdiv(maxe, 256), K, 2), dim3(256), 0, q, wb);
+    if (!h->conv3) {  // (the bf16x3 path built and packed them before the forward pass)
+        int rcb = build_dgrad_weights(h, q);
+        if (rcb) return rcb;
     }
-    for (int i = 2; i >= 1; --i) {
+    const unsigned short* douts3[3] = {nullptr, h->da2_3, h->da3_3};
+    unsigned short* dins3[3] = {nullptr, nullptr, h->da2_3};
+    for (int i = 2; i >= 1 && h->conv3; --i) {
+        const ConvL& l = *cl[i];
+        const int KHs = l.K / l.S, nvar = l.S * l.S;
+        Conv3Args a;
+        memset(&a, 0, sizeof(a));
+        a.in3 = douts3[i]; a.out = dins[i]; a.out3 = dins3[i]; a.wbase = s.wbase; a.w3 = h->w3; a.w3_stride = h->w3_stride;
+        a.in_split = 0; a.mask = acts_in[i];
+        a.in_block = gdo[i]->block; a.out_block = gdi[i]->block; a.mask_block = gact[i]->block;
+        a.n_nets = K; a.nb = nb; a.n_var = nvar; a.epilogue = 1; a.f32_nets = K;
+        a.KH = KHs; a.KWCI = KHs * l.CO; a.S = 1; a.CI = l.CO; a.CO = l.CI; a.IWp = gdo[i]->Wp;
+        a.out_Wp = gdi[i]->Wp; a.out_lo_h = gdi[i]->lo_h; a.out_lo_w = gdi[i]->lo_w;
+        a.mask_Wp = gact[i]->Wp; a.mask_lo_h = gact[i]->lo_h; a.mask_lo_w = gact[i]->lo_w;
+        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d dgrad: %d rows per kernel row is not a multiple of 32", i, a.KWCI);
+        const int npw = (l.CI == 32) ? 4 : 2;
+        int pg = 0;
+        for (int vi = 0; vi < nvar; ++vi) {
+            const int rh = vi / l.S, rw = vi % l.S;
+            const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
+            ConvVariant& v = a.var[vi];
+            v.w_off = h->w3_dg[i] + (long)vi * KHs * KHs * l.CO * l.CI * 3;
+            v.in_off_h = (rh + l.PLh - ph) / l.S + gdo[i]->lo_h - KHs + 1;
+            v.in_off_w = (rw + l.PLw - pw) / l.S + gdo[i]->lo_w - KHs + 1;
+            v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
+            v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw; v.pg_begin = pg;
+            IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
+            pg += cdiv(v.OH * v.OW, npw);
+        }
+        a.npg = pg;
+        a.n_items = (long)K * nb * a.npg;
+        if (l.CI == 32)
+            hipLaunchKernelGGL((k_conv3<1, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+        else
+            hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+    }
+    for (int i = 2; i >= 1 && !h->conv3; --i) {
         const ConvL& l = *cl[i];
         const int KHs = l.K / l.S, nvar = l.S * l.S;
         ConvFwdArgs a;
@@ -610,6 +761,10 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
         h->gP = h->L.head_stride - (h->g_w0_end - h->g_w0_begin);
     }
     h->g_w0_base = (long)cfg->n_heads * h->gP + 64;
+    {  // conv arithmetic: f32 MFMA, or f32-accurate products on the bf16 matrix cores (conv3_kernels.h)
+        const char* mode = getenv("IDQN_CONV");
+        h->conv3 = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
+    }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
     if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
     if (rc) { idqn_destroy(h); return rc; }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libidqn_hip.so")
+LIB_PATH = os.environ.get("IDQN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libidqn_hip.so")  # override: kernel experiments
 
 IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
 IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24

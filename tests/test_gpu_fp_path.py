@@ -61,8 +61,16 @@ def _relerr(got, want):
     return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_mode(request, monkeypatch):
+    """Conv arithmetic of the agents a test creates: the f32 MFMA kernels (default) or the f32-accurate products on
+    the bf16 matrix cores (csrc/conv3_kernels.h); read by idqn_create from IDQN_CONV."""
+    monkeypatch.setenv("IDQN_CONV", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5"])
-def test_cnn_every_stage_against_oracle(name):
+def test_cnn_every_stage_against_oracle(name, conv_mode):
     """Forward activations, Q-values, every backward intermediate and every leaf gradient, stage by stage."""
     import torch
 
@@ -131,7 +139,7 @@ def test_cnn_every_stage_against_oracle(name):
 
 
 @pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5", "cnn_atari_a18_b64", "fc_lunar_k3"])
-def test_full_steps_against_goldens(name):
+def test_full_steps_against_goldens(name, conv_mode):
     """Fused path (weight gradient + Adam in one kernel): losses and post-Adam parameters of every step."""
     agent, bs, rec, _ = _agent(name)
     K = agent._K
@@ -296,7 +304,7 @@ def test_entry_points_train_end_to_end(env_name, tmp_path):
     ("fc", 8, [100, 100], 4, 3, 7),
     ("fc", (6, 1), [50], 2, 9, 64),
 ])
-def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B):
+def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B, conv_mode):
     """Edge cases of the batch / shape handling: live oracle comparison of losses, gradients and one Adam step."""
     from collections import namedtuple
 

@@ -1,0 +1,24 @@
+"""Phase timestamps of the Conv_2 forward launch of the bf16x3 path (IDQN_CONV=bf16x3 IDQN_CONV_PROF=1)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn.networks.idqn import iDQN
+import bench
+agent = iDQN(0, (84, 84, 4), 6, 5, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+b = Batch(*(torch.from_numpy(x).cuda() for x in bench.synthetic(0)))
+for _ in range(20):
+    agent._learn(b)
+torch.cuda.synchronize()
+p = agent._debug("c3prof").cpu().numpy().view(np.int64).reshape(-1, 4)[:610]
+t0 = p[:, 0].min()
+q = (p - t0) / 100.0  # wall_clock64 ticks at 100 MHz -> microseconds
+print("WG start   us: min %.2f median %.2f max %.2f" % (q[:, 0].min(), np.median(q[:, 0]), q[:, 0].max()))
+print("prologue   us: median %.2f max %.2f" % (np.median(q[:, 1] - q[:, 0]), (q[:, 1] - q[:, 0]).max()))
+print("k-loop     us: median %.2f max %.2f" % (np.median(q[:, 2] - q[:, 1]), (q[:, 2] - q[:, 1]).max()))
+print("epilogue   us: median %.2f max %.2f" % (np.median(q[:, 3] - q[:, 2]), (q[:, 3] - q[:, 2]).max()))
+print("kernel end us: %.2f" % q[:, 3].max())
+order = np.argsort(q[:, 0])
+print("start times of every 50th WG:", np.round(q[order[::50], 0], 1))
