@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
     const long long t_epi = a.prof ? wall_clock64() : 0;
     if (a.prof && t == 0) {
         long long* pr = a.prof + (long)blockIdx.x * 4;
-        pr[0] = t_start; pr[1] = t_loop; pr[2] = t_epi;
+        // HW_ID (register 4): cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID (register 20) [3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        pr[0] = t_start; pr[1] = t_loop; pr[2] = t_epi | ((long long)(((xcc & 15) << 8) | ((hw >> 8) & 0xff)) << 48);
     }
     const int pos = pg * NPW + sub;
     if (pos >= npos) return;

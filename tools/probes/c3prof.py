@@ -12,7 +12,9 @@ b = Batch(*(torch.from_numpy(x).cuda() for x in bench.synthetic(0)))
 for _ in range(20):
     agent._learn(b)
 torch.cuda.synchronize()
-p = agent._debug("c3prof").cpu().numpy().view(np.int64).reshape(-1, 4)[:610]
+p = agent._debug("c3prof").cpu().numpy().view(np.int64).reshape(-1, 4)[:610].copy()
+place = (p[:, 2] >> 48) & 0xfff  # (xcc << 8) | (se, sh, cu)
+p[:, 2] &= (1 << 48) - 1
 t0 = p[:, 0].min()
 q = (p - t0) / 100.0  # wall_clock64 ticks at 100 MHz -> microseconds
 print("WG start   us: min %.2f median %.2f max %.2f" % (q[:, 0].min(), np.median(q[:, 0]), q[:, 0].max()))
@@ -22,3 +24,9 @@ print("epilogue   us: median %.2f max %.2f" % (np.median(q[:, 3] - q[:, 2]), (q[
 print("kernel end us: %.2f" % q[:, 3].max())
 order = np.argsort(q[:, 0])
 print("start times of every 50th WG:", np.round(q[order[::50], 0], 1))
+
+import collections
+per_cu = collections.Counter(place.tolist())
+hist = collections.Counter(per_cu.values())
+print("distinct (xcc, se, sh, cu) slots used: %d ; workgroups per slot histogram: %s" % (len(per_cu), dict(sorted(hist.items()))))
+print("workgroups per XCC:", dict(sorted(collections.Counter((place >> 8).tolist()).items())))
