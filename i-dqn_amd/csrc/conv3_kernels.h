@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
     for (int c = 0; c < RING - 1; ++c)
         if (c < NC) C3_STAGE(c, c)
     const long long t_loop = a.prof ? wall_clock64() : 0;
+    const long long c_loop = a.prof ? clock64() : 0;
     const int lo = (8 * h + ((lane & 15) >> 2)) * ROW3 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     int buf = 0, nbuf = RING - 1;
     for (int c = 0; c < NC; ++c) {
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
     }
 #undef C3_STAGE
     const long long t_epi = a.prof ? wall_clock64() : 0;
+    const long long c_epi = a.prof ? clock64() : 0;
     if (a.prof && t == 0) {
         long long* pr = a.prof + (long)blockIdx.x * 4;
         // HW_ID (register 4): cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID (register 20) [3:0]
@@ -249,5 +251,5 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) store3(Y3 + (row0 + mfma_row(r, h)) * ROW3, bl, res[r]);
     }
-    if (a.prof && t == 0) a.prof[(long)blockIdx.x * 4 + 3] = wall_clock64();
+    if (a.prof && t == 0) a.prof[(long)blockIdx.x * 4 + 3] = c_epi - c_loop;  // shader-clock cycles of the k-loop
 }

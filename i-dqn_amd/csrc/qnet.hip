@@ -848,17 +848,26 @@ extern "C" int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, fl
 extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const float* dh_all_dev,
                                          int32_t nb_total, int32_t nb_inner, int64_t a3_outer, int64_t a3_head,
                                          int64_t a3_inner, int64_t dh_outer, int64_t dh_head, int64_t dh_inner,
-                                         void* stream) {
-    IDQN_REQUIRE(h && a3_all_dev && dh_all_dev, "idqn_finish_step_factored: null pointer");
-    IDQN_REQUIRE(h->pend_stage == 1, "idqn_finish_step_factored: needs IDQN_F_STOP_BEFORE_DENSE0_WGRAD first");
-    IDQN_REQUIRE(nb_total >= 1 && nb_inner >= 1 && nb_total % nb_inner == 0, "idqn_finish_step_factored: bad block counts");
+                                         uint32_t phases, void* stream) {
+    IDQN_REQUIRE(h && (phases & 3u) && !(phases & ~3u), "idqn_finish_step_factored: phases must be 1, 2 or 3");
     hipStream_t q = (hipStream_t)stream;
-    h->pend_stage = 0; h->pend_B = 0;
-    int rc = launch_dense0_wgrad(h, a3_all_dev, dh_all_dev, nb_total, nb_inner, a3_outer, a3_head, a3_inner, dh_outer,
-                                 dh_head, dh_inner, true, h->pend_profile, q);
-    if (rc) return rc;
-    if ((rc = launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q))) return rc;  // every other leaf, from grad_dev
-    return step_epilogue(h, true, q);
+    int rc;
+    if (phases & IDQN_FACTORED_DENSE0) {
+        IDQN_REQUIRE(a3_all_dev && dh_all_dev, "idqn_finish_step_factored: null pointer");
+        IDQN_REQUIRE(h->pend_stage == 1, "idqn_finish_step_factored: needs IDQN_F_STOP_BEFORE_DENSE0_WGRAD first");
+        IDQN_REQUIRE(nb_total >= 1 && nb_inner >= 1 && nb_total % nb_inner == 0, "idqn_finish_step_factored: bad block counts");
+        h->pend_stage = 3; h->pend_B = 0;
+        if ((rc = launch_dense0_wgrad(h, a3_all_dev, dh_all_dev, nb_total, nb_inner, a3_outer, a3_head, a3_inner, dh_outer,
+                                      dh_head, dh_inner, true, h->pend_profile, q)))
+            return rc;
+    }
+    if (phases & IDQN_FACTORED_REST) {
+        IDQN_REQUIRE(h->pend_stage == 3, "idqn_finish_step_factored: the Dense_0 phase has to come first");
+        h->pend_stage = 0;
+        if ((rc = launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q))) return rc;  // every other leaf, from grad_dev
+        return step_epilogue(h, true, q);
+    }
+    return IDQN_OK;
 }
 
 extern "C" int idqn_set_per_buffers(idqn_handle_t h, const float* weights_dev, float* td_abs_out_dev) {

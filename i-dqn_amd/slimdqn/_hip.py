@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("IDQN_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
 IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24
 F_GRADS_ONLY, F_PROFILE, F_STOP_AFTER_DENSE0, F_STOP_BEFORE_DENSE0_WGRAD = 1, 2, 4, 8
+FACTORED_DENSE0, FACTORED_REST = 1, 2
 E_INVALID, E_HIP, E_RANGE, E_ASSERT = -1, -2, -3, -4
 
 
@@ -46,7 +47,7 @@ SYMBOLS = {
     "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
     "idqn_backward_rest": (C.c_int, [_P, _P]),
     "idqn_export_dense0_factors": (C.c_int, [_P, _P, _P, _P]),
-    "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [_P]),
+    "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [C.c_uint32, _P]),
     "idqn_apply_adam": (C.c_int, [_P, _P]),
     "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
     "sumtree_set_one": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]),

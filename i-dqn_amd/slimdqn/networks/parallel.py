@@ -20,8 +20,8 @@ samples, i.e. of rank <= global batch, far below its 7744 x 512 shape.  Ranks th
 (``a3``: K x 7744 x 32 floats, ``dh``: K x 512 x 32 floats -- 5.3 MB per rank at K=5) instead of all-reducing the
 79.3 MB product, and every rank runs the fused weight-gradient + Adam kernel over the gathered global batch: 4x
 (8 ranks) to 15x (2 ranks) fewer bytes over xGMI, the gradient is never materialised, and Adam stays fused.  The
-gathers run while ``idqn_backward_rest`` computes the conv backward; the 1.6 MB of small leaves (and the K losses)
-are all-reduced as before.  Every rank sums the same blocks in the same order, so replicas stay bit-identical.
+gather runs while ``idqn_backward_rest`` computes the conv backward; the 1.6 MB of small leaves (and the K losses)
+are all-reduced under the fused Dense_0 update, which needs only the gathered factors.  Every rank sums the same blocks in the same order, so replicas stay bit-identical.
 ``IDQN_DP_MODE=allreduce`` selects the all-reduce variants above.
 """
 import os
@@ -53,11 +53,14 @@ def _factored_step(agent, shard, global_batch, group, extra_flags):
                "idqn_export_dense0_factors")
     work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)  # ONE collective for both factors
     _hip.check(lib.idqn_backward_rest(agent._handle, q()), "idqn_backward_rest")  # conv backward, under the gather
-    dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group)  # small leaves + the K losses
+    small = dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group, async_op=True)  # small leaves + K losses
     work.wait()
-    _hip.check(lib.idqn_finish_step_factored(agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]),
-                                             world * nb, nb, n_a3 + n_dh, nb * X, X, n_a3 + n_dh, nb * Y, Y, q()),
-               "idqn_finish_step_factored")
+    args = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), world * nb, nb, n_a3 + n_dh, nb * X, X,
+            n_a3 + n_dh, nb * Y, Y)
+    # the 80 us Dense_0 update needs only the gather: it runs while the small all-reduce is still in flight
+    _hip.check(lib.idqn_finish_step_factored(*args, _hip.FACTORED_DENSE0, q()), "idqn_finish_step_factored")
+    small.wait()
+    _hip.check(lib.idqn_finish_step_factored(*args, _hip.FACTORED_REST, q()), "idqn_finish_step_factored")
     return agent._losses
 
 

@@ -106,14 +106,18 @@ int idqn_backward_rest(idqn_handle_t h, void* stream);
  *   idqn_learn_on_batch(.., IDQN_F_STOP_BEFORE_DENSE0_WGRAD)   forward, head, Dense_0 data gradient
  *   idqn_export_dense0_factors   async copies of this rank's a3 [K][nb][F*32] and dh [K][nb][J*32]
  *   (all-gather both; meanwhile idqn_backward_rest = conv backward; all-reduce the small-leaf gradient region)
- *   idqn_finish_step_factored    fused Dense_0 update from the gathered factors, Adam on every other leaf from
- *                                grad_dev, count += 1, cum_losses += losses.
+ *   idqn_finish_step_factored    phase IDQN_FACTORED_DENSE0: fused Dense_0 update from the gathered factors (needs
+ *                                only the gather, so it can run while the small-leaf all-reduce is still in flight);
+ *                                phase IDQN_FACTORED_REST: Adam on every other leaf from grad_dev, count += 1,
+ *                                cum_losses += losses.  `phases` = either or both (3), Dense_0 first.
  * Block bb of the gathered buffers lives at (bb / nb_inner) * outer + head * head_stride + (bb % nb_inner) * inner
  * (strides in floats); a plain all_gather of the exported buffers gives outer = K*nb*X, head = nb*X, inner = X.   */
 int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, float* dh_out_dev, void* stream);
+#define IDQN_FACTORED_DENSE0 1u
+#define IDQN_FACTORED_REST 2u
 int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const float* dh_all_dev, int32_t nb_total,
                               int32_t nb_inner, int64_t a3_outer, int64_t a3_head, int64_t a3_inner,
-                              int64_t dh_outer, int64_t dh_head, int64_t dh_inner, void* stream);
+                              int64_t dh_outer, int64_t dh_head, int64_t dh_inner, uint32_t phases, void* stream);
 /* Second half of the data-parallel step: Adam from grad_dev, count += 1. */
 int idqn_apply_adam(idqn_handle_t h, void* stream);
 

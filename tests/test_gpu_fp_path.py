@@ -444,7 +444,7 @@ def test_factored_step_sums_blocks_of_several_ranks():
         small += agent._grad_small  # what the all-reduce of the small-leaf region does
     agent._grad_small.copy_(small)
     _hip.check(lib.idqn_finish_step_factored(agent._handle, _hip.ptr(a3_all), _hip.ptr(dh_all), 2, 1, K * X, X, X,
-                                             K * Y, Y, Y, q()), "finish")
+                                             K * Y, Y, Y, _hip.FACTORED_DENSE0 | _hip.FACTORED_REST, q()), "finish")
     st = rec["steps"][0]
     assert np.abs(agent._losses.cpu().numpy() - np.asarray(st["losses"])).max() <= LOSS_ATOL
     flat = agent._flat(agent._online)

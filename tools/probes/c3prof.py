@@ -20,8 +20,9 @@ q = (p - t0) / 100.0  # wall_clock64 ticks at 100 MHz -> microseconds
 print("WG start   us: min %.2f median %.2f max %.2f" % (q[:, 0].min(), np.median(q[:, 0]), q[:, 0].max()))
 print("prologue   us: median %.2f max %.2f" % (np.median(q[:, 1] - q[:, 0]), (q[:, 1] - q[:, 0]).max()))
 print("k-loop     us: median %.2f max %.2f" % (np.median(q[:, 2] - q[:, 1]), (q[:, 2] - q[:, 1]).max()))
-print("epilogue   us: median %.2f max %.2f" % (np.median(q[:, 3] - q[:, 2]), (q[:, 3] - q[:, 2]).max()))
-print("kernel end us: %.2f" % q[:, 3].max())
+cyc = p[:, 3].astype(np.float64)
+loop_us = (p[:, 2] - p[:, 1]) / 100.0
+print("k-loop shader cycles: median %.0f ; cycles per microsecond (= MHz): median %.0f min %.0f max %.0f" % (np.median(cyc), np.median(cyc / loop_us), (cyc / loop_us).min(), (cyc / loop_us).max()))
 order = np.argsort(q[:, 0])
 print("start times of every 50th WG:", np.round(q[order[::50], 0], 1))
 
