@@ -87,18 +87,23 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
     float* x = a.x + ((long)set * a.nb + bb) * a.g.block;
     unsigned short* x3 = a.x3 ? a.x3 + ((long)set * a.nb + bb) * a.g.block * 3 : nullptr;
     const int b = t & 31;
+    // (h, w, c) of this thread's first element by 32-bit division once; its later elements are 8 further on
+    const int E32 = (int)a.E, WC = a.g.W * a.g.C;
+    int e = (int)e0 + (t >> 5);
+    int hh = e / WC, r = e - hh * WC;
+    int w = r / a.g.C, c = r - w * a.g.C;
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
-        int el = pass * 8 + (t >> 5);
-        long e = e0 + el;
-        if (e < a.E) {
-            int c = (int)(e % a.g.C);
-            long hw = e / a.g.C;
-            int w = (int)(hw % a.g.W), h = (int)(hw / a.g.W);
-            long row = ((long)(h + a.g.lo_h) * a.g.Wp + (w + a.g.lo_w)) * a.g.C + c;
+        const int el = pass * 8 + (t >> 5);
+        if (e < E32) {
+            const long row = ((long)(hh + a.g.lo_h) * a.g.Wp + (w + a.g.lo_w)) * a.g.C + c;
             x[row * 32 + b] = tile[el][b];
             if (x3) prep_store3(x3 + row * 96, b, tile[el][b]);
         }
+        e += 8;
+        c += 8;
+        while (c >= a.g.C) { c -= a.g.C; ++w; }
+        while (w >= a.g.W) { w -= a.g.W; ++hh; }
     }
 }
 
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
     const float* p = a.wbase[slot / a.nb];
     const float* part = a.part + (long)slot * a.NS * a.J * 32;
     float* hb = a.hbuf + (long)slot * a.J * 32;
-    // 4 rows per thread; the split partials are loaded 4 x 4 at a time (independent loads in flight) and
+    // 4 rows per thread; the split partials are loaded 8 x 4 at a time (independent loads in flight) and
     // added in fixed split order, so the sum is reproducible
     float sv[4];
     const float* pr = part + (long)(jc * 32 + jj) * 32 + b;
@@ -366,20 +371,30 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) sv[i] = p[a.b0_off + jc * 32 + jj + 8 * i];
     int sp = 0;
-    for (; sp + 4 <= a.NS; sp += 4) {
-        float v[4][4];
+    for (; sp + 8 <= a.NS; sp += 8) {
+        float v[8][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[u][i] = pr[(sp + u) * sstride + i * 256];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
     }
-    for (; sp < a.NS; ++sp)
+    if (sp < a.NS) {  // tail of up to 7 splits: all loads issued together (clamped), added in split order
+        float v[7][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sv[i] += pr[sp * sstride + i * 256];
+        for (int u = 0; u < 7; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = pr[min(sp + u, a.NS - 1) * sstride + i * 256];
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+            if (sp + u < a.NS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int jl = jj + 8 * i, j = jc * 32 + jl;
@@ -997,14 +1012,19 @@ struct AdamArgs {
 };
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int k = blockIdx.y;
+    // the grid covers [begin, end) minus the skipped range (the fused kernel's Dense_0/kernel: 98 % of the head),
+    // compacted -- not one mostly-empty workgroup per 1024 skipped elements
     long e = a.begin + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= a.skip_begin) e += a.skip_end - a.skip_begin;
     if (e >= a.end) return;
-    if (e >= a.skip_begin && e < a.skip_end) return;
     const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const long o = (long)k * a.P + e;
     const long w0n = a.w0_end - a.w0_begin;
     const long go = e < a.w0_begin ? (long)k * a.gP + e
                     : (e < a.w0_end ? a.g_w0_base + (long)k * w0n + (e - a.w0_begin) : (long)k * a.gP + e - w0n);
+    float4 th = *reinterpret_cast<float4*>(a.theta + o);  // independent of the gradient assembly below: issue first
+    float4 m = *reinterpret_cast<float4*>(a.mu + o);
+    float4 v = *reinterpret_cast<float4*>(a.nu + o);
     float4 g = *reinterpret_cast<const float4*>(a.grad + go);
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
@@ -1018,25 +1038,23 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
             const long pstride = (long)a.K * sg.slab_stride;
             g = make_float4(0.f, 0.f, 0.f, 0.f);
             int pc = 0;
-            for (; pc + 4 <= sg.npc; pc += 4) {  // 4 independent loads in flight, added in chunk order
-                const float4 x0 = *reinterpret_cast<const float4*>(sp + (pc + 0) * pstride);
-                const float4 x1 = *reinterpret_cast<const float4*>(sp + (pc + 1) * pstride);
-                const float4 x2 = *reinterpret_cast<const float4*>(sp + (pc + 2) * pstride);
-                const float4 x3 = *reinterpret_cast<const float4*>(sp + (pc + 3) * pstride);
-                g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
-                g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
-                g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
-                g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
+            for (; pc + 8 <= sg.npc; pc += 8) {  // 8 independent loads in flight, added in chunk order
+                float4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(sp + (pc + u) * pstride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
             }
-            for (; pc < sg.npc; ++pc) {
-                const float4 x = *reinterpret_cast<const float4*>(sp + pc * pstride);
-                g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+            if (pc < sg.npc) {  // tail of up to 7 chunks: every load issued, out-of-range ones re-read the last chunk
+                float4 x[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) x[u] = *reinterpret_cast<const float4*>(sp + min(pc + u, sg.npc - 1) * pstride);
+#pragma unroll
+                for (int u = 0; u < 7; ++u)
+                    if (pc + u < sg.npc) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
             }
         }
     }
-    float4 th = *reinterpret_cast<float4*>(a.theta + o);
-    float4 m = *reinterpret_cast<float4*>(a.mu + o);
-    float4 v = *reinterpret_cast<float4*>(a.nu + o);
     adam_elem(a.ad, bc1, bc2, g.x, th.x, m.x, v.x);
     adam_elem(a.ad, bc1, bc2, g.y, th.y, m.y, v.y);
     adam_elem(a.ad, bc1, bc2, g.z, th.z, m.z, v.z);

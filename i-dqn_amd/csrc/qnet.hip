@@ -506,7 +506,10 @@ int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e
     a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
     a.gP = h->gP; a.w0_begin = h->g_w0_begin; a.w0_end = h->g_w0_end; a.g_w0_base = h->g_w0_base;
     for (int i = 0; i < 3; ++i) a.seg[i] = h->segs[i];
-    hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
+    IDQN_REQUIRE(skip_b == skip_e || (skip_b >= begin && skip_e <= end && skip_b % 4 == 0 && skip_e % 4 == 0),
+                 "launch_adam: bad skip range");
+    if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
+    hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin - (skip_e - skip_b)) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
