@@ -457,16 +457,27 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f, loss_acc = 0.f;
     for (int bb = 0; bb < a.nb; ++bb) {
         const long so = (long)k * a.nb + bb, st = (long)(a.K + k) * a.nb + bb;
+        // this block's hidden rows do not depend on the q reduction below: have them in flight meanwhile
+        const float* hb = a.hbuf + so * a.J * 32 + (long)jc * 32 * 32;
+        float hreg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hreg[i] = hb[(jj + 8 * i) * 32 + b];
         for (int e = t; e < a.A * 32; e += 256) {
             const int ac = e >> 5;
             float vo = 0.f, vt = 0.f;
             const float* qo_ = a.qpart + so * NJC * 1024 + e;
             const float* qt_ = a.qpart + st * NJC * 1024 + e;
-            for (int c = 0; c < NJC; c += 4) {  // NJC = J / 32 is a multiple of 4 (J is a multiple of 128)
-                float x0 = qo_[(c + 0) * 1024], x1 = qo_[(c + 1) * 1024], x2 = qo_[(c + 2) * 1024], x3 = qo_[(c + 3) * 1024];
-                float y0 = qt_[(c + 0) * 1024], y1 = qt_[(c + 1) * 1024], y2 = qt_[(c + 2) * 1024], y3 = qt_[(c + 3) * 1024];
-                vo = (((vo + x0) + x1) + x2) + x3;
-                vt = (((vt + y0) + y1) + y2) + y3;
+            for (int c = 0; c < NJC; c += 8) {  // NJC = J / 32 is a multiple of 4; 8 (or the last 4) partials of each net at once
+                float x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int cc = min(c + u, NJC - 1);
+                    x[u] = qo_[cc * 1024];
+                    y[u] = qt_[cc * 1024];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + u < NJC) { vo += x[u]; vt += y[u]; }
             }
             vo += po[a.b1_off + ac];
             vt += pt[a.b1_off + ac];
@@ -502,9 +513,8 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
             for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
             if (lane == 0) red[0] = sq;
         }
-        const float* hb = a.hbuf + so * a.J * 32 + (long)jc * 32 * 32;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hs[jj + 8 * i][b] = hb[(jj + 8 * i) * 32 + b];
+        for (int i = 0; i < 4; ++i) hs[jj + 8 * i][b] = hreg[i];
         __syncthreads();
         loss_acc += red[0];
         float* dh = a.dh + so * a.J * 32 + (long)jc * 32 * 32;
