@@ -937,6 +937,29 @@ extern "C" int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const
     return IDQN_OK;
 }
 
+// argmax over the actions of each row, first maximum on ties (jnp.argmax, idqn.py:131)
+__global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int best = 0;
+    float bv = q[(long)i * A];
+    for (int ac = 1; ac < A; ++ac) {
+        const float v = q[(long)i * A + ac];
+        if (v > bv) { bv = v; best = ac; }
+    }
+    out[i] = best;
+}
+
+extern "C" int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                                float* q_out_dev, int32_t* action_out_dev, void* stream) {
+    IDQN_REQUIRE(action_out_dev, "idqn_best_action: null pointer");
+    int rc = idqn_q_values(h, which, head, states_dev, n, q_out_dev, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, (hipStream_t)stream, q_out_dev, n, h->cfg.n_actions, action_out_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
 extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {
     IDQN_REQUIRE(h && name && ptr_dev && nbytes, "idqn_debug_buffer: null pointer");
     for (auto& e : h->dbg)

@@ -57,6 +57,7 @@ SYMBOLS = {
     "idqn_target_update": (C.c_int, [_P, _P]),
     "idqn_target_sync": (C.c_int, [_P, _P]),
     "idqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
+    "idqn_best_action": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     "idqn_debug_buffer": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "idqn_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p]),
     "sumtree_set": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),

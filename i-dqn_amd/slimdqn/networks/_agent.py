@@ -165,6 +165,19 @@ class DeviceAgent:
                                             _hip.current_stream()), "idqn_q_values")
         return self._q_out[:n]
 
+    def _best_action(self, which, head, state):
+        """Greedy action (device int32 scalar, first maximum on ties) of one head for one state: one C call."""
+        dt = torch.uint8 if self._arch == "cnn" else torch.float32
+        s = self._dev(state, dt)
+        assert s.numel() == int(np.prod(self._obs)), "best_action takes a single state"
+        self._ensure_handle(32)
+        self._keep_q = s
+        if not hasattr(self, "_action_out"):
+            self._action_out = torch.zeros(32, dtype=torch.int32, device="cuda")
+        _hip.check(_hip.lib().idqn_best_action(self._handle, int(which), int(head), _hip.ptr(s), 1, _hip.ptr(self._q_out),
+                                               _hip.ptr(self._action_out), _hip.current_stream()), "idqn_best_action")
+        return self._action_out[0]
+
     def _debug(self, name):
         """Internal activation buffer as a flat float32 device tensor (tests only)."""
         p, nbytes = C.c_void_p(), C.c_int64()

@@ -47,4 +47,5 @@ class DQN(DeviceAgent):
 
     def best_action(self, params, state, **kwargs):
         """dqn.py:88-92."""
-        return self.q_values(params, state)[0].argmax()
+        assert params is self.params or params is self.target_params
+        return self._best_action(0 if params is self.params else 1, 0, state)

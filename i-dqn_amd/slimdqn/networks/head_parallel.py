@@ -103,7 +103,8 @@ class HeadShardedIDQN(iDQN):
         owner, local = divmod(idx, self._n_local)
         action = torch.zeros(1, dtype=torch.int64, device=self._cum.device)
         if owner == self._rank:
-            action[0] = self.q_values(params, state, local)[0].argmax()
+            assert params is self.params or params is self.target_params
+            action[0] = self._best_action(0 if params is self.params else 1, local, state)
         dist.broadcast(action, src=dist.get_global_rank(self._group, owner) if self._group is not None else owner,
                        group=self._group)
         return action[0]

@@ -82,4 +82,5 @@ class iDQN(DeviceAgent):
     def best_action(self, params, state, key):
         """Greedy action of a uniformly drawn head; the head comes from the SAME key (idqn.py:126-131)."""
         idx_params = prng.randint(key, 0, self.n_networks)
-        return self.q_values(params, state, idx_params)[0].argmax()
+        assert params is self.params or params is self.target_params
+        return self._best_action(0 if params is self.params else 1, idx_params, state)

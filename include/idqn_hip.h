@@ -131,6 +131,10 @@ int idqn_target_sync(idqn_handle_t h, void* stream);
  * states; which = 0 online / 1 target.  q_out_dev: float32 [n][A].                                 */
 int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
                   float* q_out_dev, void* stream);
+/* `network.apply(params[idx], state)` followed by `jnp.argmax` (idqn.py:126-131, dqn.py:88-92): the greedy action of
+ * each of the n states (first maximum on ties) as int32 in action_out_dev [n]; the Q-values are left in q_out_dev.   */
+int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                     float* q_out_dev, int32_t* action_out_dev, void* stream);
 
 /* Test / debug access to internal activation buffers by name (device pointer + byte size).        */
 int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes);

@@ -213,6 +213,13 @@ def test_q_values_and_formula_known_answers():
     head = prng.randint(key, 0, K)
     best = int(agent.best_action(agent.params, s[0], key).item())
     assert best == int(np.argmax(Q.forward(Q.head(p, head), s[:1], arch)[0]))
+    # ties: with a zero output layer every action has the same value and jnp.argmax returns the first
+    flat = {n: v.copy() for n, v in p.items()}
+    last = max(int(n.split("/")[0].split("_")[1]) for n in flat if n.startswith("Dense_"))
+    flat[f"Dense_{last}/kernel"][:] = 0.0
+    flat[f"Dense_{last}/bias"][:] = 0.25
+    agent._load_flat(agent._online, flat)
+    assert int(agent.best_action(agent.params, s[0], key).item()) == 0
 
 
 def test_shift_sync_and_log_semantics():
