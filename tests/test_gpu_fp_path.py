@@ -304,6 +304,25 @@ def test_entry_points_train_end_to_end(env_name, tmp_path):
     assert set(model) == {"params"} and all(np.isfinite(v).all() for m in model["params"].values() for v in m.values())
 
 
+@pytest.mark.parametrize("env_name", ["lunar_lander", "atari"])
+def test_dqn_entry_points_run_as_scripts(env_name, tmp_path):
+    """What the reference's own integration tests do (tests/test_lunar_lander.py, tests/test_atari.py:15-59): run
+    `python experiments/<env>/dqn.py` with tiny settings in a subprocess and require exit code 0."""
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "i-dqn_amd")
+    argv = ["-en", "_test_script", "-s", "1", "-dw", "-rbc", "100", "-bs", "32", "-n", "1", "-gamma", "0.99", "-lr", "1e-4",
+            "-horizon", "10", "-ne", "1", "-ntspe", "60", "-utd", "1", "-nis", "40", "-ee", "0.01", "-ed", "10",
+            "-tuf", "10"]
+    argv += ["-f", "32", "64", "64", "128", "-at", "cnn"] if env_name == "atari" else ["-f", "25", "25", "-at", "fc"]
+    code = ("import sys; sys.path.insert(0, %r); from experiments.%s.dqn import run; run(%r, save_root=%r)"
+            % (root, env_name, argv, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert os.path.exists(os.path.join(str(tmp_path), "_test_script", "dqn", "models", "1"))
+
+
 @pytest.mark.parametrize("arch,obs,feats,A,K,B", [
     ("cnn", (20, 20, 4), [32, 32, 32, 128], 5, 2, 20),     # ragged: one partly filled 32-sample block
     ("cnn", (20, 20, 4), [32, 64, 32, 256], 3, 3, 50),     # ragged second block, mixed channel widths, J = 256
