@@ -736,6 +736,9 @@ struct DenseWgradArgs {
 // (16 B per lane), the gradient comes from LDS -- exactly the access pattern of the plain Adam kernel, which
 // reaches 6.9 TB/s on MI355X.  The first version kept the tile in accumulators and ran Adam from the MFMA
 // layout at 2 waves/SIMD (5.3 TB/s); this one needs ~100 registers and 32 KB of LDS (4-5 workgroups per CU).
+#ifndef D0W_DEPTH
+#define D0W_DEPTH 4  // row groups of theta / m / v in flight per thread in the fused kernel's streaming phase
+#endif
 template <bool FUSE_ADAM, int NQ>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
@@ -751,11 +754,18 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
     const int prow = wave * (64 / LPR) + lane / LPR, pcol = (lane % LPR) * 4;
     const long o0 = base + (long)prow * a.J + pcol;
-    float4 th[2], mm[2], vv[2];
-    if (FUSE_ADAM) {  // the rows of iteration 0 are requested before the MFMA phase
-        th[0] = *reinterpret_cast<const float4*>(a.theta + o0);
-        mm[0] = *reinterpret_cast<const float4*>(a.mu + o0);
-        vv[0] = *reinterpret_cast<const float4*>(a.nu + o0);
+    // phase-2 state runs DEPTH row groups ahead (a ring of named-index registers): the rows of the first DEPTH
+    // iterations are requested before the MFMA phase, so the workgroup keeps streaming while it computes its tile
+    constexpr int DEPTH = D0W_DEPTH;
+    float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
+    if (FUSE_ADAM) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const long on = o0 + (long)(RPI * d) * a.J;
+            th[d] = *reinterpret_cast<const float4*>(a.theta + on);
+            mm[d] = *reinterpret_cast<const float4*>(a.mu + on);
+            vv[d] = *reinterpret_cast<const float4*>(a.nu + on);
+        }
     }
     f32x16 acc[NQ];
 #pragma unroll
@@ -790,15 +800,15 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
         const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int s = i & 1;
-            if (i + 1 < NIT) {  // next rows' state is requested before this row's (may-alias) stores
-                const long on = o0 + (long)(RPI * (i + 1)) * a.J;
-                th[s ^ 1] = *reinterpret_cast<const float4*>(a.theta + on);
-                mm[s ^ 1] = *reinterpret_cast<const float4*>(a.mu + on);
-                vv[s ^ 1] = *reinterpret_cast<const float4*>(a.nu + on);
-            }
+            const int s = i % DEPTH;
             const float4 g = *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
             float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
+            if (i + DEPTH < NIT) {  // the slot just read is re-filled DEPTH row groups ahead, before the (may-alias) stores
+                const long on = o0 + (long)(RPI * (i + DEPTH)) * a.J;
+                th[s] = *reinterpret_cast<const float4*>(a.theta + on);
+                mm[s] = *reinterpret_cast<const float4*>(a.mu + on);
+                vv[s] = *reinterpret_cast<const float4*>(a.nu + on);
+            }
             adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
             adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
             adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
