@@ -324,18 +324,26 @@ int cnn_setup(idqn_handle_s* h) {
     for (int i = 0; i < 3; ++i) {
         const ConvL& cl = h->conv[i];
         int npos = cl.OH * cl.OW;
-        // Grid balance: the launch has K * taps * npc workgroups of equal work and a CU runs them at MFMA
-        // speed, so pick the chunk size (4..32 positions) whose workgroup count best fills whole multiples of
-        // the 256 CUs (360 workgroups = 1.4 per CU ran at 70 % balance).
+        // Chunk size = positions per workgroup.  The launch has K * taps * npc equal workgroups, all resident at once,
+        // so its time is (workgroups on the busiest CU) x (positions per workgroup + a fixed cost of ~2 positions for
+        // the prologue / slab epilogue); a lone workgroup on a CU has nobody to hide its latencies behind (x 1.1).
+        // Measured on the Atari shapes (tools/gpu_ppc.sh): Conv_0 19 -> 38 positions 31.4 -> 28.5 us, Conv_1 16 -> 41
+        // positions 30.3 -> 26.0 us, Conv_2 stays at 11 (21.4 us); fewer chunks also mean fewer slabs to sum.
         {
             const int taps = (i == 0) ? cl.K : cl.K * cl.K;
-            double best = 1e9;
-            for (int ppc = 4; ppc <= 32; ++ppc) {
-                const int npc = (npos + ppc - 1) / ppc;
-                const long wgs = (long)K * taps * npc;
-                const double waste = (double)((wgs + 255) / 256 * 256) / (double)wgs + 0.002 * npc;  // mild bias to fewer slabs
-                if (waste < best) { best = waste; h->pos_per_chunk[i] = ppc; }
+            double best = 1e30;
+            for (int npc = 1; npc <= npos; ++npc) {
+                const int ppc = (npos + npc - 1) / npc;  // balanced chunks
+                if (ppc < 4 && npc > 1) break;
+                const long wgs = (long)K * taps * ((npos + ppc - 1) / ppc);
+                const double cost = (double)((wgs + 255) / 256) * (ppc + 2.0) * (wgs <= 256 ? 1.1 : 1.0);
+                if (cost < best) { best = cost; h->pos_per_chunk[i] = ppc; }
             }
+        }
+        {
+            char nm[16];
+            snprintf(nm, sizeof nm, "IDQN_PPC%d", i);  // experiment knob: positions per weight-gradient chunk
+            if (const char* e = getenv(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
         }
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
