@@ -164,7 +164,8 @@ struct idqn_handle_s {
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
     long wt_stride[3] = {0, 0, 0};
     // bf16x3 conv path (conv3_kernels.h): packed weight planes of every training net and the 3-plane dout buffers
-    bool conv3 = false;
+    bool conv3 = false;      // forward convs on the bf16x3 path
+    bool conv3_bwd = false;  // ... and the conv data gradients too
     unsigned short *w3 = nullptr, *da3_3 = nullptr, *da2_3 = nullptr;
     float* c3prof = nullptr;  // debug: phase timestamps of the Conv_2 forward launch (IDQN_CONV_PROF=1)
     long w3_stride = 0, w3_fwd[3] = {0, 0, 0}, w3_dg[3] = {0, 0, 0};
@@ -401,8 +402,10 @@ int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
 // bf16x3 path: the data-gradient kernels, then every kernel of the 2K training nets as packed bf16 planes
 int build_weights3(idqn_handle_s* h, hipStream_t q) {
     const int K = h->cfg.n_heads;
-    int rc = build_dgrad_weights(h, q);
-    if (rc) return rc;
+    if (h->conv3_bwd) {
+        int rc = build_dgrad_weights(h, q);
+        if (rc) return rc;
+    }
     W3PackArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.wbase = h->train.wbase; pa.w3 = h->w3; pa.w3_stride = h->w3_stride;
@@ -416,7 +419,7 @@ int build_weights3(idqn_handle_s* h, hipStream_t q) {
         j.KH = l.K; j.KWCI = l.K * l.CI; j.CO = l.CO;
         maxe = std::max(maxe, (long)j.KH * j.KWCI * j.CO);
     }
-    for (int i = 1; i < 3; ++i) {
+    for (int i = 1; i < 3 && h->conv3_bwd; ++i) {
         const ConvL& l = h->conv[i];
         const int KHs = l.K / l.S;
         const long per_var = (long)KHs * KHs * l.CO * l.CI;
@@ -583,7 +586,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
-    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3 ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3_bwd ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
     dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
     dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
     hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
@@ -617,13 +620,13 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     float* dins[3] = {nullptr, h->da1, h->da2};
     const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
     // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
-    if (!h->conv3) {  // (the bf16x3 path built and packed them before the forward pass)
+    if (!h->conv3_bwd) {  // (the bf16x3 data-gradient path built and packed them before the forward pass)
         int rcb = build_dgrad_weights(h, q);
         if (rcb) return rcb;
     }
     const unsigned short* douts3[3] = {nullptr, h->da2_3, h->da3_3};
     unsigned short* dins3[3] = {nullptr, nullptr, h->da2_3};
-    for (int i = 2; i >= 1 && h->conv3; --i) {
+    for (int i = 2; i >= 1 && h->conv3_bwd; --i) {
         const ConvL& l = *cl[i];
         const int KHs = l.K / l.S, nvar = l.S * l.S;
         Conv3Args a;
@@ -657,7 +660,7 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
         else
             hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
     }
-    for (int i = 2; i >= 1 && !h->conv3; --i) {
+    for (int i = 2; i >= 1 && !h->conv3_bwd; --i) {
         const ConvL& l = *cl[i];
         const int KHs = l.K / l.S, nvar = l.S * l.S;
         ConvFwdArgs a;
@@ -778,7 +781,8 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
     h->g_w0_base = (long)cfg->n_heads * h->gP + 64;
     {  // conv arithmetic: f32 MFMA, or f32-accurate products on the bf16 matrix cores (conv3_kernels.h)
         const char* mode = getenv("IDQN_CONV");
-        h->conv3 = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
+        h->conv3_bwd = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
+        h->conv3 = h->conv3_bwd || (cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3-forward") == 0);
     }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
     if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);

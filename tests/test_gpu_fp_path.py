@@ -61,10 +61,11 @@ def _relerr(got, want):
     return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "bf16x3-forward"])
 def conv_mode(request, monkeypatch):
     """Conv arithmetic of the agents a test creates: the f32 MFMA kernels (default) or the f32-accurate products on
-    the bf16 matrix cores (csrc/conv3_kernels.h); read by idqn_create from IDQN_CONV."""
+    the bf16 matrix cores (csrc/conv3_kernels.h) for every conv forward and data gradient, or for the forwards only;
+    read by idqn_create from IDQN_CONV."""
     monkeypatch.setenv("IDQN_CONV", request.param)
     return request.param
 
