@@ -627,22 +627,24 @@ struct DenseDgradArgs {
     ActGeom g;                 // geometry of da3
 };
 
-__global__ __launch_bounds__(256) void k_dense0_dgrad(DenseDgradArgs a) {
-    // workgroup = 4 consecutive f tiles of one (head, batch block).  dh (J x 32, <= 64 KB) is staged once
-    // by LDS-DMA and shared by the 4 waves (B operand: conflict-free ds_read_b32); the W rows (A operand,
+template <int WAVES>  // f tiles (= waves) per workgroup: 4, or 3 when that fills the chip more evenly
+__global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
+    // workgroup = WAVES consecutive f tiles of one (head, batch block).  dh (J x 32, <= 64 KB) is staged once
+    // by LDS-DMA and shared by the waves (B operand: conflict-free ds_read_b32); the W rows (A operand,
     // 16 floats per lane and chunk) stream from HBM with register double buffering.
     extern __shared__ __attribute__((aligned(16))) float dlds[];  // [J][32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    const int n_wg_ft = (a.n_ft + 3) / 4;
+    const int n_wg_ft = (a.n_ft + WAVES - 1) / WAVES;
     int item = xcd_contiguous_id();  // an XCD keeps to (mostly) one head: its dh stays in that L2
     const int fg = item % n_wg_ft;
     item /= n_wg_ft;
     const int bb = item % a.nb;
     const int k = item / a.nb;
     const float* dsrc = a.dh + ((long)k * a.nb + bb) * a.J * 32;
-    for (int o = 0; o < a.J * 32; o += 1024) glds16(dsrc + o + t * 4, &dlds[o + wave * 256]);
-    const int ft = min(fg * 4 + wave, a.n_ft - 1);
-    const bool live = fg * 4 + wave < a.n_ft;
+    for (int o = 0; o < a.J * 32; o += 256 * WAVES)
+        if (o + wave * 256 < a.J * 32) glds16(dsrc + o + t * 4, &dlds[o + wave * 256]);  // wave-uniform guard
+    const int ft = min(fg * WAVES + wave, a.n_ft - 1);
+    const bool live = fg * WAVES + wave < a.n_ft;
     const int f0 = ft * 32;
     const float* W = a.wbase[k] + a.w_off + (long)(f0 + bl) * a.J + 16 * h;
     const float* D = dlds + (16 * h) * 32 + bl;

@@ -355,7 +355,8 @@ int cnn_setup(idqn_handle_s* h) {
     // k_head_q needs > 64 KB of dynamic LDS at J = 512
     h->head_lds = (h->J * 33 + 32 * 32 + 4 * 32) * 4;
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head_q, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
-    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
+    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
+    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
     h->dominant = "k_dense0_wgrad";
     return IDQN_OK;
 }
@@ -588,8 +589,17 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     DenseDgradArgs dd;
     dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3_bwd ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
     dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
-    dd.n_items = (long)K * nb * cdiv(dd.n_ft, 4);  // workgroups
-    hipLaunchKernelGGL(k_dense0_dgrad, dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+    {  // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
+        const long wg4 = (long)K * nb * cdiv(dd.n_ft, 4), wg3 = (long)K * nb * cdiv(dd.n_ft, 3);
+        const long busy4 = cdiv(wg4, 256) * 4, busy3 = wg3 <= 512 ? cdiv(wg3, 256) * 3 : 1 << 30;
+        if (busy3 < busy4) {
+            dd.n_items = wg3;
+            hipLaunchKernelGGL((k_dense0_dgrad<3>), dim3((unsigned)dd.n_items), dim3(192), h->J * 32 * 4, q, dd);
+        } else {
+            dd.n_items = wg4;
+            hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+        }
+    }
     if (stop_before_dense0_wgrad) {
         h->pend_B = B; h->pend_stage = 1; h->pend_profile = profile;
         IDQN_HIP_CHECK(hipGetLastError());
