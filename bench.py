@@ -118,6 +118,20 @@ def main():
     from collections import namedtuple
 
     from slimdqn import _hip
+
+    # The extension normally travels prebuilt (graft build()); if this checkout has none, local rank 0 compiles it
+    # (hipcc, ~1 min) before anything touches the GPU and the other ranks wait for the file.  No CPU path exists.
+    if not os.path.exists(_hip.LIB_PATH):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(_hip.LIB_PATH):
+                    break
+                time.sleep(1.0)
+            time.sleep(2.0)  # let the linker finish writing
     from slimdqn.networks.idqn import iDQN
     from slimdqn.networks.parallel import data_parallel_step
 
