@@ -14,3 +14,16 @@ for p in (ROOT, os.path.join(ROOT, "i-dqn_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """A checkout that arrives without the built extension (it is git-ignored) compiles it once, up front: the ABI
+    test and every GPU test load it, and there is no CPU path to fall back to.  A failed build fails those tests."""
+    lib = os.path.join(ROOT, "i-dqn_amd", "libidqn_hip.so")
+    if not os.path.exists(lib) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        try:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        except Exception as e:  # the tests that need the library will say what is missing
+            print(f"[conftest] building the HIP extension failed: {e}", file=sys.stderr)
