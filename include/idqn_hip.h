@@ -72,7 +72,10 @@ typedef struct idqn_handle_s* idqn_handle_t;
 /* The caller (PyTorch-ROCm tensors, storage only) owns the arenas; the handle owns activations
  * and scratch.  count: optax step counter per head (int32, idqn.py:53); losses: per-head loss of
  * the last step (idqn.py:109); cum_losses: f64 running sum == `cumulated_losses += losses`
- * (idqn.py:72) kept on the device so that no per-step host sync is needed.                        */
+ * (idqn.py:72) kept on the device so that no per-step host sync is needed.
+ * Environment: IDQN_CONV = "bf16x3" | "bf16x3-forward" selects, at creation, the conv arithmetic that gets
+ * f32-accurate products out of the bf16 matrix cores (exact three-way operand splits, csrc/conv3_kernels.h) for all
+ * conv forwards and data gradients, or for the forwards only; unset = v_mfma_f32 everywhere.                       */
 int idqn_create(const idqn_config_t* cfg, float* online_dev, float* target_dev, float* mu_dev, float* nu_dev,
                 float* grad_dev, int32_t* count_dev, float* losses_dev, double* cum_losses_dev,
                 idqn_handle_t* out);
