@@ -742,11 +742,9 @@ struct DenseWgradArgs {
 #define D0W_DEPTH 4  // row groups of theta / m / v in flight per thread in the fused kernel's streaming phase
 #endif
 template <bool FUSE_ADAM, int NQ>  // column tile JT = 128 * NQ (256 when the dense width allows it)
-__global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
+__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
-    __shared__ __attribute__((aligned(16))) float gs[32 * JT];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    int item = blockIdx.x;
     const int jt = item % a.n_jt;
     item /= a.n_jt;
     const int ft = item % a.n_ft;
@@ -828,6 +826,11 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
                 *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
 }
+template <bool FUSE_ADAM, int NQ>
+__global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float gs[32 * 128 * NQ];
+    dense0_wgrad_body<FUSE_ADAM, NQ>(a, blockIdx.x, gs);
+}
 
 // --------------------------------------------------------------------------------------------
 // conv data gradient (+ ReLU mask of the layer below): NOT a kernel of its own.
@@ -861,16 +864,14 @@ struct ConvWgradArgs {
 // lanes of a ds_read_b128 group hit 16 distinct 4-bank slots (36 r mod 64 = 4 (9 r mod 16)) -- conflict-free.
 // The 4 waves are (tile pair) x (position slot): <2,2> = 4 tile pairs x 1 position, <1,2> = 2 x 2, <1,1> = 1 x 4.
 template <int NIT, int NOT>
-__global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const ConvWgradArgs& a, int item /* XCD-contiguous */, float* lds) {
     constexpr int NTP = NIT * NOT, PS = 4 / NTP, RPS = (NIT + NOT) * 32, ROWS = PS * RPS, NLD = ROWS / 32;
-    constexpr int LDR = 36;  // padded row stride (floats)
+    constexpr int LDR = 36;  // padded row stride (floats); lds: 2 * ROWS * LDR floats
     static_assert(NTP == 1 || NTP == 2 || NTP == 4, "4 waves = tile pairs x position slots");
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * LDR];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     // workgroup = (head, chunk of output positions, kh, kw) with the TAP fastest, on an XCD-contiguous index:
     // the KH*KW workgroups that re-read one chunk's rows run back to back on one XCD (its L2 serves the re-reads;
     // with the taps spread over all XCDs every L2 fetched every row: ~9x the traffic, 1.4 us per 16 KB round)
-    int item = xcd_contiguous_id();
     const int kw = item % a.KWe;
     item /= a.KWe;
     const int kh = item % a.KH;
@@ -980,6 +981,34 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
         const long wsize = (long)a.KH * a.KWe * a.CIe * a.CO;
         const float sb = bsum + __shfl_xor(bsum, 32);
         if (h == 0) S[wsize + ot * 32 + bl] = sb;
+    }
+}
+template <int NIT, int NOT>
+__global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36];
+    conv_wgrad_body<NIT, NOT>(a, xcd_contiguous_id(), lds);
+}
+
+// ---- experiment: the HBM-bound fused Dense_0 update and the MFMA-bound Conv_2 weight gradient in ONE launch ----
+// Both only need what the head / Dense_0 data gradient produced; they stress different parts of the chip, and a
+// single grid mixes their workgroups on every CU without the cross-queue synchronisation two streams cost.
+// Workgroup b is a conv workgroup when b % period == period - 1 (while any are left), else the next Dense_0 one.
+template <int NQ, int NIT, int NOT>
+__global__ __launch_bounds__(256) void k_mix_dense0_convw(DenseWgradArgs a, ConvWgradArgs c, int period) {
+    constexpr int LA = 32 * 128 * NQ, LC = 2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36;
+    __shared__ __attribute__((aligned(16))) float smem[LA > LC ? LA : LC];
+    // conv slots sit at b = period - 1, 2 period - 1, ... until the n_c conv workgroups are placed (the host picks
+    // period <= (n_a + n_c) / n_c, so they all fit); floor(b / period) slots lie before block b
+    const int b = blockIdx.x, n_c = (int)c.n_items;
+    const int slots_before = b / period;
+    if ((b % period) == period - 1 && slots_before < n_c) {
+        // XCD-contiguous conv index: consecutive slots land on consecutive XCDs, like consecutive block ids do
+        const int q = n_c >> 3, r = n_c & 7, x = slots_before & 7;
+        const int item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (slots_before >> 3);
+        conv_wgrad_body<NIT, NOT>(c, item, smem);
+    } else {
+        const int item = b - min(n_c, slots_before);
+        dense0_wgrad_body<true, NQ>(a, item, smem);
     }
 }
 

@@ -186,6 +186,7 @@ struct idqn_handle_s {
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
+    bool mix = false, mix_done = false;  // experiment (IDQN_MIX=1): Conv_2 weight gradient inside the fused Dense_0 launch
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
     int pend_B = 0;  // batch of a backward stopped after Dense_0 (idqn_backward_rest resumes it); 0 = none
@@ -528,12 +529,32 @@ int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e
     return IDQN_OK;
 }
 
+// arguments of the weight-gradient launch of conv layer i (shared by the plain and the mixed launch)
+ConvWgradArgs make_wgrad_args(idqn_handle_s* h, int i, int nb) {
+    NetSet& s = h->train;
+    const ConvL& l = h->conv[i];
+    const float* acts_in[3] = {s.x, s.a1, s.a2};
+    const float* douts[3] = {h->da1, h->da2, h->da3};
+    const ActGeom* gact[3] = {&h->gx, &h->ga1, &h->ga2};
+    const ActGeom* gdo[3] = {&h->gda1, &h->gda2, &h->gda3};
+    ConvWgradArgs a;
+    a.in = acts_in[i]; a.dout = douts[i]; a.slab = h->slab + h->slab_off[i];
+    a.in_net_stride = (i == 0) ? 0 : (long)nb * gact[i]->block;
+    a.slab_stride = h->slab_stride[i];
+    a.K = h->cfg.n_heads; a.nb = nb; a.npc = h->npc[i]; a.KH = l.K; a.S = l.S; a.CO = l.CO;
+    a.OH = l.OH; a.OW = l.OW; a.pos_per_chunk = h->pos_per_chunk[i];
+    a.gin = *gact[i]; a.gd = *gdo[i]; a.in_C = l.CI;
+    if (i == 0) { a.KWe = 1; a.CIe = l.K * l.CI; } else { a.KWe = l.K; a.CIe = l.CI; }
+    a.n_items = (long)a.K * a.KH * a.KWe * a.npc;  // workgroups
+    return a;
+}
+
 int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
 
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
 int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
                         long a3_head, long a3_inner, long dh_outer, long dh_head, long dh_inner, bool fuse_adam,
-                        bool profile, hipStream_t q) {
+                        bool profile, hipStream_t q, bool allow_mix = false) {
     const int K = h->cfg.n_heads;
     DenseWgradArgs dw;
     dw.a3 = a3; dw.dh = dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
@@ -553,7 +574,19 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    h->mix_done = false;
+    if (fuse_adam && nq == 2 && h->mix && allow_mix && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
+        ConvWgradArgs cw = make_wgrad_args(h, 2, nb_total);
+        const long n_all = dw.n_items + cw.n_items;
+        int period = (int)(n_all / cw.n_items);
+        if (period % 2 == 0) --period;  // odd: consecutive conv slots then visit all 8 XCDs
+        if (period >= 3) {
+            hipExtLaunchKernelGGL((k_mix_dense0_convw<2, 2, 2>), dim3((unsigned)n_all), dim3(256), 0, q, e0, e1, 0, dw, cw, period);
+            h->mix_done = true;
+        }
+    }
+    if (h->mix_done) {}
+    else if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (fuse_adam) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else hipExtLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
@@ -607,7 +640,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     }
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
     int rcw = launch_dense0_wgrad(h, s.a3, h->dh, nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
-                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q);
+                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_adam && !stop_after_dense0);
     if (rcw) return rcw;
     if (stop_after_dense0) {
         h->pend_B = B; h->pend_stage = 2;
@@ -709,18 +742,11 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     r.grad = h->grad; r.gP = h->gP; r.K = K; r.n_seg = 3;
     long nblk = 0;
     for (int i = 2; i >= 0; --i) {
-        ConvWgradArgs a;
-        a.in = acts_in[i]; a.dout = douts[i]; a.slab = h->slab + h->slab_off[i];
-        a.in_net_stride = (i == 0) ? 0 : (long)nb * gact[i]->block;
-        a.slab_stride = h->slab_stride[i];
-        a.K = K; a.nb = nb; a.npc = h->npc[i]; a.KH = cl[i]->K; a.S = cl[i]->S; a.CO = cl[i]->CO;
-        a.OH = cl[i]->OH; a.OW = cl[i]->OW; a.pos_per_chunk = h->pos_per_chunk[i];
-        a.gin = *gact[i]; a.gd = *gdo[i]; a.in_C = cl[i]->CI;
-        if (i == 0) { a.KWe = 1; a.CIe = cl[i]->K * cl[i]->CI; } else { a.KWe = cl[i]->K; a.CIe = cl[i]->CI; }
-        a.n_items = (long)K * a.KH * a.KWe * a.npc;  // workgroups
+        ConvWgradArgs a = make_wgrad_args(h, i, nb);
         const int nit = a.CIe / 32, not_ = a.CO / 32;
         dim3 grid((unsigned)a.n_items);
-        if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
+        if (i == 2 && h->mix_done) {}  // already computed beside the fused Dense_0 update (k_mix_dense0_convw)
+        else if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
         else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
         else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
         else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
@@ -792,6 +818,7 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
     {  // conv arithmetic: f32 MFMA, or f32-accurate products on the bf16 matrix cores (conv3_kernels.h)
         const char* mode = getenv("IDQN_CONV");
         h->conv3_bwd = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
+        h->mix = getenv("IDQN_MIX") && atoi(getenv("IDQN_MIX")) == 1;
         h->conv3 = h->conv3_bwd || (cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3-forward") == 0);
     }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
