@@ -142,14 +142,12 @@ struct ConvFwdArgs {
 // Compared with loading fragments straight from L2 this cuts vector-memory instructions per MFMA ~10x
 // (the register version was bound by load issue, not by MFMA or bandwidth).
 template <int CT, int PPW>  // CT = CO / 32 (1 or 2); PPW = positions per wave
-__global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
+__device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a, int item, float* lds) {
     constexpr int NSUB = 4 / CT, NPW = NSUB * PPW, KC = 32, CO = 32 * CT;
-    // ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc wait vmcnt(0) before every
-    // ds_read): [buffer][ A: KC x CO | B: NPW x (KC x 32) ]
+    // ONE LDS object (a second one beside an LDS-DMA target makes hipcc wait vmcnt(0) before every
+    // ds_read): [buffer][ A: KC x CO | B: NPW x (KC x 32) ]   = 2 * BUF_FL floats
     constexpr int A_FL = KC * CO, B_FL = KC * 32, BUF_FL = A_FL + NPW * B_FL;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FL];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    int item = xcd_contiguous_id();  // an XCD walks consecutive position groups of one net: halo rows hit its L2
     int pg = item % a.npg;
     item /= a.npg;
     const int bb = item % a.nb;
@@ -232,6 +230,11 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
             }
         }
     }
+}
+template <int CT, int PPW>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (32 * 32 * CT + (4 / CT) * PPW * 32 * 32)];
+    conv_fwd_body<CT, PPW>(a, xcd_contiguous_id(), lds);  // an XCD walks consecutive position groups of one net
 }
 
 // Transformed weights for the data gradients-as-forward-convolutions:
@@ -987,6 +990,36 @@ template <int NIT, int NOT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36];
     conv_wgrad_body<NIT, NOT>(a, xcd_contiguous_id(), lds);
+}
+
+// ---- experiment (IDQN_MIX=2): the fused Dense_0 update spread over the three stages of the conv backward ----
+// One launch = a slice [d0_first, d0_first + d0_count) of the fused Dense_0 workgroups + the weight gradient of one
+// conv layer (+ the data gradient of the same stage when CT > 0), cw / cf alternating while both last; dynamic LDS =
+// the largest role's need.
+template <int NQ, int NIT, int NOT, int CT>
+__global__ __launch_bounds__(256) void k_mix_stage(DenseWgradArgs a, int d0_first, int d0_count, ConvWgradArgs cw,
+                                                   ConvFwdArgs cf, int period) {
+    extern __shared__ __attribute__((aligned(16))) float mix_lds[];
+    // conv-type workgroups are spread evenly through the grid (Bresenham): c(b) = floor(b m / N) of them lie before
+    // block b, and block b is one iff c(b + 1) > c(b); any ratio works and every XCD gets its share of both kinds
+    const long b = blockIdx.x, N = gridDim.x;
+    const int n_cw = (int)cw.n_items, n_cf = CT > 0 ? (int)cf.n_items : 0, m = n_cw + n_cf;
+    (void)period;
+    const int s = (int)(b * m / N);
+    if ((int)((b + 1) * m / N) > s) {
+        const int both = 2 * min(n_cw, n_cf);  // while both roles last they alternate
+        if (s < both) {
+            if ((s & 1) == 0) conv_wgrad_body<NIT, NOT>(cw, s >> 1, mix_lds);
+            else if (CT > 0) conv_fwd_body<(CT > 0 ? CT : 1), 1>(cf, s >> 1, mix_lds);
+        } else if (n_cw > n_cf) {
+            conv_wgrad_body<NIT, NOT>(cw, s - n_cf, mix_lds);
+        } else if (CT > 0) {
+            conv_fwd_body<(CT > 0 ? CT : 1), 1>(cf, s - n_cw, mix_lds);
+        }
+    } else {
+        const int local = (int)(b - s);
+        if (local < d0_count) dense0_wgrad_body<true, NQ>(a, d0_first + local, mix_lds);
+    }
 }
 
 // ---- experiment: the HBM-bound fused Dense_0 update and the MFMA-bound Conv_2 weight gradient in ONE launch ----

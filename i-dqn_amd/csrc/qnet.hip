@@ -186,6 +186,9 @@ struct idqn_handle_s {
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
+    int mix_mode = 0, mix_stage = 0;  // IDQN_MIX=2: fused Dense_0 slices beside the three conv backward stages
+    long mix_d0_next = 0;
+    DenseWgradArgs mix_dw;
     bool mix = false, mix_done = false;  // experiment (IDQN_MIX=1): Conv_2 weight gradient inside the fused Dense_0 launch
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
@@ -549,6 +552,84 @@ ConvWgradArgs make_wgrad_args(idqn_handle_s* h, int i, int nb) {
     return a;
 }
 
+// arguments of the data-gradient launch of conv layer i (1 or 2): a stride-1 forward convolution over dout with the
+// transformed kernels of k_wt_build, one variant per output parity
+int make_dgrad_args(idqn_handle_s* h, int i, int nb, ConvFwdArgs& a) {
+    NetSet& s = h->train;
+    const int K = h->cfg.n_heads;
+    const ConvL& l = h->conv[i];
+    const float* douts[3] = {h->da1, h->da2, h->da3};
+    const ActGeom* gdo[3] = {&h->gda1, &h->gda2, &h->gda3};
+    const float* acts_in[3] = {s.x, s.a1, s.a2};
+    const ActGeom* gact[3] = {&h->gx, &h->ga1, &h->ga2};
+    float* dins[3] = {nullptr, h->da1, h->da2};
+    const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
+    const int KHs = l.K / l.S, nvar = l.S * l.S;
+    memset(&a, 0, sizeof(a));
+    a.in = douts[i]; a.out = dins[i]; a.wbase = s.wbase; a.wt_base = h->wt[i]; a.wt_stride = h->wt_stride[i];
+    a.in_set = s.ident; a.mask = acts_in[i];
+    a.in_block = gdo[i]->block; a.out_block = gdi[i]->block; a.mask_block = gact[i]->block;
+    a.n_nets = K; a.nb = nb; a.n_var = nvar; a.epilogue = 1;
+    a.KH = KHs; a.KWCI = KHs * l.CO; a.S = 1; a.CI = l.CO; a.CO = l.CI; a.IWp = gdo[i]->Wp;
+    a.out_Wp = gdi[i]->Wp; a.out_lo_h = gdi[i]->lo_h; a.out_lo_w = gdi[i]->lo_w;
+    a.mask_Wp = gact[i]->Wp; a.mask_lo_h = gact[i]->lo_h; a.mask_lo_w = gact[i]->lo_w;
+    IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d dgrad: %d rows per kernel row is not a multiple of 32", i, a.KWCI);
+    const int npw = (l.CI == 32) ? 4 : 2;
+    int pg = 0;
+    for (int vi = 0; vi < nvar; ++vi) {
+        const int rh = vi / l.S, rw = vi % l.S;
+        const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
+        ConvVariant& v = a.var[vi];
+        v.w_off = (long)vi * KHs * KHs * l.CO * l.CI;
+        v.in_off_h = (rh + l.PLh - ph) / l.S + gdo[i]->lo_h - KHs + 1;
+        v.in_off_w = (rw + l.PLw - pw) / l.S + gdo[i]->lo_w - KHs + 1;
+        v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
+        v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw; v.pg_begin = pg;
+        IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
+        pg += cdiv(v.OH * v.OW, npw);
+    }
+    a.npg = pg;
+    a.n_items = (long)K * nb * a.npg;
+    return IDQN_OK;
+}
+
+// IDQN_MIX=2: one stage of the conv backward (weight gradient of layer `layer`, plus its data gradient for layers 2
+// and 1) in one grid with the next slice of the fused Dense_0 update.  Standard Nature-CNN channel widths only.
+template <int NIT, int NOT, int CT>
+int launch_mix_stage_t(idqn_handle_s* h, int layer, int nb, long d0_count, hipStream_t q, hipEvent_t e0, hipEvent_t e1) {
+    ConvWgradArgs cw = make_wgrad_args(h, layer, nb);
+    ConvFwdArgs cf;
+    memset(&cf, 0, sizeof(cf));
+    if (CT > 0) {
+        int rc = make_dgrad_args(h, layer, nb, cf);
+        if (rc) return rc;
+    }
+    const long n_conv = cw.n_items + (CT > 0 ? cf.n_items : 0), n_all = d0_count + n_conv;
+    const size_t lds_w = (size_t)2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36 * 4;
+    const size_t lds_f = CT > 0 ? (size_t)2 * (32 * 32 * (CT > 0 ? CT : 1) + (4 / (CT > 0 ? CT : 1)) * 32 * 32) * 4 : 0;
+    const size_t lds = std::max<size_t>(std::max(lds_w, lds_f), (size_t)32 * 256 * 4);
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_mix_stage<2, NIT, NOT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipExtLaunchKernelGGL((k_mix_stage<2, NIT, NOT, CT>), dim3((unsigned)n_all), dim3(256), lds, q, e0, e1, 0, h->mix_dw,
+                          (int)h->mix_d0_next, (int)d0_count, cw, cf, 0);
+    h->mix_d0_next += d0_count;
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int launch_mix_stage(idqn_handle_s* h, int layer, int nb, hipStream_t q, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    const long n_d0 = h->mix_dw.n_items;
+    // Dense_0 slices per stage: 50 / 30 / 20 % (a sweep from 30/40/30 to 100/0/0 moved the step by < 3 %)
+    static int pa = getenv("IDQN_MIX_A") ? atoi(getenv("IDQN_MIX_A")) : 50, pb = getenv("IDQN_MIX_B") ? atoi(getenv("IDQN_MIX_B")) : 30;
+    const long share = layer == 2 ? n_d0 * pa / 100 : layer == 1 ? n_d0 * pb / 100 : n_d0 - h->mix_d0_next;
+    if (layer == 2) return launch_mix_stage_t<2, 2, 2>(h, 2, nb, share, q, e0, e1);
+    if (layer == 1) return launch_mix_stage_t<1, 2, 1>(h, 1, nb, share, q, e0, e1);
+    return launch_mix_stage_t<1, 1, 0>(h, 0, nb, share, q, e0, e1);
+}
+
 int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
 
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
@@ -574,7 +655,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    h->mix_done = false;
+    h->mix_done = false; h->mix_stage = 0;
+    if (fuse_adam && nq == 2 && h->mix_mode == 2 && allow_mix && nb_total == nb_inner && h->conv[0].CO == 32 && h->conv[0].K * h->conv[0].CI == 32 &&
+        h->conv[1].CI == 32 && h->conv[1].CO == 64 && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
+        int rcb = build_dgrad_weights(h, q);  // the data gradients start in this very launch
+        if (rcb) return rcb;
+        h->mix_dw = dw; h->mix_d0_next = 0; h->mix_stage = 1;
+        return launch_mix_stage(h, 2, nb_total, q, e0, e1);
+    }
     if (fuse_adam && nq == 2 && h->mix && allow_mix && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
         ConvWgradArgs cw = make_wgrad_args(h, 2, nb_total);
         const long n_all = dw.n_items + cw.n_items;
@@ -663,7 +751,7 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     float* dins[3] = {nullptr, h->da1, h->da2};
     const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
     // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
-    if (!h->conv3_bwd) {  // (the bf16x3 data-gradient path built and packed them before the forward pass)
+    if (!h->conv3_bwd && h->mix_stage == 0) {  // (the bf16x3 and staged-mix paths built them earlier)
         int rcb = build_dgrad_weights(h, q);
         if (rcb) return rcb;
     }
@@ -703,39 +791,20 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
         else
             hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
     }
-    for (int i = 2; i >= 1 && !h->conv3_bwd; --i) {
+    for (int i = 2; i >= 1 && !h->conv3_bwd && h->mix_stage == 0; --i) {
         const ConvL& l = *cl[i];
-        const int KHs = l.K / l.S, nvar = l.S * l.S;
         ConvFwdArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = douts[i]; a.out = dins[i]; a.wbase = s.wbase; a.wt_base = h->wt[i]; a.wt_stride = h->wt_stride[i];
-        a.in_set = s.ident; a.mask = acts_in[i];
-        a.in_block = gdo[i]->block; a.out_block = gdi[i]->block; a.mask_block = gact[i]->block;
-        a.n_nets = K; a.nb = nb; a.n_var = nvar; a.epilogue = 1;
-        a.KH = KHs; a.KWCI = KHs * l.CO; a.S = 1; a.CI = l.CO; a.CO = l.CI; a.IWp = gdo[i]->Wp;
-        a.out_Wp = gdi[i]->Wp; a.out_lo_h = gdi[i]->lo_h; a.out_lo_w = gdi[i]->lo_w;
-        a.mask_Wp = gact[i]->Wp; a.mask_lo_h = gact[i]->lo_h; a.mask_lo_w = gact[i]->lo_w;
-        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d dgrad: %d rows per kernel row is not a multiple of 32", i, a.KWCI);
-        const int npw = (l.CI == 32) ? 4 : 2;
-        int pg = 0;
-        for (int vi = 0; vi < nvar; ++vi) {
-            const int rh = vi / l.S, rw = vi % l.S;
-            const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
-            ConvVariant& v = a.var[vi];
-            v.w_off = (long)vi * KHs * KHs * l.CO * l.CI;
-            v.in_off_h = (rh + l.PLh - ph) / l.S + gdo[i]->lo_h - KHs + 1;
-            v.in_off_w = (rw + l.PLw - pw) / l.S + gdo[i]->lo_w - KHs + 1;
-            v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
-            v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw; v.pg_begin = pg;
-            IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
-            pg += cdiv(v.OH * v.OW, npw);
-        }
-        a.npg = pg;
-        a.n_items = (long)K * nb * a.npg;
+        int rcd = make_dgrad_args(h, i, nb, a);
+        if (rcd) return rcd;
         if (l.CI == 32)
             hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
         else
             hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+    }
+    if (h->mix_stage == 1) {  // IDQN_MIX=2: stage A (Conv_2 gradients) ran beside the first Dense_0 slice; now B and C
+        int rcm = launch_mix_stage(h, 1, nb, q);
+        if (!rcm) rcm = launch_mix_stage(h, 0, nb, q);
+        if (rcm) return rcm;
     }
     // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
     SlabReduceArgs r;
@@ -745,7 +814,7 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
         ConvWgradArgs a = make_wgrad_args(h, i, nb);
         const int nit = a.CIe / 32, not_ = a.CO / 32;
         dim3 grid((unsigned)a.n_items);
-        if (i == 2 && h->mix_done) {}  // already computed beside the fused Dense_0 update (k_mix_dense0_convw)
+        if ((i == 2 && h->mix_done) || h->mix_stage == 1) {}  // already computed beside the fused Dense_0 update
         else if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
         else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
         else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
@@ -818,7 +887,8 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
     {  // conv arithmetic: f32 MFMA, or f32-accurate products on the bf16 matrix cores (conv3_kernels.h)
         const char* mode = getenv("IDQN_CONV");
         h->conv3_bwd = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
-        h->mix = getenv("IDQN_MIX") && atoi(getenv("IDQN_MIX")) == 1;
+        h->mix_mode = getenv("IDQN_MIX") ? atoi(getenv("IDQN_MIX")) : 0;
+        h->mix = h->mix_mode == 1;
         h->conv3 = h->conv3_bwd || (cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3-forward") == 0);
     }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");

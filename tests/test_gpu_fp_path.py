@@ -139,6 +139,23 @@ def test_cnn_every_stage_against_oracle(name, conv_mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("mix", ["1", "2"])
+def test_mixed_backward_launches_match_the_goldens(mix, monkeypatch):
+    """IDQN_MIX (opt-in): the fused Dense_0 update shares its launch with the Conv_2 weight gradient (1) or is
+    sliced over the three stages of the conv backward (2).  Same arithmetic, same goldens."""
+    monkeypatch.setenv("IDQN_MIX", mix)
+    for name in ("cnn_atari_k5", "cnn_atari_a18_b64"):
+        agent, bs, rec, _ = _agent(name)
+        K = agent._K
+        for s, batch in enumerate(bs):
+            losses = agent._learn(batch).cpu().numpy()
+            assert np.abs(losses - np.asarray(rec["steps"][s]["losses"])).max() <= LOSS_ATOL, (name, s)
+        flat = agent._flat(agent._online)
+        for leaf, d in rec["steps"][len(bs) - 1]["leaves"].items():
+            err = np.abs(flat[leaf].reshape(K, -1)[:, d["idx"]] - np.asarray(d["param"]))
+            assert (err <= 3e-7).mean() >= 0.98 and err.max() <= 2 * rec["hyper"]["lr"] * len(bs), (name, leaf)
+
+
 @pytest.mark.parametrize("name", ["cnn_small", "cnn_atari_k5", "cnn_atari_a18_b64", "fc_lunar_k3"])
 def test_full_steps_against_goldens(name, conv_mode):
     """Fused path (weight gradient + Adam in one kernel): losses and post-Adam parameters of every step."""
