@@ -26,38 +26,56 @@ def head_window(n_networks: int, rank: int, world: int):
     return rank * count, count
 
 
-def sharded_target_update(agent, rank: int, world: int, group=None) -> None:
-    """The T-step over a head-sharded chain; ``agent`` holds the rows ``_online`` / ``_target`` of its window."""
+def _exchange(sends, recvs, group=None):
+    """Posts the point-to-point operations ``[(tensor, peer)]`` and returns a function that completes them.  RCCL
+    moves device rows directly; gloo (CPU tests, or two test ranks sharing one GPU) cannot receive into device memory,
+    so device rows are staged through host copies there."""
     import torch.distributed as dist
 
-    ops, first_old, incoming = [], None, None
+    staged = dist.get_backend(group) == "gloo"
+    ops, copies = [], []
+    for t, peer in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if (staged and t.is_cuda) else t, peer, group))
+    for t, peer in recvs:
+        if staged and t.is_cuda:
+            host = t.new_empty(t.shape, device="cpu")
+            copies.append((t, host))
+            ops.append(dist.P2POp(dist.irecv, host, peer, group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t, peer, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish():
+        for r in reqs:
+            r.wait()
+        for dev, host in copies:
+            dev.copy_(host)
+
+    return finish
+
+
+def sharded_target_update(agent, rank: int, world: int, group=None) -> None:
+    """The T-step over a head-sharded chain; ``agent`` holds the rows ``_online`` / ``_target`` of its window."""
+    sends, recvs, incoming = [], [], None
     if rank > 0:  # my OLD first head becomes the new last head of the rank below
-        first_old = agent._online[0].clone()
-        ops.append(dist.P2POp(dist.isend, first_old, rank - 1, group))
+        sends.append((agent._online[0].clone(), rank - 1))
     if rank < world - 1:
         incoming = agent._online.new_empty(agent._online.shape[1])
-        ops.append(dist.P2POp(dist.irecv, incoming, rank + 1, group))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
+        recvs.append((incoming, rank + 1))
+    finish = _exchange(sends, recvs, group)
     agent._local_target_update()  # target <- online, shift inside the window (its last head keeps its value)
-    for r in reqs:
-        r.wait()
+    finish()
     if incoming is not None:
         agent._online[-1].copy_(incoming)
 
 
 def sharded_target_sync(agent, rank: int, world: int, group=None) -> None:
     """The D-step over a head-sharded chain (neither side of the exchange is touched by the local sync)."""
-    import torch.distributed as dist
-
-    ops = []
-    if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, agent._online[-1], rank + 1, group))
-    if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, agent._target[0], rank - 1, group))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
+    sends = [(agent._online[-1], rank + 1)] if rank < world - 1 else []
+    recvs = [(agent._target[0], rank - 1)] if rank > 0 else []
+    finish = _exchange(sends, recvs, group)
     agent._local_target_sync()  # target[j] <- online[j-1] for the local j >= 1
-    for r in reqs:
-        r.wait()
+    finish()
 
 
 class HeadShardedIDQN(iDQN):

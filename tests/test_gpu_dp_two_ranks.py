@@ -71,3 +71,84 @@ def test_two_rank_step_equals_the_single_device_step(tmp_path, mode):
     # the replicas stay bit-identical: same blocks, same order, same arithmetic on both ranks
     for k in got[0].files:
         np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=f"{mode}: ranks diverged in {k}")
+
+
+def _hp_worker(rank, world, port, out):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "i-dqn_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slimdqn.networks.head_parallel import HeadShardedIDQN
+
+        agent = HeadShardedIDQN(9, *HP_ARGS)
+        logs = _hp_run(agent)
+        torch.cuda.synchronize()
+        np.savez(f"{out}/hp{rank}.npz", online=agent._online.cpu().numpy(), target=agent._target.cpu().numpy(),
+                 logs=np.asarray(logs, np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+HP_OBS, HP_A, HP_K = (20, 20, 4), 5, 4
+HP_ARGS = (HP_OBS, HP_A, HP_K, [32, 32, 32, 128], "cnn", 1e-3, 0.99, 1, 1, 4, 2)  # T = 4, D = 2
+
+
+def _hp_run(agent):
+    """9 environment steps of update_online / update_target on fixed batches; returns the logged losses."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+
+    class Fixed:
+        i = 0
+
+        def sample(self):
+            Fixed.i += 1
+            return Batch(*Q.synthetic_batch(300 + Fixed.i, 32, HP_OBS, HP_A, "cnn"))
+
+    Fixed.i = 0
+    rb, logs = Fixed(), []
+    for step in range(1, 10):
+        agent.update_online_params(step, rb)
+        has, lg = agent.update_target_params(step)
+        if has:
+            logs.append([lg["loss"]] + [lg[f"networks/{k}_loss"] for k in range(HP_K)])
+    return logs
+
+
+def test_two_rank_head_parallel_chain_equals_the_single_device_agent(tmp_path):
+    """Head-parallel i-DQN on two ranks (2 heads each) through T-steps (copy + shift) and D-steps (sync) with the rows
+    really travelling between processes: concatenated, the windows must equal the 4-head single-device agent."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from slimdqn.networks.idqn import iDQN
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = iDQN(9, *HP_ARGS)
+    ref_logs = _hp_run(ref)
+    torch.cuda.synchronize()
+    got = [np.load(f"{tmp_path}/hp{r}.npz") for r in range(2)]
+    online = np.concatenate([g["online"] for g in got])
+    target = np.concatenate([g["target"] for g in got])
+    # window agents re-associate the split-K sums (fewer local heads): fp32 accumulation accuracy, not bits
+    for name, a, b in (("online", online, ref._online.cpu().numpy()), ("target", target, ref._target.cpu().numpy())):
+        err = np.abs(a - b)
+        per_head = [(float((e <= 1e-6).mean()), float(e.max())) for e in err]
+        assert (err <= 1e-6).mean() >= 0.999 and err.max() <= 2 * 1e-3 * 9, (name, per_head)
+    np.testing.assert_allclose(got[0]["logs"], np.asarray(ref_logs), rtol=1e-4)
+    np.testing.assert_array_equal(got[0]["logs"], got[1]["logs"])  # every rank logs all K heads
