@@ -250,11 +250,10 @@ struct WtBuildArgs {
     WtLayer layer[2];           // blockIdx.z selects the layer
     int K;
 };
-__global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs args) {
-    const WtLayer& a = args.layer[blockIdx.z];
+__device__ __forceinline__ void wt_build_body(const WtBuildArgs& args, int bx, int k, int layer) {
+    const WtLayer& a = args.layer[layer];
     const long per_var = (long)a.KHs * a.KWs * a.CO * a.CI;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const int k = blockIdx.y;
+    const long e = (long)bx * 256 + threadIdx.x;
     if (e >= per_var * a.n_var) return;
     const int vi = (int)(e / per_var);
     long r = e - vi * per_var;
@@ -270,6 +269,7 @@ __global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs args) {
     const int kw = (rw + a.PLw) % a.S + a.S * (a.KWs - 1 - kws);
     a.wt[(long)k * a.wt_stride + e] = args.wbase[k][a.w_off + ((long)(kh * a.KW + kw) * a.CI + ci) * a.CO + co];
 }
+__global__ __launch_bounds__(256) void k_wt_build(WtBuildArgs args) { wt_build_body(args, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // --------------------------------------------------------------------------------------------
 // Dense_0 forward, split-K partials (architectures/dqn.py:67-68).  M = 32 samples, so this is a
@@ -446,12 +446,12 @@ struct TdArgs {
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
 };
 
-__global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
+__device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     __shared__ float hs[32][33];
     __shared__ float qo[32 * 32], qt[32 * 32];
     __shared__ float qmax[32], cs[32], red[1];
     __shared__ int acts[32];
-    const int jc = blockIdx.x, k = blockIdx.y, t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
     const int b = t & 31, jj = t >> 5, NJC = a.J / 32;
     const float* po = a.wbase[k];
     const float* pt = a.wbase[a.K + k];
@@ -567,6 +567,20 @@ __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
                 a.cum[k] = a.cum[k] + (double)(loss_acc / (float)a.Bdiv);
             }
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_td_dh(TdArgs a) { td_dh_body(a, blockIdx.x, blockIdx.y); }
+
+// The TD / loss kernel has J / 32 x K workgroups (80 for the Atari net) and is latency-bound; the re-indexing of the
+// Conv_1 / Conv_2 kernels for the data gradients (k_wt_build) depends on nothing this step computes, so its
+// workgroups ride in the same launch instead of costing one of their own.
+__global__ __launch_bounds__(256) void k_td_dh_wt(TdArgs a, WtBuildArgs w, int wt_nx) {
+    const int njc = a.J / 32, n_td = njc * a.K, b = blockIdx.x;
+    if (b < n_td) {
+        td_dh_body(a, b % njc, b / njc);
+    } else {
+        const int r = b - n_td, per_layer = wt_nx * w.K;
+        wt_build_body(w, r % wt_nx, (r / wt_nx) % w.K, r / per_layer);
     }
 }
 

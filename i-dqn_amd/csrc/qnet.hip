@@ -186,6 +186,7 @@ struct idqn_handle_s {
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
+    bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     int mix_mode = 0, mix_stage = 0;  // IDQN_MIX=2: fused Dense_0 slices beside the three conv backward stages
     long mix_d0_next = 0;
     DenseWgradArgs mix_dw;
@@ -386,10 +387,8 @@ int fc_setup(idqn_handle_s* h) {
 }
 
 // Conv_1 / Conv_2 kernels re-indexed for the data gradient-as-convolution (k_wt_build), f32
-int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
-    const int K = h->cfg.n_heads;
-    WtBuildArgs wb;
-    wb.wbase = h->train.wbase; wb.K = K;
+int wt_build_args(idqn_handle_s* h, WtBuildArgs& wb) {  // returns the x extent of the launch
+    wb.wbase = h->train.wbase; wb.K = h->cfg.n_heads;
     long maxe = 0;
     for (int i = 1; i <= 2; ++i) {
         const ConvL& l = h->conv[i];
@@ -399,7 +398,14 @@ int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
         w.n_var = l.S * l.S; w.KHs = l.K / l.S; w.KWs = l.K / l.S;
         maxe = std::max(maxe, (long)l.K * l.K * l.CI * l.CO);
     }
-    hipLaunchKernelGGL(k_wt_build, dim3(cdiv(maxe, 256), K, 2), dim3(256), 0, q, wb);
+    return cdiv(maxe, 256);
+}
+
+int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
+    if (h->wt_ready) return IDQN_OK;  // already built this step, inside the TD / loss launch
+    WtBuildArgs wb;
+    const int nx = wt_build_args(h, wb);
+    hipLaunchKernelGGL(k_wt_build, dim3(nx, wb.K, 2), dim3(256), 0, q, wb);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -705,7 +711,15 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
-    hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
+    h->wt_ready = false;
+    if (!h->conv3_bwd) {  // (the bf16x3 data-gradient path packs them before the forward pass)
+        WtBuildArgs wb;
+        const int nx = wt_build_args(h, wb);
+        hipLaunchKernelGGL(k_td_dh_wt, dim3((h->J / 32) * K + nx * K * 2), dim3(256), 0, q, ta, wb, nx);
+        h->wt_ready = true;
+    } else {
+        hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
+    }
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
     dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3_bwd ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
