@@ -418,8 +418,12 @@ def rccl_single_rank():
     import torch
     import torch.distributed as dist
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
+    import socket
+
+    with socket.socket() as sock:  # a free port: a fixed one collides when two suites share a box
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield dist
     dist.destroy_process_group()
