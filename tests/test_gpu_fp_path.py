@@ -345,6 +345,7 @@ def test_dqn_entry_points_run_as_scripts(env_name, tmp_path):
     ("cnn", (20, 20, 4), [32, 32, 32, 128], 5, 2, 20),     # ragged: one partly filled 32-sample block
     ("cnn", (20, 20, 4), [32, 64, 32, 256], 3, 3, 50),     # ragged second block, mixed channel widths, J = 256
     ("cnn", (36, 28, 4), [64, 32, 64, 128], 18, 1, 33),    # non-square frames, 18 actions, one sample in block 2
+    ("cnn", (20, 20, 4), [32, 32, 32, 128], 4, 2, 256),    # eight sample blocks (BASELINE config 4's global batch)
     ("fc", 8, [100, 100], 4, 3, 7),
     ("fc", (6, 1), [50], 2, 9, 64),
 ])
