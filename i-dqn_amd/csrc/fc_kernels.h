@@ -7,6 +7,8 @@
 // gradients go to the arena and the shared Adam kernel applies them.  Plain f32 FMAs: the layer
 // widths (8, 100, 4) are not MFMA-shaped and the total is ~1 MFLOP per head.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 #define FC_MAX_WIDTH 512
@@ -150,6 +152,238 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
         }
         __syncthreads();
         float* tmp = delta; delta = dprev; dprev = tmp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS version of the step (used whenever the net fits: the LunarLander sizes need 118 KB).  The first version above
+// kept every activation in a global workspace and walked each dot product as a chain of dependent L2 loads: 575 us per
+// step for an 11 k-parameter head, slower than the Atari CNN.  Here a 512-thread workgroup per head keeps the
+// activations of one 32-sample block, the deltas and the weight matrix of the current layer (odd row pitch) in LDS;
+// every thread owns one output column and eight samples (or eight input rows in the weight gradient), so a weight is
+// read once per eight FMAs and all LDS reads are broadcasts or unit-stride.  Batches larger than 32 are processed
+// block by block; the gradient arena accumulates across blocks.
+// ---------------------------------------------------------------------------------------------------
+#define FC_T 512
+#define FC_LDS_BUDGET (150 * 1024)  // bytes of LDS the step kernel may use
+
+// Plan: samples per block BS (32, 16 or 8) and the width of the staged weight column tile, so that the activations,
+// the deltas and one weight tile fit the budget.  Small nets get BS = 32 and whole matrices.
+struct FcPlan {
+    int BS, ld, tw, wfl;  // block size, activation pitch (odd), weight tile width, floats of the weight tile buffer
+    long floats;          // total LDS floats
+};
+static inline FcPlan fc_plan(const FcNet& n) {
+    FcPlan p;
+    p.ld = n.dmax + 1 + (n.dmax & 1);
+    int dinmax = 0, doutmax = 0;
+    for (int l = 0; l < n.L; ++l) { dinmax = std::max(dinmax, n.d[l]); doutmax = std::max(doutmax, n.d[l + 1]); }
+    for (int bs : {32, 16, 8}) {
+        p.BS = bs;
+        const long fixed = (long)(n.L + 3) * bs * p.ld + 3 * 32 + 8;  // acts + 2 delta buffers + qmax / sq / misc
+        const long left = FC_LDS_BUDGET / 4 - fixed;
+        if (left < (long)dinmax * 9) continue;  // not even an 8-column tile
+        int tw = (int)std::min<long>(doutmax, left / dinmax - 1);
+        tw = std::max(8, tw & ~1);              // even width -> odd pitch tw + 1
+        p.tw = std::min(tw, doutmax + (doutmax & 1));
+        p.wfl = dinmax * (p.tw | 1);
+        p.floats = fixed + p.wfl;
+        return p;
+    }
+    p.BS = 0; p.tw = 0; p.wfl = 0; p.floats = 0;  // does not fit: the generic kernel runs
+    return p;
+}
+
+// stage columns [c0, c0 + cw) of W [din][dout] (global, row-major) into LDS with pitch (tw | 1)
+__device__ __forceinline__ void fc_stage_w(const float* W, float* Wl, int din, int dout, int c0, int cw, int ldw) {
+    for (int e = threadIdx.x; e < din * cw; e += FC_T) {
+        const int i = e / cw, o = e - i * cw;
+        Wl[i * ldw + o] = W[(long)i * dout + c0 + o];
+    }
+    __syncthreads();
+}
+// out[b][o] = (relu?)(bias[o] + sum_i in[b][i] * W[i][o]) for the BS samples of a block; in / out in LDS (pitch ld)
+template <int BS>
+__device__ __forceinline__ void fc_layer_lds(const float* in, const float* W, float* Wl, const float* bias, float* out,
+                                             int ld, int din, int dout, bool relu, int tw) {
+    constexpr int NG = BS / 8;
+    const int ldw = tw | 1;
+    for (int c0 = 0; c0 < dout; c0 += tw) {
+        const int cw = min(tw, dout - c0);
+        fc_stage_w(W, Wl, din, dout, c0, cw, ldw);
+        for (int task = threadIdx.x; task < cw * NG; task += FC_T) {
+            const int o = task % cw, bg = task / cw;
+            const float* x = in + bg * 8 * ld;
+            float acc[8];
+            const float b0 = bias[c0 + o];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = b0;
+            for (int i = 0; i < din; ++i) {
+                const float w = Wl[i * ldw + o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(x[j * ld + i], w, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[(bg * 8 + j) * ld + c0 + o] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+        }
+        __syncthreads();
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(FC_T) void k_fc_step_lds(FcArgs a, int tw, int wfl) {
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    constexpr int NG = BS / 8;
+    const int k = blockIdx.x, t = threadIdx.x;
+    const FcNet& n = a.net;
+    const int B = a.B, A = n.d[n.L], ld = n.dmax + 1 + (n.dmax & 1);  // odd activation pitch
+    float* Wl = fl;                               // staged weight tile of the current layer
+    float* acts = Wl + wfl;                       // [L+1][BS][ld] online activations of the block
+    float* dA = acts + (n.L + 1) * BS * ld;       // [BS][ld] target ping / delta
+    float* dB = dA + BS * ld;                     // [BS][ld] target pong / delta
+    float* qmax = dB + BS * ld;                   // [32]
+    float* sq = qmax + 32;                        // [32]
+    float* lsum = sq + 32;                        // [1]
+    const float* po = a.online + (long)k * a.P;
+    const float* pt = a.target + (long)k * a.P;
+    float* G = a.grad + (long)k * a.P;
+    if (t == 0) lsum[0] = 0.f;
+    const int nb = (B + BS - 1) / BS;
+    for (int bb = 0; bb < nb; ++bb) {
+        const int b0 = bb * BS, nbk = min(BS, B - b0);
+        // ---- inputs of the block (rows past the batch end are zero inputs; they carry no loss weight)
+        for (int e = t; e < BS * n.d[0]; e += FC_T) {
+            const int b = e / n.d[0], i = e - b * n.d[0];
+            dA[b * ld + i] = b < nbk ? a.s2[(long)(b0 + b) * n.d[0] + i] : 0.f;
+            acts[b * ld + i] = b < nbk ? a.s[(long)(b0 + b) * n.d[0] + i] : 0.f;
+        }
+        __syncthreads();
+        // ---- target net on s'
+        float *cur = dA, *nxt = dB;
+        for (int l = 0; l < n.L; ++l) {
+            fc_layer_lds<BS>(cur, pt + n.w_off[l], Wl, pt + n.b_off[l], nxt, ld, n.d[l], n.d[l + 1], l != n.L - 1, tw);
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (t < 64) {  // wavefront max over actions: each half-wave folds every other action, one cross-lane step
+            const int b = t & 31, hh = t >> 5;
+            float m = -INFINITY;
+            if (b < BS)
+                for (int ac = hh; ac < A; ac += 2) m = fmaxf(m, cur[b * ld + ac]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (hh == 0 && b < BS) qmax[b] = m;
+        }
+        for (int e = t; e < nbk * A; e += FC_T) a.q_dbg[((long)(a.K + k) * B + b0) * A + e] = cur[(e / A) * ld + e % A];
+        __syncthreads();
+        // ---- online net on s, activations kept
+        for (int l = 0; l < n.L; ++l)
+            fc_layer_lds<BS>(acts + l * BS * ld, po + n.w_off[l], Wl, po + n.b_off[l], acts + (l + 1) * BS * ld, ld, n.d[l],
+                             n.d[l + 1], l != n.L - 1, tw);
+        const float* q = acts + n.L * BS * ld;
+        for (int e = t; e < nbk * A; e += FC_T) a.q_dbg[((long)k * B + b0) * A + e] = q[(e / A) * ld + e % A];
+        // ---- TD error, loss, dL/dq  (idqn.py:111-124)
+        float* delta = dA;
+        if (t < BS) {
+            const int b = t;
+            float sqv = 0.f, g = 0.f;
+            int ac = 0;
+            if (b < nbk) {
+                const int bg = b0 + b;
+                const float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * qmax[b];
+                ac = a.action[bg];
+                const float td = q[b * ld + ac] - tgt;
+                const float wgt = a.is_weight ? a.is_weight[bg] : 1.0f;
+                if (a.td_abs) a.td_abs[(long)k * B + bg] = fabsf(td);
+                sqv = wgt * td * td;
+                g = 2.0f * wgt * td / (float)a.Bdiv;
+            }
+            for (int o = 0; o < A; ++o) delta[b * ld + o] = (o == ac) ? g : 0.f;
+            sq[b] = sqv;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float s = lsum[0];
+            for (int b = 0; b < BS; ++b) s += sq[b];
+            lsum[0] = s;
+        }
+        // ---- backward of the block; the gradient arena accumulates over blocks
+        float* dprev = dB;
+        for (int l = n.L - 1; l >= 0; --l) {
+            const int din = n.d[l], dout = n.d[l + 1], ldw = tw | 1;
+            const float* in = acts + l * BS * ld;
+            // gW[i][o] = sum_b in[b][i] * delta[b][o]: a thread owns column o and eight rows i
+            const int n_ig = (din + 7) / 8;
+            for (int task = t; task < dout * n_ig; task += FC_T) {
+                const int o = task % dout, i0 = (task / dout) * 8;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < BS; ++b) {
+                    const float d = delta[b * ld + o];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(i0 + j < din ? in[b * ld + i0 + j] : 0.f, d, acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + j < din) {
+                        float* g = G + n.w_off[l] + (long)(i0 + j) * dout + o;
+                        *g = bb == 0 ? acc[j] : *g + acc[j];
+                    }
+            }
+            for (int o = t; o < dout; o += FC_T) {
+                float s = 0.f;
+                for (int b = 0; b < BS; ++b) s += delta[b * ld + o];
+                float* g = G + n.b_off[l] + o;
+                *g = bb == 0 ? s : *g + s;
+            }
+            if (l > 0) {
+                // dprev[b][i] = relu'(in[b][i]) * sum_o delta[b][o] W[i][o]: a thread owns row i and eight samples; the
+                // sum runs over the weight column tiles, the partial sums stay in registers (<= 4 tasks per thread)
+                float acc[4][8];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[q4][j] = 0.f;
+                for (int c0 = 0; c0 < dout; c0 += tw) {
+                    const int cw = min(tw, dout - c0);
+                    fc_stage_w(po + n.w_off[l], Wl, din, dout, c0, cw, ldw);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int task = t + q4 * FC_T;
+                        if (task < din * NG) {
+                            const int i = task % din, bg = task / din;
+                            const float* dr = delta + bg * 8 * ld + c0;
+                            for (int o = 0; o < cw; ++o) {
+                                const float w = Wl[i * ldw + o];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[q4][j] = fmaf(dr[j * ld + o], w, acc[q4][j]);
+                            }
+                        }
+                    }
+                    __syncthreads();  // the tile buffer is re-staged next
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int task = t + q4 * FC_T;
+                    if (task < din * NG) {
+                        const int i = task % din, bg = task / din;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            dprev[(bg * 8 + j) * ld + i] = in[(bg * 8 + j) * ld + i] > 0.f ? acc[q4][j] : 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+            float* tmp = delta; delta = dprev; dprev = tmp;
+        }
+    }
+    if (t == 0) {
+        const float s = lsum[0];
+        a.losses[k] = s / (float)a.Bdiv;
+        const double tt = (double)(a.count[k] + 1);
+        a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.adam_b1, tt));
+        a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.adam_b2, tt));
+        if (a.finish_step) {
+            a.count[k] += 1;
+            a.cum[k] = a.cum[k] + (double)(s / (float)a.Bdiv);
+        }
     }
 }
 

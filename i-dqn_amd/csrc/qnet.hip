@@ -176,6 +176,7 @@ struct idqn_handle_s {
     // fc
     FcNet fc;
     float* fc_ws = nullptr;
+    FcPlan fc_plan_;  // LDS plan of k_fc_step_lds (BS = 0: the net does not fit and the generic kernel runs)
     // profiling of the dominant kernel
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -382,6 +383,15 @@ int fc_setup(idqn_handle_s* h) {
     int rc;
     if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
+    h->fc_plan_ = fc_plan(n);
+    IDQN_REQUIRE(n.dmax <= FC_MAX_WIDTH, "fc: layer width %d exceeds %d", n.dmax, FC_MAX_WIDTH);
+    if (getenv("IDQN_FC_GENERIC")) h->fc_plan_.BS = 0;
+    if (h->fc_plan_.BS) {
+        const int bytes = (int)(h->fc_plan_.floats * 4);
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
     h->dominant = "k_fc_step";
     return IDQN_OK;
 }
@@ -957,7 +967,12 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         a.cum = h->cum; a.finish_step = grads_only ? 0 : 1;
         a.is_weight = h->is_weight; a.td_abs = h->td_abs;
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
-        hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
+        const FcPlan& fp = h->fc_plan_;
+        const size_t lds = (size_t)fp.floats * 4;
+        if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
+        else if (fp.BS == 16) hipLaunchKernelGGL(k_fc_step_lds<16>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
+        else if (fp.BS == 8) hipLaunchKernelGGL(k_fc_step_lds<8>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
+        else hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
             IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
             h->ev_used += 2;

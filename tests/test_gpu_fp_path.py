@@ -348,6 +348,9 @@ def test_dqn_entry_points_run_as_scripts(env_name, tmp_path):
     ("cnn", (20, 20, 4), [32, 32, 32, 128], 4, 2, 256),    # eight sample blocks (BASELINE config 4's global batch)
     ("fc", 8, [100, 100], 4, 3, 7),
     ("fc", (6, 1), [50], 2, 9, 64),
+    ("fc", 8, [200, 200], 4, 2, 40),       # 16-sample blocks and weight column tiles in the LDS kernel
+    ("fc", 12, [512, 300, 64], 6, 2, 33),  # 8-sample blocks, four layers, widest supported layer
+    ("fc", 5, [7, 9], 3, 2, 32),           # odd widths
 ])
 def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B, conv_mode):
     """Edge cases of the batch / shape handling: live oracle comparison of losses, gradients and one Adam step."""
