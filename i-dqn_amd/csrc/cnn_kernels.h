@@ -584,48 +584,40 @@ __global__ __launch_bounds__(256) void k_td_dh_wt(TdArgs a, WtBuildArgs w, int w
     }
 }
 
-// hs[j*33 + b] = relu(b0[j] + sum_s part[s][j][b]);  qs[a*32 + b] = b1[a] + sum_j hs[j][b] * W1[j][a]
-__device__ __forceinline__ void head_hidden_and_q(float* hs, float* qs, const float* part, const float* b0,
-                                                  const float* w1, const float* b1, int NS, int J, int A) {
-    const int t = threadIdx.x;
-    for (int e = t; e < J * 32; e += 256) {
-        int j = e >> 5, b = e & 31;
-        float s = b0[j];
-        for (int sp = 0; sp < NS; ++sp) s += part[((long)sp * J + j) * 32 + b];
-        hs[j * 33 + b] = fmaxf(s, 0.f);
-    }
-    __syncthreads();
-    const int g = t >> 5, b = t & 31;
-    for (int a = g; a < A; a += 8) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int j = 0; j < J; j += 4) {
-            s0 = fmaf(hs[(j + 0) * 33 + b], w1[(j + 0) * A + a], s0);
-            s1 = fmaf(hs[(j + 1) * 33 + b], w1[(j + 1) * A + a], s1);
-            s2 = fmaf(hs[(j + 2) * 33 + b], w1[(j + 2) * A + a], s2);
-            s3 = fmaf(hs[(j + 3) * 33 + b], w1[(j + 3) * A + a], s3);
-        }
-        qs[a * 32 + b] = ((s0 + s1) + (s2 + s3)) + b1[a];
-    }
-    __syncthreads();
-}
-
-// Inference variant: Q-values of one net for <= 32 states (idqn.py:131 / dqn.py:90 network.apply).
-struct HeadQArgs {
-    const float* part;
-    const float* const* wbase;
-    long b0_off, w1_off, b1_off;
-    int NS, J, A, n;
-    float* q_out;  // [n][A]
+// Inference head after k_hidden: q[b][a] = b1[a] + sum over the J / 32 chunk partials, and the greedy action (first
+// maximum, jnp.argmax) of every state.  One small workgroup; replaces the single-workgroup k_head_q (345 us) on the
+// acting path.
+struct QOutArgs {
+    const float* qpart;         // [1][1][J/32][32][32]
+    const float* const* wbase;  // [1]
+    long b1_off;
+    int NJC, A, n;
+    float* q_out;     // [n][A]
+    int32_t* action;  // [n] or nullptr
 };
-__global__ __launch_bounds__(256) void k_head_q(HeadQArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hs = lds;
-    float* qs = hs + a.J * 33;
+__global__ __launch_bounds__(256) void k_q_out(QOutArgs a) {
+    __shared__ float qs[32 * 32];
     const float* p = a.wbase[0];
-    head_hidden_and_q(hs, qs, a.part, p + a.b0_off, p + a.w1_off, p + a.b1_off, a.NS, a.J, a.A);
     for (int e = threadIdx.x; e < a.A * 32; e += 256) {
-        int ac = e >> 5, b = e & 31;
-        if (b < a.n) a.q_out[b * a.A + ac] = qs[e];
+        const int ac = e >> 5, b = e & 31;
+        float v = 0.f;
+        for (int c = 0; c < a.NJC; c += 4) {  // NJC is a multiple of 4; added in chunk order like k_td_dh
+            const float x0 = a.qpart[(c + 0) * 1024 + e], x1 = a.qpart[(c + 1) * 1024 + e];
+            const float x2 = a.qpart[(c + 2) * 1024 + e], x3 = a.qpart[(c + 3) * 1024 + e];
+            v = (((v + x0) + x1) + x2) + x3;
+        }
+        v += p[a.b1_off + ac];
+        qs[e] = v;
+        if (b < a.n) a.q_out[b * a.A + ac] = v;
+    }
+    __syncthreads();
+    if (a.action && (int)threadIdx.x < a.n) {
+        const int b = threadIdx.x;
+        int best = 0;
+        float bv = qs[b];
+        for (int ac = 1; ac < a.A; ++ac)
+            if (qs[ac * 32 + b] > bv) { bv = qs[ac * 32 + b]; best = ac; }
+        a.action[b] = best;
     }
 }
 

@@ -161,6 +161,7 @@ struct idqn_handle_s {
     NetSet train, infer;
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
+    float *infer_hbuf = nullptr, *infer_qpart = nullptr;  // k_hidden outputs of the single inference net
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
     long wt_stride[3] = {0, 0, 0};
     // bf16x3 conv path (conv3_kernels.h): packed weight planes of every training net and the 3-plane dout buffers
@@ -172,7 +173,6 @@ struct idqn_handle_s {
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
     SlabSeg segs[3];  // slab descriptors of the last backward (consumed by the fused Adam launch)
-    int head_lds = 0;
     // fc
     FcNet fc;
     float* fc_ws = nullptr;
@@ -320,6 +320,8 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
     if ((rc = alloc_zero(&h->hbuf, (long)2 * K * nb * h->J * 32, h, "h"))) return rc;
     if ((rc = alloc_zero(&h->qpart, (long)2 * K * nb * (h->J / 32) * 32 * 32, h, "qpart"))) return rc;
+    if ((rc = alloc_zero(&h->infer_hbuf, (long)h->J * 32, h, "infer_h"))) return rc;
+    if ((rc = alloc_zero(&h->infer_qpart, (long)(h->J / 32) * 32 * 32, h, "infer_qpart"))) return rc;
     for (int i = 1; i < 3; ++i) {
         const ConvL& cl = h->conv[i];
         IDQN_REQUIRE(cl.K % cl.S == 0, "conv %d: kernel %d not a multiple of stride %d", i, cl.K, cl.S);
@@ -358,9 +360,6 @@ int cnn_setup(idqn_handle_s* h) {
         slab_total += (long)h->npc[i] * K * h->slab_stride[i];
     }
     if ((rc = alloc_zero(&h->slab, slab_total, h, "slab"))) return rc;
-    // k_head_q needs > 64 KB of dynamic LDS at J = 512
-    h->head_lds = (h->J * 33 + 32 * 32 + 4 * 32) * 4;
-    IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_head_q, hipFuncAttributeMaxDynamicSharedMemorySize, h->head_lds));
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
     h->dominant = "k_dense0_wgrad";
@@ -1064,31 +1063,6 @@ extern "C" int idqn_target_sync(idqn_handle_t h, void* stream) {
     return IDQN_OK;
 }
 
-extern "C" int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
-                             float* q_out_dev, void* stream) {
-    IDQN_REQUIRE(h && states_dev && q_out_dev, "idqn_q_values: null pointer");
-    IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_q_values: bad head / which");
-    IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_q_values: n = %d, must be in [1, 32]", n);
-    hipStream_t q = (hipStream_t)stream;
-    const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
-    if (h->cfg.arch == IDQN_ARCH_CNN) {
-        hipLaunchKernelGGL(k_set_ptr, dim3(1), dim3(1), 0, q, h->infer.wbase, params);
-        int rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q);
-        if (rc) return rc;
-        HeadQArgs a;
-        a.part = h->infer.part; a.wbase = h->infer.wbase; a.b0_off = h->off_b0; a.w1_off = h->off_w1; a.b1_off = h->off_b1;
-        a.NS = h->NS; a.J = h->J; a.A = h->cfg.n_actions; a.n = n; a.q_out = q_out_dev;
-        hipLaunchKernelGGL(k_head_q, dim3(1), dim3(256), h->head_lds, q, a);
-    } else {
-        FcQArgs a;
-        a.net = h->fc; a.params = params; a.s = (const float*)states_dev; a.n = n; a.q_out = q_out_dev;
-        a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
-        hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
-    }
-    IDQN_HIP_CHECK(hipGetLastError());
-    return IDQN_OK;
-}
-
 // argmax over the actions of each row, first maximum on ties (jnp.argmax, idqn.py:131)
 __global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1102,14 +1076,46 @@ __global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t
     out[i] = best;
 }
 
+static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                         float* q_out_dev, int32_t* action_out_dev, void* stream) {
+    IDQN_REQUIRE(h && states_dev && q_out_dev, "idqn_q_values: null pointer");
+    IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_q_values: bad head / which");
+    IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_q_values: n = %d, must be in [1, 32]", n);
+    hipStream_t q = (hipStream_t)stream;
+    const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
+    if (h->cfg.arch == IDQN_ARCH_CNN) {
+        hipLaunchKernelGGL(k_set_ptr, dim3(1), dim3(1), 0, q, h->infer.wbase, params);
+        int rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q);
+        if (rc) return rc;
+        HiddenArgs hi;
+        hi.part = h->infer.part; hi.wbase = h->infer.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = 1;
+        hi.NS = h->NS; hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->infer_hbuf; hi.qpart = h->infer_qpart;
+        hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 1), dim3(256), 0, q, hi);
+        QOutArgs qo;
+        qo.qpart = h->infer_qpart; qo.wbase = h->infer.wbase; qo.b1_off = h->off_b1; qo.NJC = h->J / 32;
+        qo.A = h->cfg.n_actions; qo.n = n; qo.q_out = q_out_dev; qo.action = action_out_dev;
+        hipLaunchKernelGGL(k_q_out, dim3(1), dim3(256), 0, q, qo);
+    } else {
+        FcQArgs a;
+        a.net = h->fc; a.params = params; a.s = (const float*)states_dev; a.n = n; a.q_out = q_out_dev;
+        a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
+        hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
+        if (action_out_dev)
+            hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev);
+    }
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+extern "C" int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                             float* q_out_dev, void* stream) {
+    return q_values_impl(h, which, head, states_dev, n, q_out_dev, nullptr, stream);
+}
+
 extern "C" int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
                                 float* q_out_dev, int32_t* action_out_dev, void* stream) {
     IDQN_REQUIRE(action_out_dev, "idqn_best_action: null pointer");
-    int rc = idqn_q_values(h, which, head, states_dev, n, q_out_dev, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, (hipStream_t)stream, q_out_dev, n, h->cfg.n_actions, action_out_dev);
-    IDQN_HIP_CHECK(hipGetLastError());
-    return IDQN_OK;
+    return q_values_impl(h, which, head, states_dev, n, q_out_dev, action_out_dev, stream);
 }
 
 extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {
