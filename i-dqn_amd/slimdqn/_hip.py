@@ -110,9 +110,12 @@ def ptr(t):
 
 
 def current_stream():
+    """torch's current stream of the current device as a hipStream_t.  (Goes to the raw-stream call directly:
+    ``torch.cuda.current_stream()`` resolves the device index through several Python layers, 12 us per call, and the
+    step makes several calls.)"""
     import torch
 
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def make_config(arch, n_heads, n_actions, obs, features, max_batch, lr, eps, gamma_n, b1=0.9, b2=0.999):
