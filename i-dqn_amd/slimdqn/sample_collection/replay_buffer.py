@@ -142,7 +142,9 @@ class _MemoryView:
     """Read-only mapping ``key -> ReplayElement`` over the device store (what tests call ``_memory``)."""
 
     def __init__(self, rb):
-        self._rb = rb
+        import weakref
+
+        self._rb = weakref.proxy(rb)  # no reference cycle: dropping the buffer frees its HBM at once
 
     def keys(self):
         lo = max(0, self._rb.add_count - self._rb._max_capacity)
