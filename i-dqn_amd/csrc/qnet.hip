@@ -135,6 +135,7 @@ int build_layout(const idqn_config_t& c, Layout& L) {
 // One set of nets that run forward together: the 2K training nets, or the single inference net.
 struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
+    int NS = 0, rows_per_split = 0;  // split-K of this set's Dense_0 forward
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -217,8 +218,14 @@ int alloc_zero16(unsigned short** p, long n, idqn_handle_s* h, const char* name)
     return IDQN_OK;
 }
 
-int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag) {
+int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
+    s.NS = h->NS; s.rows_per_split = h->rows_per_split;
+    if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
+        const int units = h->F / 32;
+        s.rows_per_split = units_per_split * 32;
+        s.NS = (units + units_per_split - 1) / units_per_split;
+    }
     IDQN_HIP_CHECK(hipMalloc((void**)&s.wbase, sizeof(float*) * n_nets));
     IDQN_HIP_CHECK(hipMalloc((void**)&s.in_set, sizeof(int) * n_nets));
     IDQN_HIP_CHECK(hipMalloc((void**)&s.ident, sizeof(int) * n_nets));
@@ -232,7 +239,7 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     if ((rc = alloc_zero(&s.a1, (long)n_nets * nb * h->ga1.block, h, (t + "a1").c_str()))) return rc;
     if ((rc = alloc_zero(&s.a2, (long)n_nets * nb * h->ga2.block, h, (t + "a2").c_str()))) return rc;
     if ((rc = alloc_zero(&s.a3, (long)n_nets * nb * h->ga3.block, h, (t + "a3").c_str()))) return rc;
-    if ((rc = alloc_zero(&s.part, (long)n_nets * nb * h->NS * h->J * 32, h, (t + "part").c_str()))) return rc;
+    if ((rc = alloc_zero(&s.part, (long)n_nets * nb * s.NS * h->J * 32, h, (t + "part").c_str()))) return rc;
     return IDQN_OK;
 }
 
@@ -283,7 +290,7 @@ int cnn_setup(idqn_handle_s* h) {
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
-    if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_"))) return rc;
+    if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
     if (h->conv3) {
         NetSet& ts = h->train;
         if ((rc = alloc_zero16(&ts.x3, (long)2 * nb * h->gx.block * 3, h, "x3"))) return rc;
@@ -524,8 +531,8 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     }
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
-    d.n_nets = s.n_nets; d.nb = nb; d.NS = h->NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
-    d.rows_per_split = h->rows_per_split;
+    d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
+    d.rows_per_split = s.rows_per_split;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     IDQN_HIP_CHECK(hipGetLastError());
@@ -705,7 +712,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
     // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
     HiddenArgs hi;
-    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = h->NS;
+    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
     hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
     TdArgs ta;
@@ -1084,12 +1091,14 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     hipStream_t q = (hipStream_t)stream;
     const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
     if (h->cfg.arch == IDQN_ARCH_CNN) {
-        hipLaunchKernelGGL(k_set_ptr, dim3(1), dim3(1), 0, q, h->infer.wbase, params);
+        // the acting net's parameter pointer is entry (which * K + head) of the training table: no pointer upload
+        h->infer.wbase = h->train.wbase + (which * h->cfg.n_heads + head);
+        (void)params;
         int rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q);
         if (rc) return rc;
         HiddenArgs hi;
         hi.part = h->infer.part; hi.wbase = h->infer.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = 1;
-        hi.NS = h->NS; hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->infer_hbuf; hi.qpart = h->infer_qpart;
+        hi.NS = h->infer.NS; hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->infer_hbuf; hi.qpart = h->infer_qpart;
         hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 1), dim3(256), 0, q, hi);
         QOutArgs qo;
         qo.qpart = h->infer_qpart; qo.wbase = h->infer.wbase; qo.b1_off = h->off_b1; qo.NJC = h->J / 32;
