@@ -1162,4 +1162,3 @@ __global__ void k_step_epilogue(int32_t* count, const float* losses, double* cum
     cum[k] = cum[k] + (double)losses[k];
 }
 
-__global__ void k_set_ptr(const float** dst, const float* v) { *dst = v; }
