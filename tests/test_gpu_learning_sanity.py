@@ -74,3 +74,67 @@ def test_agents_learn_the_one_step_task(algo):
     assert (hits / 200 >= 0.95).all(), hits / 200
     logs = [r for r in p["wandb"].records if "loss" in r]
     assert logs and logs[-1]["loss"] < logs[0]["loss"]  # the TD loss went down over the run
+
+
+class QuadrantFrames:
+    """Atari-protocol environment (``state`` = stack of 4 frames, ``observation`` = newest frame): the newest frame
+    has one bright quadrant; the rewarded action is that quadrant's index.  Two-step episodes as above."""
+
+    def __init__(self, seed, size=20):
+        self.rng = np.random.default_rng(seed)
+        self.size, self.n_actions = size, 4
+        self.state_height = self.state_width = size
+        self.n_stacked_frames = 4
+        self.n_steps = 0
+
+    def _frame(self):
+        self.target = int(self.rng.integers(4))
+        f = self.rng.integers(0, 40, (self.size, self.size), dtype=np.uint8)
+        h = self.size // 2
+        r, c = divmod(self.target, 2)
+        f[r * h : (r + 1) * h, c * h : (c + 1) * h] += 200
+        return f
+
+    @property
+    def observation(self):
+        return np.copy(self.state[:, :, -1])
+
+    def reset(self):
+        self.state = np.zeros((self.size, self.size, 4), np.uint8)
+        self.state[:, :, -1] = self._frame()
+        self.n_steps = 0
+
+    def step(self, action):
+        reward = 1.0 if int(action) == self.target else 0.0
+        self.n_steps += 1
+        self.state = np.concatenate([self.state[:, :, 1:], self._frame()[:, :, None]], axis=2)
+        return reward, self.n_steps >= 2
+
+
+@pytest.mark.parametrize("conv", ["f32", "bf16x3"])
+def test_cnn_heads_learn_from_pixels(conv, monkeypatch):
+    from experiments.base.dqn import train
+    from experiments.base.utils import NullLogger
+    from slimdqn import prng
+    from slimdqn.networks.idqn import iDQN
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer
+    from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+
+    monkeypatch.setenv("IDQN_CONV", conv)
+    p = {"epsilon_end": 0.05, "epsilon_duration": 1000, "n_epochs": 1, "n_training_steps_per_epoch": 3000,
+         "n_initial_samples": 200, "horizon": 10, "wandb": NullLogger()}
+    env = QuadrantFrames(0)
+    rb = ReplayBuffer(UniformSamplingDistribution(0), batch_size=32, max_capacity=4000, stack_size=4, update_horizon=1,
+                      gamma=0.99)
+    q_key, train_key = prng.split(prng.PRNGKey(1))
+    agent = iDQN(q_key, (20, 20, 4), 4, n_networks=2, features=[32, 32, 32, 128], architecture_type="cnn",
+                 learning_rate=3e-4, gamma=0.99, update_horizon=1, update_to_data=1, target_update_frequency=100,
+                 target_sync_frequency=10, adam_eps=1.5e-4)
+    train(train_key, p, agent, env, rb)
+    test_env, hits = QuadrantFrames(77), np.zeros(2)
+    for _ in range(100):
+        test_env.reset()
+        test_env.step(0)  # a state with two real frames
+        for k in range(2):
+            hits[k] += int(agent.q_values(agent.params, test_env.state, k)[0].argmax().item()) == test_env.target
+    assert (hits / 100 >= 0.9).all(), hits / 100
