@@ -112,3 +112,23 @@ def test_batched_fp32_cpu_baseline_matches_fp64_oracle():
     np.testing.assert_allclose(losses32, losses64, atol=1e-5)
     for n in p:
         np.testing.assert_allclose(step.p[n].detach().numpy(), new_p[n], atol=2e-6)
+
+
+def test_adam_restatement_matches_torch_optim_adam_over_many_steps():
+    """optax.adam(lr, b1=.9, b2=.999, eps, eps_root=0) and torch.optim.Adam(lr, betas, eps) are the same recurrence
+    (bias-corrected moments, eps outside the square root): an independent implementation must reproduce the oracle's
+    `adam_update` step for step."""
+    import torch
+
+    rng = np.random.default_rng(0)
+    theta0 = rng.standard_normal(50)
+    grads = rng.standard_normal((25, 50)) * np.exp(rng.uniform(-6, 2, (25, 1)))
+    lr, eps = 6.25e-5, 1.5e-4
+    th, m, v = theta0.copy(), np.zeros(50), np.zeros(50)
+    p = torch.nn.Parameter(torch.from_numpy(theta0.copy()))
+    opt = torch.optim.Adam([p], lr=lr, betas=(0.9, 0.999), eps=eps)
+    for t, g in enumerate(grads):
+        th, m, v = Q.adam_update(th, g, m, v, t, lr, eps)
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        np.testing.assert_allclose(th, p.detach().numpy(), rtol=1e-12, atol=1e-15)
