@@ -678,14 +678,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         h->ev_used += 2;
     }
     h->mix_done = false; h->mix_stage = 0;
-    if (fuse_adam && nq == 2 && h->mix_mode == 2 && allow_mix && nb_total == nb_inner && h->conv[0].CO == 32 && h->conv[0].K * h->conv[0].CI == 32 &&
+    if (fuse_adam && nq == 2 && h->mix_mode == 2 && !h->conv3_bwd && allow_mix && nb_total == nb_inner && h->conv[0].CO == 32 && h->conv[0].K * h->conv[0].CI == 32 &&
         h->conv[1].CI == 32 && h->conv[1].CO == 64 && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
         int rcb = build_dgrad_weights(h, q);  // the data gradients start in this very launch
         if (rcb) return rcb;
         h->mix_dw = dw; h->mix_d0_next = 0; h->mix_stage = 1;
         return launch_mix_stage(h, 2, nb_total, q, e0, e1);
     }
-    if (fuse_adam && nq == 2 && h->mix && allow_mix && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
+    if (fuse_adam && nq == 2 && h->mix && !h->conv3_bwd && allow_mix && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
         ConvWgradArgs cw = make_wgrad_args(h, 2, nb_total);
         const long n_all = dw.n_items + cw.n_items;
         int period = (int)(n_all / cw.n_items);
