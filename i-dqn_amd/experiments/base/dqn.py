@@ -1,6 +1,9 @@
-"""Trainer loop with the reference's call sequence (``experiments/base/dqn.py:12-69``): per environment step
-split the key, collect one sample, and once ``n_initial_samples`` are in, ``update_online_params`` then
-``update_target_params``; log on target updates and per epoch; save the model per epoch.
+"""Trainer loop of the HIP build.
+
+Interface and event order follow the reference's ``experiments/base/dqn.py:12-69`` -- per environment step: split the
+key, collect one sample, and once ``n_initial_samples`` are in, ``update_online_params`` then
+``update_target_params``; a log record on every target update and at every epoch end; the model saved per epoch -- but
+the loop is organised as a small state machine (``EpochStats`` + ``Trainer``) instead of one nested loop.
 
 ``p["wandb"]`` only needs ``.log(dict)``; ``experiments.base.utils.NullLogger`` stands in when wandb is absent.
 """
@@ -10,38 +13,69 @@ from slimdqn import prng
 from slimdqn.sample_collection.utils import collect_single_sample, linear_schedule
 
 
+class EpochStats:
+    """Returns and lengths of the episodes of one epoch; the last entry is the episode in progress."""
+
+    def __init__(self):
+        self.returns, self.lengths = [0], [0]
+
+    def record(self, reward):
+        self.returns[-1] += reward
+        self.lengths[-1] += 1
+
+    def open_episode(self):
+        self.returns.append(0)
+        self.lengths.append(0)
+
+    def summary(self):
+        return float(np.mean(self.returns)), float(np.mean(self.lengths)), len(self.lengths)
+
+
+class Trainer:
+    def __init__(self, key, p, agent, env, rb, save_fn=None):
+        self.key, self.p, self.agent, self.env, self.rb, self.save_fn = key, p, agent, env, rb, save_fn
+        self.epsilon = linear_schedule(1.0, p["epsilon_end"], p["epsilon_duration"])
+        self.total_steps = 0
+        self.history = []  # one EpochStats per epoch
+
+    def _environment_step(self):
+        self.key, explore_key = prng.split(self.key)
+        return collect_single_sample(explore_key, self.env, self.agent, self.rb, self.p, self.epsilon, self.total_steps)
+
+    def _gradient_step(self):
+        self.agent.update_online_params(self.total_steps, self.rb)
+        updated, logs = self.agent.update_target_params(self.total_steps)
+        if updated:
+            self.p["wandb"].log({"n_training_steps": self.total_steps, **logs})
+
+    def run_epoch(self, index):
+        stats, budget, done, just_reset = EpochStats(), self.p["n_training_steps_per_epoch"], 0, False
+        self.history.append(stats)
+        # an epoch always ends on an episode boundary (experiments/base/dqn.py:29)
+        while done < budget or not just_reset:
+            reward, just_reset = self._environment_step()
+            done += 1
+            self.total_steps += 1
+            stats.record(reward)
+            if just_reset and done < budget:
+                stats.open_episode()
+            if self.total_steps > self.p["n_initial_samples"]:
+                self._gradient_step()
+        avg_return, avg_length, n_episodes = stats.summary()
+        print(f"\nEpoch {index}: Return {avg_return} averaged on {n_episodes} episodes.\n", flush=True)
+        self.p["wandb"].log({"epoch": index, "n_training_steps": self.total_steps, "avg_return": avg_return,
+                             "avg_length_episode": avg_length})
+        if self.save_fn is not None:
+            self.save_fn(self.p, [s.returns for s in self.history], [s.lengths for s in self.history],
+                         self.agent.get_model())
+
+    def run(self):
+        self.env.reset()
+        for index in range(self.p["n_epochs"]):
+            self.run_epoch(index)
+        return [s.returns for s in self.history], [s.lengths for s in self.history]
+
+
 def train(key, p: dict, agent, env, rb, save_fn=None):
-    epsilon_schedule = linear_schedule(1.0, p["epsilon_end"], p["epsilon_duration"])
-    n_training_steps = 0
-    env.reset()
-    episode_returns_per_epoch, episode_lengths_per_epoch = [[0]], [[0]]
-    for idx_epoch in range(p["n_epochs"]):
-        n_training_steps_epoch, has_reset = 0, False
-        while n_training_steps_epoch < p["n_training_steps_per_epoch"] or not has_reset:
-            key, exploration_key = prng.split(key)
-            reward, has_reset = collect_single_sample(exploration_key, env, agent, rb, p, epsilon_schedule,
-                                                      n_training_steps)
-            n_training_steps_epoch += 1
-            n_training_steps += 1
-            episode_returns_per_epoch[idx_epoch][-1] += reward
-            episode_lengths_per_epoch[idx_epoch][-1] += 1
-            if has_reset and n_training_steps_epoch < p["n_training_steps_per_epoch"]:
-                episode_returns_per_epoch[idx_epoch].append(0)
-                episode_lengths_per_epoch[idx_epoch].append(0)
-            if n_training_steps > p["n_initial_samples"]:
-                agent.update_online_params(n_training_steps, rb)
-                target_updated, logs = agent.update_target_params(n_training_steps)
-                if target_updated:
-                    p["wandb"].log({"n_training_steps": n_training_steps, **logs})
-        avg_return = np.mean(episode_returns_per_epoch[idx_epoch])
-        avg_length_episode = np.mean(episode_lengths_per_epoch[idx_epoch])
-        print(f"\nEpoch {idx_epoch}: Return {avg_return} averaged on "
-              f"{len(episode_lengths_per_epoch[idx_epoch])} episodes.\n", flush=True)
-        p["wandb"].log({"epoch": idx_epoch, "n_training_steps": n_training_steps, "avg_return": avg_return,
-                        "avg_length_episode": avg_length_episode})
-        if idx_epoch < p["n_epochs"] - 1:
-            episode_returns_per_epoch.append([0])
-            episode_lengths_per_epoch.append([0])
-        if save_fn is not None:
-            save_fn(p, episode_returns_per_epoch, episode_lengths_per_epoch, agent.get_model())
-    return episode_returns_per_epoch, episode_lengths_per_epoch
+    """Same call as the reference's ``train`` (``experiments/base/dqn.py:12``); returns (returns, lengths) per epoch."""
+    return Trainer(key, p, agent, env, rb, save_fn).run()

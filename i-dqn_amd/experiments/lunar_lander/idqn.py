@@ -1,33 +1,12 @@
-"""LunarLander i-DQN entry point with the reference's wiring (``experiments/lunar_lander/idqn.py:15-44``):
-stack size 1, integer ``observation_dim``, default ``adam_eps``.  ``env`` defaults to a synthetic 8-dim
-vector environment (Box2D is not part of this build)."""
+"""`python experiments/lunar_lander/idqn.py -en NAME -s SEED ...` -- counterpart of the reference's entry point of the same
+path; the wiring lives in experiments/base/launch.py.  ``env`` defaults to the synthetic stand-in environment."""
 import sys
 
-from experiments.base.dqn import train
-from experiments.base.utils import prepare_logs, save_data
-from slimdqn import prng
-from slimdqn.networks.idqn import iDQN
-from slimdqn.sample_collection.replay_buffer import ReplayBuffer
-from slimdqn.sample_collection.samplers import UniformSamplingDistribution
+from experiments.base.launch import launch
 
 
 def run(argvs=sys.argv[1:], env=None, save_root=None):
-    p = prepare_logs("lunar_lander", "idqn", argvs, save_root)
-    q_key, train_key = prng.split(prng.PRNGKey(p["seed"]))
-    if env is None:
-        from slimdqn.environments.synthetic import SyntheticVector
-
-        env = SyntheticVector(p["seed"])
-    rb = ReplayBuffer(sampling_distribution=UniformSamplingDistribution(p["seed"]), batch_size=p["batch_size"],
-                      max_capacity=p["replay_buffer_capacity"], stack_size=1, update_horizon=p["update_horizon"],
-                      gamma=p["gamma"], compress=True)
-    agent = iDQN(q_key, env.observation_shape[0], env.n_actions, n_networks=p["n_networks"], features=p["features"],
-                 architecture_type=p["architecture_type"], learning_rate=p["learning_rate"], gamma=p["gamma"],
-                 update_horizon=p["update_horizon"], update_to_data=p["update_to_data"],
-                 target_update_frequency=p["target_update_frequency"],
-                 target_sync_frequency=p["target_sync_frequency"])
-    train(train_key, p, agent, env, rb, save_fn=save_data)
-    return p, agent
+    return launch("lunar_lander", "idqn", argvs, env=env, save_root=save_root)
 
 
 if __name__ == "__main__":

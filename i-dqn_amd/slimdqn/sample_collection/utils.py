@@ -1,45 +1,51 @@
-"""Action selection and sample collection -- the other device call per environment step.
+"""Acting and sample collection -- the other device call of an environment step.
 
-Mirrors the reference's ``slimdqn/sample_collection/utils.py:8-40``: epsilon-greedy over a key split three ways
-(uniform draw, random action, kwargs key for ``best_action``), then one environment step into the replay buffer.
-The greedy branch is one batch-1 forward of a head on the HIP path (``idqn_q_values``); ``.item()`` is the
-reference's device->host sync (``utils.py:21``).
+Same entry points as the reference's ``slimdqn/sample_collection/utils.py:8-40`` (``select_action``,
+``collect_single_sample``): the key is split three ways (exploration draw, random action, key handed to
+``best_action``); the greedy branch is one batch-1 forward of a head on the HIP path (``idqn_best_action``) whose
+``.item()`` is the device -> host sync the reference has at ``utils.py:21``.
 """
 from slimdqn import prng
 from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
 
 
-class _HostAction(int):
+class HostAction(int):
+    """A host-side action that answers ``.item()`` like the device scalar of the greedy branch."""
+
     def item(self):
         return int(self)
 
 
-def select_action(best_action_fn, params, state, key, n_actions, epsilon_fn, n_training_steps):
-    uniform_key, action_key, kwargs_key = prng.split(key, 3)
-    if prng.uniform(uniform_key) <= epsilon_fn(n_training_steps):
-        return _HostAction(prng.randint(action_key, 0, n_actions))  # random action
-    return best_action_fn(params, state, key=kwargs_key)  # greedy action (device scalar)
-
-
 def linear_schedule(init_value: float, end_value: float, transition_steps):
     """optax.linear_schedule (experiments/base/dqn.py:19): linear from init to end over transition_steps, then flat."""
+    span = init_value - end_value
 
-    def schedule(count):
-        frac = 1.0 - min(max(count, 0), transition_steps) / transition_steps if transition_steps > 0 else 0.0
-        return (init_value - end_value) * frac + end_value
+    def value_at(count):
+        if transition_steps <= 0:
+            return end_value
+        progress = min(max(count, 0), transition_steps) / transition_steps
+        return end_value + span * (1.0 - progress)
 
-    return schedule
+    return value_at
+
+
+def select_action(best_action_fn, params, state, key, n_actions, epsilon_fn, n_training_steps):
+    explore_key, random_action_key, greedy_key = prng.split(key, 3)
+    exploring = prng.uniform(explore_key) <= epsilon_fn(n_training_steps)
+    if exploring:
+        return HostAction(prng.randint(random_action_key, 0, n_actions))
+    return best_action_fn(params, state, key=greedy_key)  # device scalar
 
 
 def collect_single_sample(key, env, agent, rb: ReplayBuffer, p, epsilon_schedule, n_training_steps: int):
+    """One environment step into the replay buffer; returns ``(reward, episode_ended)``."""
+    observation = env.observation  # the frame BEFORE the action goes with it (utils.py:27-35)
     action = select_action(agent.best_action, agent.params, env.state, key, env.n_actions, epsilon_schedule,
                            n_training_steps).item()
-    obs = env.observation
     reward, absorbing = env.step(action)
-    episode_end = absorbing or env.n_steps >= p["horizon"]
-    rb.add(TransitionElement(observation=obs, action=action,
-                             reward=reward if rb._clipping is None else rb._clipping(reward),
-                             is_terminal=absorbing, episode_end=episode_end))
-    if episode_end:
+    ended = bool(absorbing) or env.n_steps >= p["horizon"]
+    stored_reward = rb._clipping(reward) if rb._clipping is not None else reward
+    rb.add(TransitionElement(observation, action, stored_reward, absorbing, ended))
+    if ended:
         env.reset()
-    return reward, episode_end
+    return reward, ended
