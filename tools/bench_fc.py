@@ -1,15 +1,19 @@
+"""Step time of the MLP (LunarLander-style) i-DQN step and the latency of acting with it."""
 import os, sys, time
-ROOT = "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
 import numpy as np, torch
 from collections import namedtuple
 from slimdqn.networks.idqn import iDQN
-from oracle import qnet_ref as Q
 Batch = namedtuple("Batch", "state action reward next_state is_terminal")
 for K, feats in ((3, [100, 100]), (5, [200, 200]), (16, [100, 100])):
     agent = iDQN(0, 8, 4, K, feats, "fc", 3e-4, 0.99, 1, 1, 10**9, 10**9)
-    b = Batch(*(torch.from_numpy(np.asarray(x)).cuda() for x in Q.synthetic_batch(0, 32, 8, 4, "fc")))
-    b = Batch(b.state.float(), b.action.int(), b.reward.float(), b.next_state.float(), b.is_terminal.to(torch.uint8))
+    rng = np.random.default_rng(0)
+    b = Batch(torch.from_numpy(rng.standard_normal((32, 8)).astype(np.float32)).cuda(),
+              torch.from_numpy(rng.integers(0, 4, 32).astype(np.int32)).cuda(),
+              torch.from_numpy(rng.standard_normal(32).astype(np.float32)).cuda(),
+              torch.from_numpy(rng.standard_normal((32, 8)).astype(np.float32)).cuda(),
+              torch.from_numpy((rng.random(32) < 0.05).astype(np.uint8)).cuda())
     for _ in range(50): agent._learn(b)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 2000
