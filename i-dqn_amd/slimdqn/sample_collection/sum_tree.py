@@ -42,6 +42,16 @@ class SumTree:
             "sumtree_set")
 
     def set(self, indices, values) -> None:
+        if isinstance(indices, (int, np.integer)) and isinstance(values, (int, float, np.floating)):
+            # one leaf (what every add / remove of the prioritized sampler does): index and value travel as kernel
+            # arguments, no upload -- same arithmetic as the vector path for n = 1
+            assert values >= 0.0, "Values must be positive."
+            if not 0 <= int(indices) < self._nodes_dev.numel() - self._first_leaf_offset:
+                raise IndexError("sum tree index out of range")
+            self.max_recorded_priority = max(self.max_recorded_priority, values)
+            _hip.check(_hip.lib().sumtree_set_one(_hip.ptr(self._nodes_dev), self._depth, int(indices), float(values), None,
+                                                  _hip.current_stream()), "sumtree_set_one")
+            return
         if isinstance(indices, (int, np.integer)):
             indices = np.asarray([indices], np.int32)
         if isinstance(values, (int, float, np.floating)):
