@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _worker(rank, world, port, mode, out):
+def _worker(rank, world, port, mode, out, name="cnn_atari_a18_b64"):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,7 +35,7 @@ def _worker(rank, world, port, mode, out):
         from slimdqn.networks.parallel import data_parallel_step, shard_of
         from test_gpu_fp_path import _agent
 
-        agent, bs, rec, _ = _agent("cnn_atari_a18_b64")
+        agent, bs, rec, _ = _agent(name)
         losses = None
         for batch in bs:
             kw = dict(mode="factored") if mode == "factored" else dict(mode="allreduce", overlap=(mode == "overlap"))
@@ -48,15 +48,16 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["factored", "overlap", "plain"])
-def test_two_rank_step_equals_the_single_device_step(tmp_path, mode):
+@pytest.mark.parametrize("mode,name", [("factored", "cnn_atari_a18_b64"), ("overlap", "cnn_atari_a18_b64"),
+                                       ("plain", "cnn_atari_a18_b64"), ("plain", "fc_lunar_k3")])
+def test_two_rank_step_equals_the_single_device_step(tmp_path, mode, name):
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
-    rec = json.load(open(os.path.join(GOLDEN, "fp_path_cnn_atari_a18_b64.json")))
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path), name), nprocs=2, join=True)
+    rec = json.load(open(os.path.join(GOLDEN, f"fp_path_{name}.json")))
     n_steps = len(rec["steps"])
     last = rec["steps"][n_steps - 1]
     got = [np.load(f"{tmp_path}/rank{r}.npz") for r in range(2)]
