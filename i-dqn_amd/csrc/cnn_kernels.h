@@ -17,7 +17,7 @@
 // LDS; weight gradient + Adam: MFMA tile parked in LDS, then whole-row streaming of theta / m / v).
 // f32 MFMA is 64 FLOP/clk/SIMD: one dword of each operand per 64-cycle instruction.
 #pragma once
-#include "common.h"
+#include "convp.h"
 
 struct ActGeom {
     int H, W, C;        // logical extent
@@ -31,26 +31,9 @@ struct ActGeom {
 // minibatch tile is transposed in LDS so that both the HBM read and the HBM write are coalesced)
 // architectures/dqn.py:44  `jnp.array(x, ndmin=4) / 255.0`
 // --------------------------------------------------------------------------------------------
-// exact three-way bf16 split of an f32 value into a 3-plane row [plane][32] (see conv3_kernels.h)
-__device__ __forceinline__ unsigned short idqn_bf16_rne(float x) {
-    unsigned int u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ void prep_store3(unsigned short* row, int col, float v) {
-    const unsigned short h0 = idqn_bf16_rne(v);
-    float r = v - __uint_as_float((unsigned int)h0 << 16);
-    const unsigned short h1 = idqn_bf16_rne(r);
-    r = r - __uint_as_float((unsigned int)h1 << 16);
-    row[col] = h0;
-    row[32 + col] = h1;
-    row[64 + col] = idqn_bf16_rne(r);
-}
-
 struct PrepArgs {
     const uint8_t* src[2];  // state, next_state  [B][E]
     float* x;               // [n_sets][nb][g.block]
-    unsigned short* x3;     // the same rows as three bf16 planes (conv3_kernels.h) or nullptr
     long E;                 // H*W*C
     int B, nb, n_sets;
     ActGeom g;
@@ -85,7 +68,6 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
     }
     __syncthreads();
     float* x = a.x + ((long)set * a.nb + bb) * a.g.block;
-    unsigned short* x3 = a.x3 ? a.x3 + ((long)set * a.nb + bb) * a.g.block * 3 : nullptr;
     const int b = t & 31;
     // (h, w, c) of this thread's first element by 32-bit division once; its later elements are 8 further on
     const int E32 = (int)a.E, WC = a.g.W * a.g.C;
@@ -98,7 +80,6 @@ __global__ __launch_bounds__(256) void k_prep_u8(PrepArgs a) {
         if (e < E32) {
             const long row = ((long)(hh + a.g.lo_h) * a.g.Wp + (w + a.g.lo_w)) * a.g.C + c;
             x[row * 32 + b] = tile[el][b];
-            if (x3) prep_store3(x3 + row * 96, b, tile[el][b]);
         }
         e += 8;
         c += 8;
@@ -628,8 +609,9 @@ __global__ __launch_bounds__(256) void k_q_out(QOutArgs a) {
 struct DenseDgradArgs {
     const float* dh;   // [K][nb][J][32]
     const float* a3;   // [2K][nb][F*32]  (online nets first)
-    float* da3;        // [K][nb][g.block]
-    unsigned short* da3_3;  // the same rows as three bf16 planes or nullptr
+    float* da3;        // [K][nb][g.block] f32 rows or nullptr (plane path)
+    unsigned short* da3p;  // the same pixels as three bf16 planes (convp.h layout, geometry g) or nullptr
+    float* pb;             // [K * nb][H * W][C] sums of da3 over the 32 samples (Conv_2 bias gradient) or nullptr
     const float* const* wbase;
     long w_off, n_items;
     int K, nb, n_ft, F, J, C;  // C = channels of a3 (f = pos*C + c)
@@ -639,8 +621,10 @@ struct DenseDgradArgs {
 template <int WAVES>  // f tiles (= waves) per workgroup: 4, or 3 when that fills the chip more evenly
 __global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
     // workgroup = WAVES consecutive f tiles of one (head, batch block).  dh (J x 32, <= 64 KB) is staged once
-    // by LDS-DMA and shared by the waves (B operand: conflict-free ds_read_b32); the W rows (A operand,
-    // 16 floats per lane and chunk) stream from HBM with register double buffering.
+    // by LDS-DMA and shared by the waves (A operand, rows = samples: conflict-free ds_read_b32); the W rows (B operand,
+    // columns = the tile's 32 f rows, 16 floats per lane and chunk) stream from HBM with register double buffering.
+    // D[b][f]: a lane ends up with ONE row f and 4 x 4 consecutive samples -- float4 mask loads / stores, 8-byte plane
+    // pieces, and the sum over the samples is 15 adds and one cross-half shuffle.
     extern __shared__ __attribute__((aligned(16))) float dlds[];  // [J][32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     const int n_wg_ft = (a.n_ft + WAVES - 1) / WAVES;
@@ -666,10 +650,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
     _Pragma("unroll") for (int u = 0; u < 4; ++u) wv[s][u] = *reinterpret_cast<const float4*>(W + (c) * 32 + 4 * u);
 #define D0D_MMA(c, s)                                                          \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                            \
-        acc = mfma32(wv[s][u].x, D[((c) * 32 + 4 * u + 0) * 32], acc);         \
-        acc = mfma32(wv[s][u].y, D[((c) * 32 + 4 * u + 1) * 32], acc);         \
-        acc = mfma32(wv[s][u].z, D[((c) * 32 + 4 * u + 2) * 32], acc);         \
-        acc = mfma32(wv[s][u].w, D[((c) * 32 + 4 * u + 3) * 32], acc);         \
+        acc = mfma32(D[((c) * 32 + 4 * u + 0) * 32], wv[s][u].x, acc);         \
+        acc = mfma32(D[((c) * 32 + 4 * u + 1) * 32], wv[s][u].y, acc);         \
+        acc = mfma32(D[((c) * 32 + 4 * u + 2) * 32], wv[s][u].z, acc);         \
+        acc = mfma32(D[((c) * 32 + 4 * u + 3) * 32], wv[s][u].w, acc);         \
     }
     D0D_LOAD(0, 0)
     D0D_LOAD(1, 1)
@@ -687,20 +671,47 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
 #undef D0D_LOAD
 #undef D0D_MMA
     if (!live) return;
-    const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32;
-    float* O = a.da3 + ((long)k * a.nb + bb) * a.g.block;
-    const int pos = f0 / a.C, c0 = f0 - pos * a.C;
+    // this lane: row f = f0 + bl, samples (r & 3) + 8 (r >> 2) + 4 h
+    const int f = f0 + bl;
+    const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)f * 32 + 4 * h;
+    float4 mk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mk[g] = *reinterpret_cast<const float4*>(A3 + 8 * g);
+    float val[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        val[4 * g + 0] = mk[g].x > 0.f ? acc[4 * g + 0] : 0.f;
+        val[4 * g + 1] = mk[g].y > 0.f ? acc[4 * g + 1] : 0.f;
+        val[4 * g + 2] = mk[g].z > 0.f ? acc[4 * g + 2] : 0.f;
+        val[4 * g + 3] = mk[g].w > 0.f ? acc[4 * g + 3] : 0.f;
+    }
+    const int pos = f / a.C, c = f - pos * a.C;
     const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
-    const long row0 = ((long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w)) * a.C + c0;
-    float mk[16];  // all mask loads first: interleaved with the stores they would serialise (may-alias)
+    const long pix = (long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w);
+    if (a.da3) {
+        float* O = a.da3 + ((long)k * a.nb + bb) * a.g.block + (pix * a.C + c) * 32 + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mk[r] = A3[(long)(f0 + mfma_row(r, h)) * 32 + bl];
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(O + 8 * g) = make_float4(val[4 * g], val[4 * g + 1], val[4 * g + 2], val[4 * g + 3]);
+    }
+    if (a.da3p) {
+        unsigned short* O = a.da3p + ((long)k * a.nb + bb) * a.g.block * 3 + pix * (3L * a.C * 32) + (long)c * 32 + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[(row0 + mfma_row(r, h)) * 32 + bl] = mk[r] > 0.f ? acc[r] : 0.f;
-    if (a.da3_3) {
-        unsigned short* O3 = a.da3_3 + ((long)k * a.nb + bb) * a.g.block * 3;
+        for (int g = 0; g < 4; ++g) {
+            unsigned q0a, q1a, q2a, q0b, q1b, q2b;
+            split3_pk(val[4 * g + 0], val[4 * g + 1], q0a, q1a, q2a);
+            split3_pk(val[4 * g + 2], val[4 * g + 3], q0b, q1b, q2b);
+            *reinterpret_cast<uint2*>(O + 8 * g) = make_uint2(q0a, q0b);
+            *reinterpret_cast<uint2*>(O + (long)a.C * 32 + 8 * g) = make_uint2(q1a, q1b);
+            *reinterpret_cast<uint2*>(O + 2L * a.C * 32 + 8 * g) = make_uint2(q2a, q2b);
+        }
+    }
+    if (a.pb) {
+        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) prep_store3(O3 + (row0 + mfma_row(r, h)) * 96, bl, mk[r] > 0.f ? acc[r] : 0.f);
+        for (int r = 0; r < 16; ++r) s += val[r];
+        s += __shfl_xor(s, 32);
+        if (h == 0) a.pb[(((long)k * a.nb + bb) * (a.g.H * a.g.W) + pos) * a.C + c] = s;
     }
 }
 
@@ -996,59 +1007,6 @@ template <int NIT, int NOT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36];
     conv_wgrad_body<NIT, NOT>(a, xcd_contiguous_id(), lds);
-}
-
-// ---- experiment (IDQN_MIX=2): the fused Dense_0 update spread over the three stages of the conv backward ----
-// One launch = a slice [d0_first, d0_first + d0_count) of the fused Dense_0 workgroups + the weight gradient of one
-// conv layer (+ the data gradient of the same stage when CT > 0), cw / cf alternating while both last; dynamic LDS =
-// the largest role's need.
-template <int NQ, int NIT, int NOT, int CT>
-__global__ __launch_bounds__(256) void k_mix_stage(DenseWgradArgs a, int d0_first, int d0_count, ConvWgradArgs cw,
-                                                   ConvFwdArgs cf, int period) {
-    extern __shared__ __attribute__((aligned(16))) float mix_lds[];
-    // conv-type workgroups are spread evenly through the grid (Bresenham): c(b) = floor(b m / N) of them lie before
-    // block b, and block b is one iff c(b + 1) > c(b); any ratio works and every XCD gets its share of both kinds
-    const long b = blockIdx.x, N = gridDim.x;
-    const int n_cw = (int)cw.n_items, n_cf = CT > 0 ? (int)cf.n_items : 0, m = n_cw + n_cf;
-    (void)period;
-    const int s = (int)(b * m / N);
-    if ((int)((b + 1) * m / N) > s) {
-        const int both = 2 * min(n_cw, n_cf);  // while both roles last they alternate
-        if (s < both) {
-            if ((s & 1) == 0) conv_wgrad_body<NIT, NOT>(cw, s >> 1, mix_lds);
-            else if (CT > 0) conv_fwd_body<(CT > 0 ? CT : 1), 1>(cf, s >> 1, mix_lds);
-        } else if (n_cw > n_cf) {
-            conv_wgrad_body<NIT, NOT>(cw, s - n_cf, mix_lds);
-        } else if (CT > 0) {
-            conv_fwd_body<(CT > 0 ? CT : 1), 1>(cf, s - n_cw, mix_lds);
-        }
-    } else {
-        const int local = (int)(b - s);
-        if (local < d0_count) dense0_wgrad_body<true, NQ>(a, d0_first + local, mix_lds);
-    }
-}
-
-// ---- experiment: the HBM-bound fused Dense_0 update and the MFMA-bound Conv_2 weight gradient in ONE launch ----
-// Both only need what the head / Dense_0 data gradient produced; they stress different parts of the chip, and a
-// single grid mixes their workgroups on every CU without the cross-queue synchronisation two streams cost.
-// Workgroup b is a conv workgroup when b % period == period - 1 (while any are left), else the next Dense_0 one.
-template <int NQ, int NIT, int NOT>
-__global__ __launch_bounds__(256) void k_mix_dense0_convw(DenseWgradArgs a, ConvWgradArgs c, int period) {
-    constexpr int LA = 32 * 128 * NQ, LC = 2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36;
-    __shared__ __attribute__((aligned(16))) float smem[LA > LC ? LA : LC];
-    // conv slots sit at b = period - 1, 2 period - 1, ... until the n_c conv workgroups are placed (the host picks
-    // period <= (n_a + n_c) / n_c, so they all fit); floor(b / period) slots lie before block b
-    const int b = blockIdx.x, n_c = (int)c.n_items;
-    const int slots_before = b / period;
-    if ((b % period) == period - 1 && slots_before < n_c) {
-        // XCD-contiguous conv index: consecutive slots land on consecutive XCDs, like consecutive block ids do
-        const int q = n_c >> 3, r = n_c & 7, x = slots_before & 7;
-        const int item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (slots_before >> 3);
-        conv_wgrad_body<NIT, NOT>(c, item, smem);
-    } else {
-        const int item = b - min(n_c, slots_before);
-        dense0_wgrad_body<true, NQ>(a, item, smem);
-    }
 }
 
 // slab reduce for all conv layers in ONE launch: grad[k][off + e] = sum_pc slab[pc][k][e]  (fixed order)

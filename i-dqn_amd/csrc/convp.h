@@ -1,0 +1,138 @@
+// Convolutions of the Nature-CNN on the bf16 matrix cores with f32 accuracy ("plane" kernels, gfx950).
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (MI355X_MICROARCH.md: 64 vs 1024 FLOP/clk/SIMD) and
+// gfx950 has no xf32.  Every f32 operand is therefore split EXACTLY into three bf16 terms x = x0 + x1 + x2 (8 + 8 + 8
+// significand bits, round-to-nearest at every level, each residual is representable) and a product is formed from six
+// partial products, down to 2^-23 of it:   a b ~= a2 b0 + a0 b2 + a1 b1 + a1 b0 + a0 b1 + a0 b0   (smallest first),
+// accumulated in f32 by v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k-steps against 8 x 64 for the f32 MFMA (2.7x).
+// Conv_0 reads uint8 pixels: u is exact in ONE bf16 plane, the division by 255 (architectures/dqn.py:44) moves into the
+// packed kernel (w / 255, one rounding, like x / 255 in the reference), so Conv_0 needs 3 products, not 6.
+//
+// Layouts (all bf16, "plane" layout):
+//   activations  act[slot = net * nb + batch block][hp][wp][plane 0..NP-1][c][32 samples]     row (c) = 64 bytes
+//                zero borders materialise SAME padding (flax default, architectures/dqn.py:43-51); NP = 3, Conv_0's
+//                input has NP = 1.  16 channels of one plane of one pixel = 1 KiB contiguous = one LDS-DMA instruction.
+//   weights      packed once per step per net in MFMA-fragment order:
+//                wq[superstep = (kh, 16-channel chunk)][tap kw][32-channel out tile][plane][lane][8]   (1 KiB blocks)
+// One layout serves both contraction shapes: the forward / data-gradient kernels sum over channels (k = rows: fragments
+// by ds_read_b64_tr_b16, 4 rows x 64 B per half-wave = all 64 banks once), the weight-gradient kernels sum over samples
+// (k = the 32 samples of a row: fragments by ds_read_b128, rows XOR-swizzled at LDS-DMA time).
+#pragma once
+#include "common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CP_MAX_STRIPS 4  // input rows one workgroup's output positions may span
+
+// ---- forward / data-gradient launch ---------------------------------------------------------------------------
+struct CItem {  // one workgroup: np consecutive output positions (row-major over the variant's OH x OW) of one net
+    int net, bb, var, p0, np, pad0, pad1, pad2;
+};
+struct CVar {  // one sub-convolution of a launch (forward: one; data gradient of a stride-S conv: S * S output parities)
+    long w_off;              // bytes from the net's packed weights
+    int in_off_h, in_off_w;  // padded input row / column read by output (0, 0), tap (0, 0)
+    int OH, OW;
+    int out_mul, out_add_h, out_add_w;  // output position (oh, ow) -> (oh * out_mul + out_add_h, ...)
+    int pad;
+};
+struct CFwdArgs {
+    const unsigned short* in;   // input planes
+    const unsigned short* wq;   // packed weights
+    const CItem* items;
+    const float* const* wbase;  // [n_nets] f32 parameter bases (bias)
+    unsigned short* out3;       // output planes or nullptr
+    float* out_f32;             // f32 rows [slot][(yh * f32_W + yw) * CO + co][32] or nullptr (Conv_2 -> Dense_0 input)
+    const unsigned short* mask3;  // epilogue 1: forward activation planes whose sign masks the result (plane 0 is read)
+    float* pb;                  // epilogue 1: per-position sums over the 32 samples [slot][pos][CO] (bias gradient) or nullptr
+    long wq_stride;             // bytes per net
+    long in_slot, out_slot, mask_slot, f32_slot;  // bytes / bytes / bytes / floats per (net, batch block)
+    long b_off;
+    int in_split;   // input slot of net n: (in_split > 0 ? n >= in_split : n) * nb + bb
+    int nb, n_var, epilogue;
+    int KH, NCC, S, SX, CO;           // NCC = 16-channel chunks per tap (1 for Conv_0); SX = pixel chunks per output step
+    int pix_bytes, plane_bytes, xstep, row_bytes;  // input geometry in bytes (xstep: between consecutive pixel chunks)
+    int out_Wp, out_lo_h, out_lo_w, out_W, out_H;  // out_W x out_H: unpadded grid (pb indexing)
+    int mask_Wp, mask_lo_h, mask_lo_w, mask_C;
+    int f32_W;
+    CVar var[4];
+};
+
+// ---- weight-gradient launch -----------------------------------------------------------------------------------
+struct CWItem {  // one workgroup: positions [p0, p0 + np) of one head, one kernel row (Conv_0: all kernel rows)
+    int net, kh, chunk, p0, np, pad0, pad1, pad2;
+};
+struct CWgradArgs {
+    const unsigned short* x;    // forward input planes of the conv
+    const unsigned short* dy;   // gradient w.r.t. the conv's output, planes [K][nb][...] zero-bordered
+    const float* pb;            // [K * nb][OH * OW][CO] sums of dy over the samples (bias gradient) or nullptr
+    const CWItem* items;
+    float* slab;                // [n_chunks][K][slab_stride]: weights [(kh, kw, ci)][co], then bias [co]
+    long x_slot, dy_slot, slab_stride;  // bytes, bytes, floats
+    int x_shared;               // 1: every head reads slot bb (Conv_0 reads the staged `state`), 0: slot k * nb + bb
+    int K, nb, KH, KW, S, CI, CO, OH, OW;
+    int x_pix, x_plane, x_row;  // bytes
+    int dy_pix, dy_Wp, dy_lo_h, dy_lo_w;
+    int PG;                     // positions per LDS stage
+    float out_div;              // 1, or 255 for Conv_0 (its input planes hold the raw pixel values)
+};
+
+// ---- staging launch: uint8 minibatch -> bf16 plane, and every conv kernel -> packed bf16 planes -------------------
+struct PackJob {
+    long src_off;   // floats from the net's parameter base (the conv kernel leaf, HWIO)
+    long dst_off;   // bytes from the net's packed base
+    int n_nets;     // nets this job covers (2K forward, K data gradient)
+    int KHv, NQ, NCC, CT;        // virtual conv: kernel rows, taps per superstep, 16-channel chunks, out tiles
+    int mode;                    // 0 forward kernel; 1 data-gradient kernel of output parity (rh, rw)
+    int KW, CI, CO, S, PLh, PLw, rh, rw, KHs;  // the layer's real geometry (mode 1: KHs = K / S taps per parity)
+    int div255;                  // Conv_0: pack w / 255
+    long first_block;            // block range of this job inside the pack part of the grid
+    int blocks_per_net, pad;
+};
+struct StageArgs {
+    const uint8_t* src[2];  // state, next_state  [B][E] uint8 (nullptr src[1]: one set)
+    unsigned short* x1;     // [n_sets][nb][Hp][Wp][C][32] bf16
+    long E;
+    int B, nb, n_sets, H, W, C, lo_h, lo_w, Hp, Wp;
+    int n_prep_blocks;      // blocks [0, n_prep_blocks) stage pixels, the rest pack weights
+    const float* const* wbase;
+    unsigned short* wq;
+    long wq_stride;         // bytes per net
+    int n_jobs, pad;
+    PackJob job[8];
+};
+
+// exact three-way bf16 split of two f32 values, round-to-nearest-even at every level (a plain cast: v_cvt_pk_bf16_f32,
+// which keeps a NaN a NaN).  Returns the pair packed (v0 in the low half) per plane.
+__device__ __forceinline__ void split3_pk(float v0, float v1, unsigned& q0, unsigned& q1, unsigned& q2) {
+    bf16x2 h = __builtin_convertvector((f32x2){v0, v1}, bf16x2);
+    q0 = __builtin_bit_cast(unsigned, h);
+    float r0 = v0 - __uint_as_float(q0 << 16), r1 = v1 - __uint_as_float(q0 & 0xffff0000u);
+    h = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
+    q1 = __builtin_bit_cast(unsigned, h);
+    r0 -= __uint_as_float(q1 << 16);
+    r1 -= __uint_as_float(q1 & 0xffff0000u);
+    h = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
+    q2 = __builtin_bit_cast(unsigned, h);
+}
+
+// LDS-DMA from inline asm: 16 B per lane, global (scalar base + per-lane 32-bit byte offset) -> LDS (M0 + 16 * lane).
+// hipcc treats its own global_load_lds builtin as an LDS store and drains vmcnt(0) in front of every later LDS read;
+// from asm the copy is invisible to that bookkeeping and is ordered by the explicit s_waitcnt vmcnt + s_barrier.
+__device__ __forceinline__ void dma16(unsigned voff, unsigned long sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// host-side launchers (convp_fwd.hip / convp_wgrad.hip / convp_stage.hip)
+int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t lds_bytes, hipStream_t q);
+int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q);
+int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
+int convp_fwd_max_nt(int CT);

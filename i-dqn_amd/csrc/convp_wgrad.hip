@@ -1,0 +1,202 @@
+// Plane-layout conv weight gradient (convp.h has the layouts and the arithmetic).
+//   gW[kh][kw][ci][co] = sum over (oh, ow, sample b) of  x[oh*S + kh][ow*S + kw][ci][b] * dy[oh][ow][co][b]
+//   (jax.value_and_grad of the flax conv, idqn.py:105); the bias gradient is the sum of dy, taken from the per-position
+//   sums `pb` its producer already wrote.
+// The contraction index is (position, sample): k = the 32 samples of a row, so an MFMA fragment is 16 contiguous bytes of
+// ONE row -- rows of x ([kw, ci] = M side) and of dy ([co] = N side) are copied into LDS by LDS-DMA with the four 16-byte
+// slots of every 64-byte row XOR-swizzled by (row >> 2) & 3 (on the SOURCE address: the DMA writes LDS linearly), which
+// makes the ds_read_b128 fragment reads conflict-free.
+// Workgroup = (head, kernel row kh, chunk of output positions) [Conv_0: all 8 kernel rows]; its (KW * CI / 32) x (CO / 32)
+// tiles of 32 x 32 are dealt to the 4 waves; a stage = up to PG consecutive positions of one output row: the strip of
+// input pixels they read (shared between neighbours) + their dy pixels, double-buffered, one barrier per stage.
+// Every workgroup writes its partial sums to its own slab; k_adam adds the slabs in chunk order (no atomics: replicas of
+// a data-parallel run must stay bit-identical).
+#include "convp.h"
+
+namespace {
+
+__device__ __forceinline__ bf16x8 frag128(const unsigned char* p) {
+    return *(const __attribute__((address_space(3))) bf16x8*)p;
+}
+
+template <int NPX, int CT, int NTW, int PG>
+__global__ __launch_bounds__(256) void k_cwgrad(CWgradArgs a, unsigned stage_bytes, int MT) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const CWItem it = a.items[xcd_contiguous_id()];  // the kernel rows of one chunk share an XCD
+    const int OW = a.OW, p0 = it.p0, p_end = it.p0 + it.np, k = it.net;
+    const int dy_pix = 3 * a.CO * 64;
+    // LDS stage: [x region][PG dy pixels]
+    const unsigned strip_bytes = (PG + 1) * 1024;  // Conv_0: one strip per kernel row, (4 PG + 4) pixels of 256 B
+    const unsigned XB = NPX == 3 ? (unsigned)(((PG - 1) * a.S + a.KW) * a.x_pix) : (unsigned)a.KH * strip_bytes;
+    const unsigned pos_stride = (unsigned)(a.S * a.x_pix);
+    const int ct = wave % CT;
+    const int NH = a.CI / 32;
+    unsigned tbase[NTW];
+    int tm[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int m = (wave + 4 * i) / CT;
+        tm[i] = m < MT ? m : -1;
+        const int mm = min(m, MT - 1);
+        tbase[i] = NPX == 3 ? (unsigned)((mm / NH) * a.x_pix + (mm % NH) * 2048) : (unsigned)mm * strip_bytes;
+    }
+    const unsigned swz = (cl >> 2) & 3;
+    const unsigned rd0 = cl * 64 + ((0u + h) ^ swz) * 16, rd1 = cl * 64 + ((2u + h) ^ swz) * 16;  // k-step 0 / 1
+    const unsigned voff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);          // swizzled DMA source
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&lds[0];
+    const unsigned long xb = (unsigned long)a.x, dyb = (unsigned long)a.dy;
+
+    auto cnt_of = [&](int pos) { return min(PG, min((pos / OW + 1) * OW, p_end) - pos); };
+    auto stage = [&](int bb, int pos, unsigned buf) {
+        const int oh = pos / OW, ow0 = pos - oh * OW, cnt = cnt_of(pos);
+        const unsigned long xs = xb + (unsigned long)(a.x_shared ? bb : k * a.nb + bb) * (unsigned long)a.x_slot;
+        if (NPX == 3) {
+            const unsigned long src = xs + (unsigned long)(oh * a.S + it.kh) * (unsigned long)a.x_row +
+                                      (unsigned long)(ow0 * a.S) * (unsigned long)a.x_pix;
+            const int npiece = (((cnt - 1) * a.S + a.KW) * a.x_pix) >> 10;
+            for (int i = wave; i < npiece; i += 4) dma16(voff, src + (unsigned long)i * 1024, buf + i * 1024);
+        } else {
+            const int npiece = cnt + 1;
+            for (int kh = 0; kh < a.KH; ++kh) {
+                const unsigned long src = xs + (unsigned long)(oh * a.S + kh) * (unsigned long)a.x_row + (unsigned long)ow0 * 1024;
+                for (int i = wave; i < npiece; i += 4) dma16(voff, src + (unsigned long)i * 1024, buf + kh * strip_bytes + i * 1024);
+            }
+        }
+        const unsigned long dsrc = dyb + (unsigned long)(k * a.nb + bb) * (unsigned long)a.dy_slot +
+                                   ((unsigned long)(oh + a.dy_lo_h) * a.dy_Wp + (ow0 + a.dy_lo_w)) * (unsigned long)dy_pix;
+        const int ndp = (cnt * dy_pix) >> 10;
+        for (int i = wave; i < ndp; i += 4) dma16(voff, dsrc + (unsigned long)i * 1024, buf + XB + i * 1024);
+    };
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int ibb = 0, ipos = p0, cbb = 0, cpos = p0, par = 0;
+    stage(ibb, ipos, lds0);
+    ipos += cnt_of(ipos);
+    if (ipos >= p_end) { ipos = p0; ++ibb; }
+
+    // bias gradient of this chunk: the per-position sums of dy, added in (batch block, position) order
+    float bsum = 0.f;
+    // (wave-uniform branch; lanes past CO read a clamped column -- a lane-divergent branch here makes hipcc treat the
+    // loop state below as divergent and the DMA's scalar operands end up in VGPRs)
+    const bool bias_wave = a.pb && (NPX == 1 || it.kh == 0) && wave == 0;
+    const int bcol = min(lane, a.CO - 1);
+    if (bias_wave) {
+        const int npos = a.OH * a.OW, n = it.np * a.nb;
+        for (int e0 = 0; e0 < n; e0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u, n - 1), bb = e / it.np, p = p0 + (e - bb * it.np);
+                v[u] = a.pb[((long)(k * a.nb + bb) * npos + p) * a.CO + bcol];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < n) bsum += v[u];
+        }
+    }
+
+    while (cbb < a.nb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ibb < a.nb) {
+            stage(ibb, ipos, lds0 + (par ^ 1) * stage_bytes);
+            ipos += cnt_of(ipos);
+            if (ipos >= p_end) { ipos = p0; ++ibb; }
+        }
+        const unsigned char* cur = lds + par * stage_bytes;
+        const int cnt = cnt_of(cpos);
+#pragma unroll
+        for (int pp = 0; pp < PG; ++pp) {
+            if (pp < cnt) {  // wave-uniform
+                const unsigned char* xp = cur + pp * pos_stride;
+                const unsigned char* dp = cur + XB + pp * dy_pix + ct * 2048;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned rd = ks ? rd1 : rd0;
+                    bf16x8 d[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) d[pl] = frag128(dp + pl * (a.CO * 64) + rd);
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) {
+                        bf16x8 x[NPX];
+#pragma unroll
+                        for (int pl = 0; pl < NPX; ++pl) x[pl] = frag128(xp + tbase[i] + pl * a.x_plane + rd);
+                        if (NPX == 3) {  // smallest terms first
+                            acc[i] = mfma_bf16(x[2], d[0], acc[i]);
+                            acc[i] = mfma_bf16(x[0], d[2], acc[i]);
+                            acc[i] = mfma_bf16(x[1], d[1], acc[i]);
+                            acc[i] = mfma_bf16(x[1], d[0], acc[i]);
+                            acc[i] = mfma_bf16(x[0], d[1], acc[i]);
+                            acc[i] = mfma_bf16(x[0], d[0], acc[i]);
+                        } else {
+                            acc[i] = mfma_bf16(x[0], d[2], acc[i]);
+                            acc[i] = mfma_bf16(x[0], d[1], acc[i]);
+                            acc[i] = mfma_bf16(x[0], d[0], acc[i]);
+                        }
+                    }
+                }
+            }
+        }
+        cpos += cnt;
+        if (cpos >= p_end) { cpos = p0; ++cbb; }
+        par ^= 1;
+    }
+
+    float* S = a.slab + ((long)it.chunk * a.K + k) * a.slab_stride;
+    const long row_base = NPX == 3 ? (long)it.kh * a.KW * a.CI : 0;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (tm[i] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            S[(row_base + tm[i] * 32 + mfma_row(r, h)) * a.CO + ct * 32 + cl] = acc[i][r] / a.out_div;
+    }
+    if (bias_wave && lane < a.CO) S[(long)a.KH * a.KW * a.CI * a.CO + lane] = bsum;
+}
+
+template <int NPX, int CT, int NTW, int PG>
+int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipStream_t q) {
+    static size_t attr = 0;
+    if (lds_bytes > attr) {
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cwgrad<NPX, CT, NTW, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr = lds_bytes;
+    }
+    hipLaunchKernelGGL((k_cwgrad<NPX, CT, NTW, PG>), dim3((unsigned)n_items), dim3(256), lds_bytes, q, a, (unsigned)(lds_bytes / 2), MT);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+}  // namespace
+
+// MT = 32-row tiles on the M side of one workgroup (KW * CI / 32, Conv_0: its 8 kernel rows)
+int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q) {
+    IDQN_REQUIRE(lds_bytes <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes);
+    const int ntw = (MT * CT + 3) / 4;
+    if (NPX == 1) {
+        IDQN_REQUIRE(a.PG == 4, "plane wgrad: Conv_0 stages 4 positions");
+        if (CT == 1 && ntw == 2) return launch_one<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q);
+        if (CT == 2 && ntw == 4) return launch_one<1, 2, 4, 4>(a, MT, n_items, lds_bytes, q);
+    } else {
+        IDQN_REQUIRE(a.PG == 2, "plane wgrad: stages of 2 positions");
+        if (CT == 1) switch (ntw) {
+            case 1: return launch_one<3, 1, 1, 2>(a, MT, n_items, lds_bytes, q);
+            case 2: return launch_one<3, 1, 2, 2>(a, MT, n_items, lds_bytes, q);
+            default: break;
+        }
+        else switch (ntw) {
+            case 2: return launch_one<3, 2, 2, 2>(a, MT, n_items, lds_bytes, q);
+            case 3: return launch_one<3, 2, 3, 2>(a, MT, n_items, lds_bytes, q);
+            case 4: return launch_one<3, 2, 4, 2>(a, MT, n_items, lds_bytes, q);
+            default: break;
+        }
+    }
+    IDQN_REQUIRE(false, "plane wgrad: no kernel for %d planes, %d x %d tiles", NPX, MT, CT);
+}

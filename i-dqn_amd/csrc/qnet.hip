@@ -10,14 +10,15 @@
 // and only interiors are ever written, so they stay zero for any nb.
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
 
-#include "conv3_kernels.h"
-#ifndef C3_RING
-#define C3_RING 2
-#endif
+#include <map>
+#include <tuple>
+
+#include "cnn_kernels.h"
 #include "fc_kernels.h"
 
 namespace {
@@ -139,9 +140,14 @@ struct NetSet {
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
-    float *x = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *part = nullptr;
-    unsigned short *x3 = nullptr, *a1_3 = nullptr, *a2_3 = nullptr;  // 3-plane bf16 copies (conv3 path only)
+    float *x = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *part = nullptr;  // x, a1, a2: f32 conv path only
+    unsigned short *x1 = nullptr, *a1p = nullptr, *a2p = nullptr, *wq = nullptr;       // plane conv path (convp.h)
 };
+
+// host-side plans of the plane conv launches: the work items of a launch depend only on geometry, net count and batch
+// blocks, so they are built once and kept on the device
+struct FwdPlan { CItem* dev = nullptr; int n_items = 0, NT = 0; size_t lds = 0; };
+struct WgradPlan { CWItem* dev = nullptr; int n_items = 0, n_chunks = 0, MT = 0, PG = 0; size_t lds = 0; };
 
 }  // namespace
 
@@ -165,12 +171,13 @@ struct idqn_handle_s {
     float *infer_hbuf = nullptr, *infer_qpart = nullptr;  // k_hidden outputs of the single inference net
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
     long wt_stride[3] = {0, 0, 0};
-    // bf16x3 conv path (conv3_kernels.h): packed weight planes of every training net and the 3-plane dout buffers
-    bool conv3 = false;      // forward convs on the bf16x3 path
-    bool conv3_bwd = false;  // ... and the conv data gradients too
-    unsigned short *w3 = nullptr, *da3_3 = nullptr, *da2_3 = nullptr;
-    float* c3prof = nullptr;  // debug: phase timestamps of the Conv_2 forward launch (IDQN_CONV_PROF=1)
-    long w3_stride = 0, w3_fwd[3] = {0, 0, 0}, w3_dg[3] = {0, 0, 0};
+    // plane conv path (convp.h; the default): packed weight planes per net, plane dout buffers, per-position dy sums
+    bool planes = true;
+    unsigned short *da3p = nullptr, *da2p = nullptr, *da1p = nullptr;
+    float* pbuf[3] = {nullptr, nullptr, nullptr};  // [K * nb][OH * OW][CO] of conv layer i
+    long wq_stride = 0, wq_fwd[3] = {0, 0, 0}, wq_dg[3] = {0, 0, 0};  // bytes
+    std::map<std::tuple<int, int, int>, FwdPlan> fwd_plans;   // (role, n_nets, nb)
+    std::map<std::tuple<int, int>, WgradPlan> wgrad_plans;    // (layer, nb)
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
     SlabSeg segs[3];  // slab descriptors of the last backward (consumed by the fused Adam launch)
@@ -189,10 +196,6 @@ struct idqn_handle_s {
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
-    int mix_mode = 0, mix_stage = 0;  // IDQN_MIX=2: fused Dense_0 slices beside the three conv backward stages
-    long mix_d0_next = 0;
-    DenseWgradArgs mix_dw;
-    bool mix = false, mix_done = false;  // experiment (IDQN_MIX=1): Conv_2 weight gradient inside the fused Dense_0 launch
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
     int pend_B = 0;  // batch of a backward stopped after Dense_0 (idqn_backward_rest resumes it); 0 = none
@@ -235,9 +238,16 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     IDQN_HIP_CHECK(hipMemcpy(s.ident, id.data(), sizeof(int) * n_nets, hipMemcpyHostToDevice));
     std::string t(tag);
     int rc;
-    if ((rc = alloc_zero(&s.x, (long)n_in_sets * nb * h->gx.block, h, (t + "x").c_str()))) return rc;
-    if ((rc = alloc_zero(&s.a1, (long)n_nets * nb * h->ga1.block, h, (t + "a1").c_str()))) return rc;
-    if ((rc = alloc_zero(&s.a2, (long)n_nets * nb * h->ga2.block, h, (t + "a2").c_str()))) return rc;
+    if (h->planes) {  // bf16 planes: one for the pixels, three per activation (block = rows x 32 samples)
+        if ((rc = alloc_zero16(&s.x1, (long)n_in_sets * nb * h->gx.block, h, (t + "x1").c_str()))) return rc;
+        if ((rc = alloc_zero16(&s.a1p, (long)n_nets * nb * h->ga1.block * 3, h, (t + "a1p").c_str()))) return rc;
+        if ((rc = alloc_zero16(&s.a2p, (long)n_nets * nb * h->ga2.block * 3, h, (t + "a2p").c_str()))) return rc;
+        if ((rc = alloc_zero16(&s.wq, (long)n_nets * h->wq_stride / 2, h, (t + "wq").c_str()))) return rc;
+    } else {
+        if ((rc = alloc_zero(&s.x, (long)n_in_sets * nb * h->gx.block, h, (t + "x").c_str()))) return rc;
+        if ((rc = alloc_zero(&s.a1, (long)n_nets * nb * h->ga1.block, h, (t + "a1").c_str()))) return rc;
+        if ((rc = alloc_zero(&s.a2, (long)n_nets * nb * h->ga2.block, h, (t + "a2").c_str()))) return rc;
+    }
     if ((rc = alloc_zero(&s.a3, (long)n_nets * nb * h->ga3.block, h, (t + "a3").c_str()))) return rc;
     if ((rc = alloc_zero(&s.part, (long)n_nets * nb * s.NS * h->J * 32, h, (t + "part").c_str()))) return rc;
     return IDQN_OK;
@@ -289,27 +299,29 @@ int cnn_setup(idqn_handle_s* h) {
     }
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
-    if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
-    if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
-    if (h->conv3) {
-        NetSet& ts = h->train;
-        if ((rc = alloc_zero16(&ts.x3, (long)2 * nb * h->gx.block * 3, h, "x3"))) return rc;
-        if ((rc = alloc_zero16(&ts.a1_3, (long)2 * K * nb * h->ga1.block * 3, h, "a1_3"))) return rc;
-        if ((rc = alloc_zero16(&ts.a2_3, (long)2 * K * nb * h->ga2.block * 3, h, "a2_3"))) return rc;
-        if ((rc = alloc_zero16(&h->da3_3, (long)K * nb * h->gda3.block * 3, h, "da3_3"))) return rc;
-        if ((rc = alloc_zero16(&h->da2_3, (long)K * nb * h->gda2.block * 3, h, "da2_3"))) return rc;
+    if (h->planes) {  // packed weights of one net: forward kernels of the three layers, then the data-gradient kernels
         long off = 0;
-        for (int i = 0; i < 3; ++i) {  // forward kernels, then the transformed data-gradient kernels
-            h->w3_fwd[i] = off;
-            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 3;
+        for (int i = 0; i < 3; ++i) {
+            h->wq_fwd[i] = off;
+            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 6;  // 3 planes x 2 bytes
         }
         for (int i = 1; i < 3; ++i) {
-            h->w3_dg[i] = off;
-            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 3;
+            h->wq_dg[i] = off;
+            off += (long)h->conv[i].K * h->conv[i].K * h->conv[i].CI * h->conv[i].CO * 6;
         }
-        h->w3_stride = (off + 63) / 64 * 64;
-        if ((rc = alloc_zero16(&h->w3, (long)2 * K * h->w3_stride, h, "w3"))) return rc;
-        if (getenv("IDQN_CONV_PROF") && (rc = alloc_zero(&h->c3prof, 2L * 4 * 4096, h, "c3prof"))) return rc;
+        h->wq_stride = (off + 1023) / 1024 * 1024;
+    }
+    if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
+    if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
+    if (h->planes) {
+        if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
+        if ((rc = alloc_zero16(&h->da2p, (long)K * nb * h->gda2.block * 3, h, "da2p"))) return rc;
+        if ((rc = alloc_zero16(&h->da1p, (long)K * nb * h->gda1.block * 3, h, "da1p"))) return rc;
+        for (int i = 0; i < 3; ++i) {
+            char nm[8];
+            snprintf(nm, sizeof nm, "pb%d", i);
+            if ((rc = alloc_zero(&h->pbuf[i], (long)K * nb * h->conv[i].OH * h->conv[i].OW * h->conv[i].CO, h, nm))) return rc;
+        }
     }
     std::vector<const float*> wb(2 * K);
     std::vector<int> is(2 * K);
@@ -321,9 +333,11 @@ int cnn_setup(idqn_handle_s* h) {
     IDQN_HIP_CHECK(hipMemcpy(h->train.in_set, is.data(), sizeof(int) * 2 * K, hipMemcpyHostToDevice));
     IDQN_HIP_CHECK(hipMemset(h->infer.in_set, 0, sizeof(int)));
     if ((rc = alloc_zero(&h->dh, (long)K * nb * h->J * 32, h, "dh"))) return rc;
-    if ((rc = alloc_zero(&h->da3, (long)K * nb * h->gda3.block, h, "da3"))) return rc;
-    if ((rc = alloc_zero(&h->da2, (long)K * nb * h->gda2.block, h, "da2"))) return rc;
-    if ((rc = alloc_zero(&h->da1, (long)K * nb * h->gda1.block, h, "da1"))) return rc;
+    if (!h->planes) {
+        if ((rc = alloc_zero(&h->da3, (long)K * nb * h->gda3.block, h, "da3"))) return rc;
+        if ((rc = alloc_zero(&h->da2, (long)K * nb * h->gda2.block, h, "da2"))) return rc;
+        if ((rc = alloc_zero(&h->da1, (long)K * nb * h->gda1.block, h, "da1"))) return rc;
+    }
     if ((rc = alloc_zero(&h->qdbg, (long)2 * K * nb * 32 * 32, h, "q"))) return rc;
     if ((rc = alloc_zero(&h->hbuf, (long)2 * K * nb * h->J * 32, h, "h"))) return rc;
     if ((rc = alloc_zero(&h->qpart, (long)2 * K * nb * (h->J / 32) * 32 * 32, h, "qpart"))) return rc;
@@ -333,7 +347,7 @@ int cnn_setup(idqn_handle_s* h) {
         const ConvL& cl = h->conv[i];
         IDQN_REQUIRE(cl.K % cl.S == 0, "conv %d: kernel %d not a multiple of stride %d", i, cl.K, cl.S);
         h->wt_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + 63) / 64 * 64;
-        if ((rc = alloc_zero(&h->wt[i], (long)K * h->wt_stride[i], h, i == 1 ? "wt1" : "wt2"))) return rc;
+        if (!h->planes && (rc = alloc_zero(&h->wt[i], (long)K * h->wt_stride[i], h, i == 1 ? "wt1" : "wt2"))) return rc;
     }
     // weight-gradient slabs: one per workgroup chunk of 16 output positions; one region per conv layer
     long slab_total = 0;
@@ -362,6 +376,12 @@ int cnn_setup(idqn_handle_s* h) {
             if (const char* e = getenv(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
         }
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
+        if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
+            const int per_chunk = K * (i == 0 ? 1 : cl.K);
+            int nch = (256 + per_chunk / 2) / per_chunk;
+            if (const char* e = getenv("IDQN_WCHUNKS")) nch = atoi(e);
+            h->npc[i] = std::max(1, std::min(nch, npos));
+        }
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
         h->slab_off[i] = slab_total;
         slab_total += (long)h->npc[i] * K * h->slab_stride[i];
@@ -426,87 +446,289 @@ int build_dgrad_weights(idqn_handle_s* h, hipStream_t q) {
     return IDQN_OK;
 }
 
-// bf16x3 path: the data-gradient kernels, then every kernel of the 2K training nets as packed bf16 planes
-int build_weights3(idqn_handle_s* h, hipStream_t q) {
-    const int K = h->cfg.n_heads;
-    if (h->conv3_bwd) {
-        int rc = build_dgrad_weights(h, q);
-        if (rc) return rc;
-    }
-    W3PackArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.wbase = h->train.wbase; pa.w3 = h->w3; pa.w3_stride = h->w3_stride;
-    for (int i = 1; i < 3; ++i) { pa.wt[i] = h->wt[i]; pa.wt_stride[i] = h->wt_stride[i]; }
-    int nj = 0;
-    long maxe = 0;
-    for (int i = 0; i < 3; ++i) {
+// ---- plane conv path: launch plans -----------------------------------------------------------------------------
+// role 0..2: forward of Conv_0..2; 3: data gradient of Conv_2; 4: data gradient of Conv_1
+struct RoleGeom {
+    int NPA, CT, NQ, NCC, S, SX, KH, n_var;
+    CVar var[4];
+};
+
+int role_geom(idqn_handle_s* h, int role, RoleGeom& g) {
+    memset(&g, 0, sizeof(g));
+    if (role <= 2) {
+        const ConvL& l = h->conv[role];
+        g.NPA = role == 0 ? 1 : 3; g.CT = l.CO / 32; g.S = l.S; g.KH = l.K; g.n_var = 1;
+        if (role == 0) {  // (kw, c) rows of a kernel row in 16-row chunks of 4 pixels x 4 channels
+            IDQN_REQUIRE(l.CI == 4 && l.K == 8 && l.S == 4, "plane conv: Conv_0 is built for 8x8 stride 4 over 4 channels");
+            g.NQ = l.K * l.CI / 16; g.NCC = 1; g.SX = 1;
+        } else {
+            g.NQ = l.K; g.NCC = l.CI / 16; g.SX = l.S;
+        }
+        CVar& v = g.var[0];
+        v.w_off = h->wq_fwd[role]; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
+        v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0;
+    } else {
+        const int i = role == 3 ? 2 : 1;
         const ConvL& l = h->conv[i];
-        W3Job& j = pa.job[nj++];
-        j.src = 0; j.src_off = l.w_off; j.dst_off = h->w3_fwd[i]; j.n_nets = 2 * K;
-        j.KH = l.K; j.KWCI = l.K * l.CI; j.CO = l.CO;
-        maxe = std::max(maxe, (long)j.KH * j.KWCI * j.CO);
-    }
-    for (int i = 1; i < 3 && h->conv3_bwd; ++i) {
-        const ConvL& l = h->conv[i];
+        const ActGeom& gd = i == 2 ? h->gda3 : h->gda2;
         const int KHs = l.K / l.S;
-        const long per_var = (long)KHs * KHs * l.CO * l.CI;
-        for (int vi = 0; vi < l.S * l.S; ++vi) {
-            IDQN_REQUIRE(nj < 8, "bf16x3 conv path: more than 8 weight blocks to pack");
-            W3Job& j = pa.job[nj++];
-            j.src = i; j.src_off = vi * per_var; j.dst_off = h->w3_dg[i] + vi * per_var * 3; j.n_nets = K;
-            j.KH = KHs; j.KWCI = KHs * l.CO; j.CO = l.CI;
+        g.NPA = 3; g.CT = l.CI / 32; g.NQ = KHs; g.NCC = l.CO / 16; g.S = 1; g.SX = 1; g.KH = KHs; g.n_var = l.S * l.S;
+        IDQN_REQUIRE(g.n_var <= 4, "plane conv: stride %d data gradient has more than 4 parities", l.S);
+        for (int vi = 0; vi < g.n_var; ++vi) {
+            const int rh = vi / l.S, rw = vi % l.S;
+            const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
+            CVar& v = g.var[vi];
+            v.w_off = h->wq_dg[i] + (long)vi * KHs * KHs * l.CO * l.CI * 6;
+            v.in_off_h = (rh + l.PLh - ph) / l.S + gd.lo_h - KHs + 1;
+            v.in_off_w = (rw + l.PLw - pw) / l.S + gd.lo_w - KHs + 1;
+            v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
+            v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw;
+            IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
         }
     }
-    hipLaunchKernelGGL(k_w3_pack, dim3(cdiv(maxe, 256), 2 * K, nj), dim3(256), 0, q, pa);
-    IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
+}
+
+// LDS bytes of one stage for positions [p0, p0 + np) of a variant with OW columns
+long fwd_stage_bytes(const RoleGeom& g, int OW, int p0, int np, int* n_rows) {
+    long bytes = (long)g.NQ * g.CT * 3 * 1024;
+    const int oh0 = p0 / OW, oh1 = (p0 + np - 1) / OW;
+    for (int row = oh0; row <= oh1; ++row) {
+        const int lo = std::max(p0, row * OW), hi = std::min(p0 + np, (row + 1) * OW);
+        bytes += (long)((hi - lo - 1) * g.SX + g.NQ) * g.NPA * 1024;
+    }
+    *n_rows = oh1 - oh0 + 1;
+    return bytes;
+}
+
+int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
+    auto key = std::make_tuple(role, n_nets, nb);
+    auto itp = h->fwd_plans.find(key);
+    if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
+    const int nt_max = convp_fwd_max_nt(g.CT);
+    long npos_total = 0;
+    for (int v = 0; v < g.n_var; ++v) npos_total += (long)g.var[v].OH * g.var[v].OW;
+    // about one workgroup per CU and launch (they are all co-resident, one per CU: equal work = no tail)
+    static const int target = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 256;
+    const int per_slot = std::max(1, target / (n_nets * nb));
+    std::vector<CItem> items;
+    int np_all = 0;
+    long stage_max = 0;
+    for (int v = 0; v < g.n_var; ++v) {
+        const int OW = g.var[v].OW, npos = g.var[v].OH * OW;
+        int R = std::max(1L, std::min((long)npos, (per_slot * (long)npos + npos_total / 2) / npos_total));
+        // limits: tiles per wave, rows spanned, LDS (two stages in 160 KB)
+        for (;; ++R) {
+            const int np = (npos + R - 1) / R;
+            bool ok = (np * g.CT + 3) / 4 <= nt_max;
+            for (int r = 0, p0 = 0; ok && r < R; ++r) {
+                const int n = npos / R + (r < npos % R ? 1 : 0);
+                int rows;
+                if (n > 0 && (fwd_stage_bytes(g, OW, p0, n, &rows) > 80 * 1024 || rows > CP_MAX_STRIPS)) ok = false;
+                p0 += n;
+            }
+            if (ok || R >= npos) break;
+        }
+        for (int n = 0; n < n_nets; ++n)
+            for (int bb = 0; bb < nb; ++bb)
+                for (int r = 0, p0 = 0; r < R; ++r) {
+                    const int cnt = npos / R + (r < npos % R ? 1 : 0);
+                    if (cnt == 0) continue;
+                    CItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.net = n; it.bb = bb; it.var = v; it.p0 = p0; it.np = cnt;
+                    items.push_back(it);
+                    int rows;
+                    stage_max = std::max(stage_max, fwd_stage_bytes(g, OW, p0, cnt, &rows));
+                    IDQN_REQUIRE(rows <= CP_MAX_STRIPS, "plane conv: %d positions span %d rows", cnt, rows);
+                    np_all = std::max(np_all, cnt);
+                    p0 += cnt;
+                }
+    }
+    // net-major order: consecutive items (which the XCD-contiguous remap keeps on one XCD) share a net's weights
+    std::stable_sort(items.begin(), items.end(), [](const CItem& x, const CItem& y) {
+        return x.net != y.net ? x.net < y.net : x.bb < y.bb;
+    });
+    FwdPlan pl;
+    pl.n_items = (int)items.size();
+    pl.NT = (np_all * g.CT + 3) / 4;
+    IDQN_REQUIRE(pl.NT >= 1 && pl.NT <= nt_max, "plane conv: role %d needs %d tiles per wave", role, pl.NT);
+    pl.lds = (size_t)(2 * stage_max);
+    IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane conv: role %d needs %zu bytes of LDS", role, pl.lds);
+    IDQN_HIP_CHECK(hipMalloc((void**)&pl.dev, sizeof(CItem) * items.size()));
+    h->owned.push_back((void*)pl.dev);
+    IDQN_HIP_CHECK(hipMemcpy(pl.dev, items.data(), sizeof(CItem) * items.size(), hipMemcpyHostToDevice));
+    *out = &(h->fwd_plans[key] = pl);
+    return IDQN_OK;
+}
+
+int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out) {
+    auto key = std::make_tuple(layer, nb);
+    auto itp = h->wgrad_plans.find(key);
+    if (itp != h->wgrad_plans.end()) { *out = &itp->second; return IDQN_OK; }
+    const ConvL& l = h->conv[layer];
+    const int K = h->cfg.n_heads, npos = l.OH * l.OW, nch = h->npc[layer];
+    WgradPlan pl;
+    pl.n_chunks = nch;
+    pl.PG = layer == 0 ? 4 : 2;
+    pl.MT = layer == 0 ? l.K : l.K * l.CI / 32;
+    const long dy_pix = 3L * l.CO * 64, x_pix = (layer == 0 ? 1L : 3L) * l.CI * 64;
+    const long XB = layer == 0 ? (long)l.K * (pl.PG + 1) * 1024 : ((pl.PG - 1) * l.S + l.K) * x_pix;
+    pl.lds = (size_t)(2 * (XB + pl.PG * dy_pix));
+    IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
+    std::vector<CWItem> items;
+    for (int k = 0; k < K; ++k)
+        for (int c = 0, p0 = 0; c < nch; ++c) {
+            const int cnt = npos / nch + (c < npos % nch ? 1 : 0);
+            for (int kh = 0; kh < (layer == 0 ? 1 : l.K); ++kh) {
+                CWItem it;
+                memset(&it, 0, sizeof(it));
+                it.net = k; it.kh = kh; it.chunk = c; it.p0 = p0; it.np = cnt;
+                items.push_back(it);
+            }
+            p0 += cnt;
+        }
+    pl.n_items = (int)items.size();
+    IDQN_HIP_CHECK(hipMalloc((void**)&pl.dev, sizeof(CWItem) * items.size()));
+    h->owned.push_back((void*)pl.dev);
+    IDQN_HIP_CHECK(hipMemcpy(pl.dev, items.data(), sizeof(CWItem) * items.size(), hipMemcpyHostToDevice));
+    (void)nb;
+    *out = &(h->wgrad_plans[key] = pl);
+    return IDQN_OK;
+}
+
+// staging launch: pixels -> bf16 plane, conv kernels -> packed planes (forward kernels of every net of the set, and
+// for the training set the data-gradient kernels of the K online nets)
+int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, int nb, hipStream_t q) {
+    StageArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src[0] = st; a.src[1] = st2 ? st2 : st;
+    a.x1 = s.x1; a.E = (long)h->gx.H * h->gx.W * h->gx.C; a.B = B; a.nb = nb; a.n_sets = s.n_in_sets;
+    a.H = h->gx.H; a.W = h->gx.W; a.C = h->gx.C; a.lo_h = h->gx.lo_h; a.lo_w = h->gx.lo_w; a.Hp = h->gx.Hp; a.Wp = h->gx.Wp;
+    a.n_prep_blocks = cdiv(a.E, 64) * nb * s.n_in_sets;
+    a.wbase = s.wbase; a.wq = s.wq; a.wq_stride = h->wq_stride;
+    const bool train = &s == &h->train;
+    long blocks = 0;
+    int nj = 0;
+    for (int i = 0; i < 3; ++i) {
+        const ConvL& l = h->conv[i];
+        PackJob& j = a.job[nj++];
+        j.src_off = l.w_off; j.dst_off = h->wq_fwd[i]; j.n_nets = s.n_nets;
+        j.KHv = l.K; j.CT = l.CO / 32; j.mode = 0;
+        if (i == 0) { j.NQ = l.K * l.CI / 16; j.NCC = 1; j.div255 = 1; } else { j.NQ = l.K; j.NCC = l.CI / 16; }
+        j.KW = l.K; j.CI = l.CI; j.CO = l.CO; j.S = l.S;
+        j.blocks_per_net = cdiv((long)j.KHv * j.NCC * j.NQ * j.CT * 64, 256);
+        j.first_block = blocks;
+        blocks += (long)j.blocks_per_net * j.n_nets;
+    }
+    for (int i = 2; i >= 1 && train; --i) {
+        const ConvL& l = h->conv[i];
+        const int KHs = l.K / l.S;
+        for (int vi = 0; vi < l.S * l.S; ++vi) {
+            IDQN_REQUIRE(nj < 8, "plane conv: more than 8 kernel blocks to pack");
+            PackJob& j = a.job[nj++];
+            j.src_off = l.w_off; j.dst_off = h->wq_dg[i] + (long)vi * KHs * KHs * l.CO * l.CI * 6; j.n_nets = h->cfg.n_heads;
+            j.KHv = KHs; j.NQ = KHs; j.NCC = l.CO / 16; j.CT = l.CI / 32; j.mode = 1;
+            j.KW = l.K; j.CI = l.CI; j.CO = l.CO; j.S = l.S; j.PLh = l.PLh; j.PLw = l.PLw; j.rh = vi / l.S; j.rw = vi % l.S; j.KHs = KHs;
+            j.blocks_per_net = cdiv((long)j.KHv * j.NCC * j.NQ * j.CT * 64, 256);
+            j.first_block = blocks;
+            blocks += (long)j.blocks_per_net * j.n_nets;
+        }
+    }
+    a.n_jobs = nj;
+    return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q);
+}
+
+// one plane conv launch: role 0..2 forward of Conv_0..2 for net set s, 3 / 4 data gradient of Conv_2 / Conv_1
+int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
+    RoleGeom g;
+    int rc = role_geom(h, role, g);
+    if (rc) return rc;
+    const bool fwd = role <= 2;
+    const int n_nets = fwd ? s.n_nets : h->cfg.n_heads;
+    FwdPlan* pl;
+    if ((rc = plan_fwd(h, role + (fwd && &s == &h->infer ? 8 : 0), n_nets, nb, g, &pl))) return rc;
+    CFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.items = pl->dev; a.wbase = s.wbase; a.wq = s.wq; a.wq_stride = h->wq_stride; a.nb = nb; a.n_var = g.n_var;
+    a.KH = g.KH; a.NCC = g.NCC; a.S = g.S; a.SX = g.SX;
+    for (int v = 0; v < g.n_var; ++v) a.var[v] = g.var[v];
+    const ActGeom* gin;   // input planes
+    const ActGeom* gout;  // output planes
+    if (fwd) {
+        const ConvL& l = h->conv[role];
+        const unsigned short* ins[3] = {s.x1, s.a1p, s.a2p};
+        unsigned short* outs[3] = {s.a1p, s.a2p, nullptr};
+        const ActGeom* gi[3] = {&h->gx, &h->ga1, &h->ga2};
+        const ActGeom* go[3] = {&h->ga1, &h->ga2, &h->ga3};
+        gin = gi[role]; gout = go[role];
+        a.in = ins[role]; a.out3 = outs[role]; a.epilogue = 0; a.b_off = l.b_off; a.CO = l.CO;
+        a.in_split = role == 0 ? (s.n_in_sets > 1 ? s.n_nets / 2 : s.n_nets + 1) : 0;
+        if (role == 2) { a.out_f32 = s.a3; a.f32_slot = h->ga3.block; a.f32_W = l.OW; }
+        a.pix_bytes = g.NPA * l.CI * 64; a.plane_bytes = l.CI * 64;
+        a.xstep = role == 0 ? 1024 : a.pix_bytes;
+    } else {
+        const int i = role == 3 ? 2 : 1;
+        const ConvL& l = h->conv[i];
+        gin = i == 2 ? &h->gda3 : &h->gda2;
+        gout = i == 2 ? &h->gda2 : &h->gda1;
+        const ActGeom* gm = i == 2 ? &h->ga2 : &h->ga1;
+        a.in = i == 2 ? h->da3p : h->da2p;
+        a.out3 = i == 2 ? h->da2p : h->da1p;
+        a.mask3 = i == 2 ? s.a2p : s.a1p;
+        a.pb = h->pbuf[i - 1];
+        a.epilogue = 1; a.CO = l.CI; a.in_split = 0;
+        a.mask_slot = gm->block * 6; a.mask_Wp = gm->Wp; a.mask_lo_h = gm->lo_h; a.mask_lo_w = gm->lo_w; a.mask_C = l.CI;
+        a.pix_bytes = 3 * l.CO * 64; a.plane_bytes = l.CO * 64; a.xstep = a.pix_bytes;
+    }
+    a.in_slot = gin->block * (role == 0 ? 2 : 6);
+    a.row_bytes = gin->Wp * a.pix_bytes;
+    a.out_slot = gout->block * 6; a.out_Wp = gout->Wp; a.out_lo_h = gout->lo_h; a.out_lo_w = gout->lo_w;
+    a.out_W = gout->W; a.out_H = gout->H;
+    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->lds, q);
+}
+
+int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
+    NetSet& s = h->train;
+    const ConvL& l = h->conv[layer];
+    WgradPlan* pl;
+    int rc = plan_wgrad(h, layer, nb, &pl);
+    if (rc) return rc;
+    const unsigned short* xs[3] = {s.x1, s.a1p, s.a2p};
+    const unsigned short* dys[3] = {h->da1p, h->da2p, h->da3p};
+    const ActGeom* gx[3] = {&h->gx, &h->ga1, &h->ga2};
+    const ActGeom* gd[3] = {&h->gda1, &h->gda2, &h->gda3};
+    CWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = xs[layer]; a.dy = dys[layer]; a.pb = h->pbuf[layer]; a.items = pl->dev; a.slab = h->slab + h->slab_off[layer];
+    const int npx = layer == 0 ? 1 : 3;
+    a.x_slot = gx[layer]->block * 2 * npx; a.dy_slot = gd[layer]->block * 6; a.slab_stride = h->slab_stride[layer];
+    a.x_shared = layer == 0 ? 1 : 0;
+    a.K = h->cfg.n_heads; a.nb = nb; a.KH = l.K; a.KW = l.K; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.OH = l.OH; a.OW = l.OW;
+    a.x_pix = npx * l.CI * 64; a.x_plane = l.CI * 64; a.x_row = gx[layer]->Wp * a.x_pix;
+    a.dy_pix = 3 * l.CO * 64; a.dy_Wp = gd[layer]->Wp; a.dy_lo_h = gd[layer]->lo_h; a.dy_lo_w = gd[layer]->lo_w;
+    a.PG = pl->PG; a.out_div = layer == 0 ? 255.0f : 1.0f;
+    return convp_launch_wgrad(a, npx, pl->MT, l.CO / 32, pl->n_items, pl->lds, q);
 }
 
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
 int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q) {
     const int nb = cdiv(B, 32);
     IDQN_REQUIRE(nb <= s.nb_cap, "batch %d exceeds the workspace (%d blocks of 32)", B, s.nb_cap);
-    const bool c3 = h->conv3 && &s == &h->train;
-    PrepArgs pa;
-    pa.src[0] = st; pa.src[1] = st2 ? st2 : st;
-    pa.x = s.x; pa.x3 = c3 ? s.x3 : nullptr;
-    pa.E = (long)h->gx.H * h->gx.W * h->gx.C; pa.B = B; pa.nb = nb; pa.n_sets = s.n_in_sets; pa.g = h->gx;
-    hipLaunchKernelGGL(k_prep_u8, dim3(cdiv(pa.E, 64), nb, s.n_in_sets), dim3(256), 0, q, pa);
-    const float* ins[3] = {s.x, s.a1, s.a2};
-    float* outs[3] = {s.a1, s.a2, s.a3};
-    const ActGeom* gin[3] = {&h->gx, &h->ga1, &h->ga2};
-    const ActGeom* gout[3] = {&h->ga1, &h->ga2, &h->ga3};
-    if (c3) {
-        int rc3 = build_weights3(h, q);  // transformed data-gradient kernels + the packed bf16 planes of every kernel
-        if (rc3) return rc3;
-        const unsigned short* ins3[3] = {s.x3, s.a1_3, s.a2_3};
-        unsigned short* outs3[3] = {s.a1_3, s.a2_3, nullptr};
-        const int K = h->cfg.n_heads;
-        for (int i = 0; i < 3; ++i) {
-            const ConvL& l = h->conv[i];
-            Conv3Args a;
-            memset(&a, 0, sizeof(a));
-            a.in3 = ins3[i]; a.out = outs[i]; a.out3 = outs3[i]; a.wbase = s.wbase; a.w3 = h->w3; a.w3_stride = h->w3_stride;
-            a.in_split = (i == 0) ? K : 0;  // Conv_0: online nets read `state`, target nets `next_state`
-            a.b_off = l.b_off; a.in_block = gin[i]->block; a.out_block = gout[i]->block;
-            a.n_nets = s.n_nets; a.nb = nb; a.n_var = 1; a.epilogue = 0;
-            a.f32_nets = (i == 2) ? s.n_nets : K;  // a1 / a2 in f32 only where the backward pass reads them
-            a.KH = l.K; a.KWCI = l.K * l.CI; a.S = l.S; a.CI = l.CI; a.CO = l.CO; a.IWp = gin[i]->Wp;
-            a.out_Wp = gout[i]->Wp; a.out_lo_h = gout[i]->lo_h; a.out_lo_w = gout[i]->lo_w;
-            IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d: a kernel row of %d (kw, ci) rows is not a multiple of the 32-row chunk", i, a.KWCI);
-            const int npw = (l.CO == 32) ? 4 : 2;
-            ConvVariant& v = a.var[0];
-            v.w_off = h->w3_fwd[i]; v.in_off_h = 0; v.in_off_w = 0; v.OH = l.OH; v.OW = l.OW;
-            v.out_mul = 1; v.out_add_h = 0; v.out_add_w = 0; v.pg_begin = 0;
-            a.npg = cdiv(l.OH * l.OW, npw);
-            a.n_items = (long)s.n_nets * nb * a.npg;
-            if (i == 2 && h->c3prof && a.n_items <= 4096) a.prof = (long long*)h->c3prof;
-            if (l.CO == 32)
-                hipLaunchKernelGGL((k_conv3<1, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-            else
-                hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-        }
+    if (h->planes) {
+        int rc = planes_stage(h, s, st, st2, B, nb, q);
+        for (int i = 0; i < 3 && !rc; ++i) rc = planes_conv(h, s, i, nb, q);
+        if (rc) return rc;
     } else {
+        PrepArgs pa;
+        pa.src[0] = st; pa.src[1] = st2 ? st2 : st;
+        pa.x = s.x;
+        pa.E = (long)h->gx.H * h->gx.W * h->gx.C; pa.B = B; pa.nb = nb; pa.n_sets = s.n_in_sets; pa.g = h->gx;
+        hipLaunchKernelGGL(k_prep_u8, dim3(cdiv(pa.E, 64), nb, s.n_in_sets), dim3(256), 0, q, pa);
+        const float* ins[3] = {s.x, s.a1, s.a2};
+        float* outs[3] = {s.a1, s.a2, s.a3};
+        const ActGeom* gin[3] = {&h->gx, &h->ga1, &h->ga2};
+        const ActGeom* gout[3] = {&h->ga1, &h->ga2, &h->ga3};
         for (int i = 0; i < 3; ++i) {
             const ConvL& l = h->conv[i];
             ConvFwdArgs a;
@@ -615,49 +837,12 @@ int make_dgrad_args(idqn_handle_s* h, int i, int nb, ConvFwdArgs& a) {
     return IDQN_OK;
 }
 
-// IDQN_MIX=2: one stage of the conv backward (weight gradient of layer `layer`, plus its data gradient for layers 2
-// and 1) in one grid with the next slice of the fused Dense_0 update.  Standard Nature-CNN channel widths only.
-template <int NIT, int NOT, int CT>
-int launch_mix_stage_t(idqn_handle_s* h, int layer, int nb, long d0_count, hipStream_t q, hipEvent_t e0, hipEvent_t e1) {
-    ConvWgradArgs cw = make_wgrad_args(h, layer, nb);
-    ConvFwdArgs cf;
-    memset(&cf, 0, sizeof(cf));
-    if (CT > 0) {
-        int rc = make_dgrad_args(h, layer, nb, cf);
-        if (rc) return rc;
-    }
-    const long n_conv = cw.n_items + (CT > 0 ? cf.n_items : 0), n_all = d0_count + n_conv;
-    const size_t lds_w = (size_t)2 * (4 / (NIT * NOT)) * (NIT + NOT) * 32 * 36 * 4;
-    const size_t lds_f = CT > 0 ? (size_t)2 * (32 * 32 * (CT > 0 ? CT : 1) + (4 / (CT > 0 ? CT : 1)) * 32 * 32) * 4 : 0;
-    const size_t lds = std::max<size_t>(std::max(lds_w, lds_f), (size_t)32 * 256 * 4);
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_mix_stage<2, NIT, NOT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipExtLaunchKernelGGL((k_mix_stage<2, NIT, NOT, CT>), dim3((unsigned)n_all), dim3(256), lds, q, e0, e1, 0, h->mix_dw,
-                          (int)h->mix_d0_next, (int)d0_count, cw, cf, 0);
-    h->mix_d0_next += d0_count;
-    IDQN_HIP_CHECK(hipGetLastError());
-    return IDQN_OK;
-}
-
-int launch_mix_stage(idqn_handle_s* h, int layer, int nb, hipStream_t q, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-    const long n_d0 = h->mix_dw.n_items;
-    // Dense_0 slices per stage: 50 / 30 / 20 % (a sweep from 30/40/30 to 100/0/0 moved the step by < 3 %)
-    static int pa = getenv("IDQN_MIX_A") ? atoi(getenv("IDQN_MIX_A")) : 50, pb = getenv("IDQN_MIX_B") ? atoi(getenv("IDQN_MIX_B")) : 30;
-    const long share = layer == 2 ? n_d0 * pa / 100 : layer == 1 ? n_d0 * pb / 100 : n_d0 - h->mix_d0_next;
-    if (layer == 2) return launch_mix_stage_t<2, 2, 2>(h, 2, nb, share, q, e0, e1);
-    if (layer == 1) return launch_mix_stage_t<1, 2, 1>(h, 1, nb, share, q, e0, e1);
-    return launch_mix_stage_t<1, 1, 0>(h, 0, nb, share, q, e0, e1);
-}
-
 int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
 
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
 int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
                         long a3_head, long a3_inner, long dh_outer, long dh_head, long dh_inner, bool fuse_adam,
-                        bool profile, hipStream_t q, bool allow_mix = false) {
+                        bool profile, hipStream_t q) {
     const int K = h->cfg.n_heads;
     DenseWgradArgs dw;
     dw.a3 = a3; dw.dh = dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
@@ -677,26 +862,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    h->mix_done = false; h->mix_stage = 0;
-    if (fuse_adam && nq == 2 && h->mix_mode == 2 && !h->conv3_bwd && allow_mix && nb_total == nb_inner && h->conv[0].CO == 32 && h->conv[0].K * h->conv[0].CI == 32 &&
-        h->conv[1].CI == 32 && h->conv[1].CO == 64 && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
-        int rcb = build_dgrad_weights(h, q);  // the data gradients start in this very launch
-        if (rcb) return rcb;
-        h->mix_dw = dw; h->mix_d0_next = 0; h->mix_stage = 1;
-        return launch_mix_stage(h, 2, nb_total, q, e0, e1);
-    }
-    if (fuse_adam && nq == 2 && h->mix && !h->conv3_bwd && allow_mix && h->conv[2].CI == 64 && h->conv[2].CO == 64) {
-        ConvWgradArgs cw = make_wgrad_args(h, 2, nb_total);
-        const long n_all = dw.n_items + cw.n_items;
-        int period = (int)(n_all / cw.n_items);
-        if (period % 2 == 0) --period;  // odd: consecutive conv slots then visit all 8 XCDs
-        if (period >= 3) {
-            hipExtLaunchKernelGGL((k_mix_dense0_convw<2, 2, 2>), dim3((unsigned)n_all), dim3(256), 0, q, e0, e1, 0, dw, cw, period);
-            h->mix_done = true;
-        }
-    }
-    if (h->mix_done) {}
-    else if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (fuse_adam) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else hipExtLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
@@ -728,7 +894,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
     h->wt_ready = false;
-    if (!h->conv3_bwd) {  // (the bf16x3 data-gradient path packs them before the forward pass)
+    if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
         WtBuildArgs wb;
         const int nx = wt_build_args(h, wb);
         hipLaunchKernelGGL(k_td_dh_wt, dim3((h->J / 32) * K + nx * K * 2), dim3(256), 0, q, ta, wb, nx);
@@ -738,7 +904,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     }
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
-    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3_3 = h->conv3_bwd ? h->da3_3 : nullptr; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
     dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
     {  // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
         const long wg4 = (long)K * nb * cdiv(dd.n_ft, 4), wg3 = (long)K * nb * cdiv(dd.n_ft, 3);
@@ -758,7 +924,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     }
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
     int rcw = launch_dense0_wgrad(h, s.a3, h->dh, nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
-                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_adam && !stop_after_dense0);
+                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q);
     if (rcw) return rcw;
     if (stop_after_dense0) {
         h->pend_B = B; h->pend_stage = 2;
@@ -771,87 +937,46 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
 int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     const int K = h->cfg.n_heads, nb = cdiv(B, 32);
     NetSet& s = h->train;
-    const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
-    // conv data gradients
-    const ConvL* cl[3] = {c0, c1, c2};
-    const float* douts[3] = {h->da1, h->da2, h->da3};
-    const ActGeom* gdo[3] = {&h->gda1, &h->gda2, &h->gda3};
-    const float* acts_in[3] = {s.x, s.a1, s.a2};
-    const ActGeom* gact[3] = {&h->gx, &h->ga1, &h->ga2};
-    float* dins[3] = {nullptr, h->da1, h->da2};
-    const ActGeom* gdi[3] = {nullptr, &h->gda1, &h->gda2};
-    // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
-    if (!h->conv3_bwd && h->mix_stage == 0) {  // (the bf16x3 and staged-mix paths built them earlier)
-        int rcb = build_dgrad_weights(h, q);
-        if (rcb) return rcb;
-    }
-    const unsigned short* douts3[3] = {nullptr, h->da2_3, h->da3_3};
-    unsigned short* dins3[3] = {nullptr, nullptr, h->da2_3};
-    for (int i = 2; i >= 1 && h->conv3_bwd; --i) {
-        const ConvL& l = *cl[i];
-        const int KHs = l.K / l.S, nvar = l.S * l.S;
-        Conv3Args a;
-        memset(&a, 0, sizeof(a));
-        a.in3 = douts3[i]; a.out = dins[i]; a.out3 = dins3[i]; a.wbase = s.wbase; a.w3 = h->w3; a.w3_stride = h->w3_stride;
-        a.in_split = 0; a.mask = acts_in[i];
-        a.in_block = gdo[i]->block; a.out_block = gdi[i]->block; a.mask_block = gact[i]->block;
-        a.n_nets = K; a.nb = nb; a.n_var = nvar; a.epilogue = 1; a.f32_nets = K;
-        a.KH = KHs; a.KWCI = KHs * l.CO; a.S = 1; a.CI = l.CO; a.CO = l.CI; a.IWp = gdo[i]->Wp;
-        a.out_Wp = gdi[i]->Wp; a.out_lo_h = gdi[i]->lo_h; a.out_lo_w = gdi[i]->lo_w;
-        a.mask_Wp = gact[i]->Wp; a.mask_lo_h = gact[i]->lo_h; a.mask_lo_w = gact[i]->lo_w;
-        IDQN_REQUIRE(a.KWCI % 32 == 0, "conv %d dgrad: %d rows per kernel row is not a multiple of 32", i, a.KWCI);
-        const int npw = (l.CI == 32) ? 4 : 2;
-        int pg = 0;
-        for (int vi = 0; vi < nvar; ++vi) {
-            const int rh = vi / l.S, rw = vi % l.S;
-            const int ph = (rh + l.PLh) % l.S, pw = (rw + l.PLw) % l.S;
-            ConvVariant& v = a.var[vi];
-            v.w_off = h->w3_dg[i] + (long)vi * KHs * KHs * l.CO * l.CI * 3;
-            v.in_off_h = (rh + l.PLh - ph) / l.S + gdo[i]->lo_h - KHs + 1;
-            v.in_off_w = (rw + l.PLw - pw) / l.S + gdo[i]->lo_w - KHs + 1;
-            v.OH = (l.IH - rh + l.S - 1) / l.S; v.OW = (l.IW - rw + l.S - 1) / l.S;
-            v.out_mul = l.S; v.out_add_h = rh; v.out_add_w = rw; v.pg_begin = pg;
-            IDQN_REQUIRE(v.in_off_h >= 0 && v.in_off_w >= 0 && v.OH > 0 && v.OW > 0, "conv %d dgrad: bad variant geometry", i);
-            pg += cdiv(v.OH * v.OW, npw);
-        }
-        a.npg = pg;
-        a.n_items = (long)K * nb * a.npg;
-        if (l.CI == 32)
-            hipLaunchKernelGGL((k_conv3<1, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-        else
-            hipLaunchKernelGGL((k_conv3<2, C3_RING>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-    }
-    for (int i = 2; i >= 1 && !h->conv3_bwd && h->mix_stage == 0; --i) {
-        const ConvL& l = *cl[i];
-        ConvFwdArgs a;
-        int rcd = make_dgrad_args(h, i, nb, a);
-        if (rcd) return rcd;
-        if (l.CI == 32)
-            hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-        else
-            hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
-    }
-    if (h->mix_stage == 1) {  // IDQN_MIX=2: stage A (Conv_2 gradients) ran beside the first Dense_0 slice; now B and C
-        int rcm = launch_mix_stage(h, 1, nb, q);
-        if (!rcm) rcm = launch_mix_stage(h, 0, nb, q);
-        if (rcm) return rcm;
-    }
-    // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
+    const ConvL* cl[3] = {&h->conv[0], &h->conv[1], &h->conv[2]};
     SlabReduceArgs r;
     r.grad = h->grad; r.gP = h->gP; r.K = K; r.n_seg = 3;
     long nblk = 0;
+    if (h->planes) {
+        // data gradients (stride-1 convolutions over the zero-bordered dout planes), then the weight gradients
+        int rc = planes_conv(h, s, 3, nb, q);
+        if (!rc) rc = planes_conv(h, s, 4, nb, q);
+        for (int i = 2; i >= 0 && !rc; --i) rc = planes_wgrad(h, i, nb, q);
+        if (rc) return rc;
+    } else {
+        // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
+        int rcb = build_dgrad_weights(h, q);
+        if (rcb) return rcb;
+        for (int i = 2; i >= 1; --i) {
+            const ConvL& l = *cl[i];
+            ConvFwdArgs a;
+            int rcd = make_dgrad_args(h, i, nb, a);
+            if (rcd) return rcd;
+            if (l.CI == 32)
+                hipLaunchKernelGGL((k_conv_fwd<1, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+            else
+                hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
+        }
+    }
+    // conv weight gradients: slabs (one region per layer), then ONE reduce launch into the gradient arena
     for (int i = 2; i >= 0; --i) {
-        ConvWgradArgs a = make_wgrad_args(h, i, nb);
-        const int nit = a.CIe / 32, not_ = a.CO / 32;
-        dim3 grid((unsigned)a.n_items);
-        if ((i == 2 && h->mix_done) || h->mix_stage == 1) {}  // already computed beside the fused Dense_0 update
-        else if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
-        else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
-        else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
-        else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
+        const ConvL& l = *cl[i];
+        if (!h->planes) {
+            ConvWgradArgs a = make_wgrad_args(h, i, nb);
+            const int nit = a.CIe / 32, not_ = a.CO / 32;
+            dim3 grid((unsigned)a.n_items);
+            if (nit == 1 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(256), 0, q, a);
+            else if (nit == 1 && not_ == 2) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(256), 0, q, a);
+            else if (nit == 2 && not_ == 1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(256), 0, q, a);
+            else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
+        }
         SlabSeg& g = r.seg[2 - i];
-        g.slab = a.slab; g.slab_stride = a.slab_stride; g.w_off = cl[i]->w_off; g.b_off = cl[i]->b_off;
-        g.wsize = (long)a.KH * a.KWe * a.CIe * a.CO; g.npc = a.npc; g.bsize = a.CO;
+        g.slab = h->slab + h->slab_off[i]; g.slab_stride = h->slab_stride[i]; g.w_off = l.w_off; g.b_off = l.b_off;
+        g.wsize = (long)l.K * l.K * l.CI * l.CO; g.npc = h->npc[i]; g.bsize = l.CO;
         g.first_block = nblk;
         nblk += cdiv(g.wsize + g.bsize, 256);
     }
@@ -914,12 +1039,10 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
         h->gP = h->L.head_stride - (h->g_w0_end - h->g_w0_begin);
     }
     h->g_w0_base = (long)cfg->n_heads * h->gP + 64;
-    {  // conv arithmetic: f32 MFMA, or f32-accurate products on the bf16 matrix cores (conv3_kernels.h)
+    {  // conv arithmetic: f32-accurate products on the bf16 matrix cores (convp.h, the default), or the f32 MFMA kernels
         const char* mode = getenv("IDQN_CONV");
-        h->conv3_bwd = cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3") == 0;
-        h->mix_mode = getenv("IDQN_MIX") ? atoi(getenv("IDQN_MIX")) : 0;
-        h->mix = h->mix_mode == 1;
-        h->conv3 = h->conv3_bwd || (cfg->arch == IDQN_ARCH_CNN && mode && strcmp(mode, "bf16x3-forward") == 0);
+        h->planes = cfg->arch == IDQN_ARCH_CNN && !(mode && strcmp(mode, "f32") == 0);
+        IDQN_REQUIRE(!mode || !strcmp(mode, "f32") || !strcmp(mode, "bf16x3"), "IDQN_CONV must be f32 or bf16x3, got '%s'", mode);
     }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
     if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
