@@ -181,11 +181,9 @@ int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items
     IDQN_REQUIRE(lds_bytes <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes);
     const int ntw = (MT * CT + 3) / 4;
     if (NPX == 1) {
-        IDQN_REQUIRE(a.PG == 4, "plane wgrad: Conv_0 stages 4 positions");
-        if (CT == 1 && ntw == 2) return launch_one<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q);
-        if (CT == 2 && ntw == 4) return launch_one<1, 2, 4, 4>(a, MT, n_items, lds_bytes, q);
-    } else {
-        IDQN_REQUIRE(a.PG == 2, "plane wgrad: stages of 2 positions");
+        if (CT == 1 && ntw == 2 && a.PG == 4) return launch_one<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q);
+        if (CT == 2 && ntw == 4 && a.PG == 2) return launch_one<1, 2, 4, 2>(a, MT, n_items, lds_bytes, q);
+    } else if (a.PG == 2) {
         if (CT == 1) switch (ntw) {
             case 1: return launch_one<3, 1, 1, 2>(a, MT, n_items, lds_bytes, q);
             case 2: return launch_one<3, 1, 2, 2>(a, MT, n_items, lds_bytes, q);
@@ -195,6 +193,18 @@ int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items
             case 2: return launch_one<3, 2, 2, 2>(a, MT, n_items, lds_bytes, q);
             case 3: return launch_one<3, 2, 3, 2>(a, MT, n_items, lds_bytes, q);
             case 4: return launch_one<3, 2, 4, 2>(a, MT, n_items, lds_bytes, q);
+            default: break;
+        }
+    } else if (a.PG == 1) {  // wide input pixels (64 channels, stride 2): one position per stage fits the LDS
+        if (CT == 1) switch (ntw) {
+            case 1: return launch_one<3, 1, 1, 1>(a, MT, n_items, lds_bytes, q);
+            case 2: return launch_one<3, 1, 2, 1>(a, MT, n_items, lds_bytes, q);
+            default: break;
+        }
+        else switch (ntw) {
+            case 2: return launch_one<3, 2, 2, 1>(a, MT, n_items, lds_bytes, q);
+            case 3: return launch_one<3, 2, 3, 1>(a, MT, n_items, lds_bytes, q);
+            case 4: return launch_one<3, 2, 4, 1>(a, MT, n_items, lds_bytes, q);
             default: break;
         }
     }

@@ -570,11 +570,14 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out) {
     const int K = h->cfg.n_heads, npos = l.OH * l.OW, nch = h->npc[layer];
     WgradPlan pl;
     pl.n_chunks = nch;
-    pl.PG = layer == 0 ? 4 : 2;
     pl.MT = layer == 0 ? l.K : l.K * l.CI / 32;
     const long dy_pix = 3L * l.CO * 64, x_pix = (layer == 0 ? 1L : 3L) * l.CI * 64;
-    const long XB = layer == 0 ? (long)l.K * (pl.PG + 1) * 1024 : ((pl.PG - 1) * l.S + l.K) * x_pix;
-    pl.lds = (size_t)(2 * (XB + pl.PG * dy_pix));
+    for (pl.PG = layer == 0 ? 4 : 2;; --pl.PG) {  // positions per LDS stage: as many as two stages leave room for
+        const long XB = layer == 0 ? (long)l.K * (pl.PG + 1) * 1024 : ((pl.PG - 1) * l.S + l.K) * x_pix;
+        pl.lds = (size_t)(2 * (XB + pl.PG * dy_pix));
+        if (pl.lds <= 160 * 1024 || pl.PG == 1) break;
+        if (layer == 0) --pl.PG;  // Conv_0: 4 or 2 positions
+    }
     IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
     std::vector<CWItem> items;
     for (int k = 0; k < K; ++k)
