@@ -25,6 +25,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 #define CP_MAX_STRIPS 4  // input rows one workgroup's output positions may span
 
@@ -42,15 +46,18 @@ struct CVar {  // one sub-convolution of a launch (forward: one; data gradient o
 struct CFwdArgs {
     const unsigned short* in;   // input planes
     const unsigned short* wq;   // packed weights
-    const CItem* items;
-    const float* const* wbase;  // [n_nets] f32 parameter bases (bias)
+    const float* pbase[2];      // f32 parameter arenas: net n < n_first reads pbase[0] + n * pstride, else pbase[1] + (n - n_first) * pstride
     unsigned short* out3;       // output planes or nullptr
     float* out_f32;             // f32 rows [slot][(yh * f32_W + yw) * CO + co][32] or nullptr (Conv_2 -> Dense_0 input)
     const unsigned short* mask3;  // epilogue 1: forward activation planes whose sign masks the result (plane 0 is read)
     float* pb;                  // epilogue 1: per-position sums over the 32 samples [slot][pos][CO] (bias gradient) or nullptr
     long wq_stride;             // bytes per net
     long in_slot, out_slot, mask_slot, f32_slot;  // bytes / bytes / bytes / floats per (net, batch block)
-    long b_off;
+    long b_off, pstride;
+    int n_first;
+    // work items (no table: a workgroup derives its item from its index): per (net, batch block) slot, variant v has
+    // r_cnt[v] balanced ranges of its OH * OW positions, the ranges of variant v start at r_begin[v]
+    int items_per_slot, r_begin[4], r_cnt[4];
     int in_split;   // input slot of net n: (in_split > 0 ? n >= in_split : n) * nb + bb
     int nb, n_var, epilogue;
     int KH, NCC, S, SX, CO;           // NCC = 16-channel chunks per tap (1 for Conv_0); SX = pixel chunks per output step
@@ -127,12 +134,41 @@ __device__ __forceinline__ void dma16(unsigned voff, unsigned long sbase, unsign
                  : "memory", "m0");
 }
 
+// Touch every 64-byte line of the kernel-argument segment with back-to-back scalar loads at kernel entry.  hipcc loads
+// argument fields lazily, next to their first use: a prologue that needs ~60 of them in dependent steps paid 8 scalar
+// round trips (measured ~4000 cycles); after this warm-up they all hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    static_assert(BYTES <= 8 * 64, "kernel arguments longer than 8 cache lines");
+    auto kp = (const __attribute__((address_space(4))) u32x4*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (BYTES + 63) / 64;  // lines; all loads are issued before the one wait the asm statement forces
+    const u32x4 v0 = kp[0], v1 = kp[L > 1 ? 4 : 0], v2 = kp[L > 2 ? 8 : 0], v3 = kp[L > 3 ? 12 : 0];
+    const u32x4 v4 = kp[L > 4 ? 16 : 0], v5 = kp[L > 5 ? 20 : 0], v6 = kp[L > 6 ? 24 : 0], v7 = kp[L > 7 ? 28 : 0];
+    asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits until at most n of this
+// wave's vector-memory operations (LDS-DMA copies included) are outstanding
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define CP_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        CP_W(1) CP_W(2) CP_W(3) CP_W(4) CP_W(5) CP_W(6) CP_W(7) CP_W(8) CP_W(9) CP_W(10) CP_W(11) CP_W(12) CP_W(13) CP_W(14)
+        CP_W(15) CP_W(16) CP_W(17) CP_W(18) CP_W(19) CP_W(20) CP_W(21) CP_W(22) CP_W(23) CP_W(24) CP_W(25) CP_W(26) CP_W(27)
+        CP_W(28) CP_W(29) CP_W(30) CP_W(31) CP_W(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // 0, or more than the cases cover: wait for all
+    }
+#undef CP_W
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // host-side launchers (convp_fwd.hip / convp_wgrad.hip / convp_stage.hip)
-int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t lds_bytes, hipStream_t q);
+// stage_bytes: one of the two LDS stage buffers; lds_bytes: whole dynamic LDS (convp_fwd_lds)
+int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, size_t lds_bytes,
+                     hipStream_t q, long long* prof = nullptr);
+size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue);  // prof: per-workgroup phase stamps [n_items][8] (debugging) or nullptr
 int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
 int convp_fwd_max_nt(int CT);

@@ -14,7 +14,15 @@
 // double-buffered, one s_barrier per superstep, then NQ x NT tile-steps of 6 (Conv_0: 3) MFMAs from LDS fragments.
 // Orientation: A = activations (rows = samples), B = weights (columns = channels), so a lane ends up with 4 x 4
 // consecutive samples of ONE channel: plane rows are written as 8-byte pieces, the bias / mask is one value per lane.
+#include <cstdlib>
+
 #include "convp.h"
+
+#ifndef CP_ABLATE
+#define CP_ABLATE 0  // timing experiments only (results are wrong): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA in the loop
+#endif
+
+int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue);
 
 namespace {
 
@@ -24,18 +32,47 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* p) {
     s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q + 32);  // 4 rows (256 B) on
     return __builtin_shufflevector(__builtin_bit_cast(bf16x4, v0), __builtin_bit_cast(bf16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
 }
+__device__ __forceinline__ s16x4 tr_half(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 v0, s16x4 v1) {
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, v0), __builtin_bit_cast(bf16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+}
 __device__ __forceinline__ bf16x8 frag_lin(const unsigned char* p) {
     return *(const __attribute__((address_space(3))) bf16x8*)p;
 }
 
 template <int NPA, int CT, int NQ, int NT>
-__global__ __launch_bounds__(256) void k_cfwd(CFwdArgs a, unsigned stage_bytes) {
+__global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, int ring, long long* prof) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int WB = NQ * CT * 3 * 1024, BLKA = NPA * 1024, NWP = NQ * CT * 3;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const CItem it = a.items[xcd_contiguous_id()];  // an XCD walks consecutive items of one net
-    const CVar& v = a.var[it.var];
+    // waves 0-3 compute (one per SIMD), waves 4-7 only issue the LDS-DMA copies: a wave that did both kept its matrix pipe
+    // idle for the ~1000 cycles per superstep its ~11 copies take to issue
+    const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    // (stamps are unconditional up to the loop: a branch here splits the block and the kernel-argument loads, which the
+    // scheduler otherwise batches at the top, become a chain of dependent round trips)
+    const long long pt0 = clock64(), pw0 = wall_clock64();
+    warm_kernargs<sizeof(CFwdArgs)>();
+    CItem it;  // derived from the workgroup index (an XCD walks consecutive items of one net): no dependent load
+    int vi = 0;
+    {
+        const int b = xcd_contiguous_id();
+        const int slot = b / a.items_per_slot, rr = b - slot * a.items_per_slot;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < a.n_var && rr >= a.r_begin[i]) vi = i;
+        it.net = slot / a.nb;
+        it.bb = slot - it.net * a.nb;
+        it.var = vi;
+        const int r = rr - a.r_begin[vi], npos_v = a.var[vi].OH * a.var[vi].OW, R = a.r_cnt[vi];
+        const int base = npos_v / R, rem = npos_v - base * R;
+        it.p0 = r * base + min(r, rem);
+        it.np = base + (r < rem ? 1 : 0);
+    }
+    const CVar& v = a.var[vi];
     const int OW = v.OW, p0 = it.p0, np = it.np;
     const int in_slot = (a.in_split > 0 ? (it.net >= a.in_split ? 1 : 0) : it.net) * a.nb + it.bb;
     const int out_slot = it.net * a.nb + it.bb;
@@ -85,16 +122,16 @@ __global__ __launch_bounds__(256) void k_cfwd(CFwdArgs a, unsigned stage_bytes) 
     const unsigned long wb0 = (unsigned long)a.wq + (unsigned long)it.net * a.wq_stride + (unsigned long)v.w_off;
     const int NSS = a.KH * a.NCC;
 
-    auto stage = [&](int ss, unsigned buf) {
+    auto stage = [&](int ss, unsigned buf, int first, int step) {
         const int kh = ss / a.NCC, cc = ss - kh * a.NCC;
         const unsigned long wsrc = wb0 + (unsigned long)ss * WB;
-        for (int i = wave; i < NWP; i += 4) dma16(lane16, wsrc + (unsigned long)i * 1024, buf + i * 1024);
+        for (int i = first; i < NWP; i += step) dma16(lane16, wsrc + (unsigned long)i * 1024, buf + i * 1024);
         const unsigned long so_ = (unsigned long)kh * (unsigned long)a.row_bytes + (unsigned long)cc * 1024;
 #pragma unroll
         for (int r = 0; r < CP_MAX_STRIPS; ++r) {
             const unsigned long src = sb[r] + so_;
             const unsigned dst = buf + WB + soff[r];
-            for (int x = wave; x < nx[r]; x += 4) {
+            for (int x = first; x < nx[r]; x += step) {
 #pragma unroll
                 for (int pl = 0; pl < NPA; ++pl)
                     dma16(lane16, src + (unsigned long)x * (unsigned long)a.xstep + (unsigned long)pl * (unsigned long)a.plane_bytes,
@@ -103,89 +140,175 @@ __global__ __launch_bounds__(256) void k_cfwd(CFwdArgs a, unsigned stage_bytes) 
         }
     };
 
+    // epilogue operands that only depend on the item: requested now, used after the loop
+    const int co = ct * 32 + cl;
+    float bias = 0.f;
+    if (a.epilogue == 0)
+        bias = (it.net < a.n_first ? a.pbase[0] + (long)it.net * a.pstride : a.pbase[1] + (long)(it.net - a.n_first) * a.pstride)[a.b_off + co];
+    // data gradient: the ReLU mask = plane 0 of the forward activation at the output pixel, 2 KB per tile, copied into
+    // LDS behind the stage buffers while the last superstep computes
+    const unsigned mask_lds = ring * stage_bytes + wave * (NT * 2048);
+    auto tile_out = [&](int p, int& yh, int& yw) {
+        const int oh = p / OW, ow = p - oh * OW;
+        yh = oh * v.out_mul + v.out_add_h;
+        yw = ow * v.out_mul + v.out_add_w;
+    };
+
     f32x16 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    stage(0, lds0);
+    const long long pt1 = clock64();
+    long long pwait = 0, pt2 = 0;
+    if (loader) {
+        // ---- loader waves: copy `ring - 1` supersteps ahead while the compute waves work ----------------------------
+        // Superstep ss + ring - 1 goes into the buffer superstep ss - 1 was read from, right after barrier ss.  Before
+        // barrier ss a loader only needs ITS copies of superstep ss to have landed: vmcnt counts in issue order, so it
+        // waits until at most the copies of the younger supersteps (cnt per superstep, the same every time) are left.
+        int cnt = (NWP - wave + 3) / 4;
+#pragma unroll
+        for (int r = 0; r < CP_MAX_STRIPS; ++r) cnt += ((nx[r] - wave + 3) / 4) * NPA;
+        const int ahead = ring - 1;
+        for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
+        int nbuf = ahead == 2 ? 2 : 1;  // buffer of superstep ss + ahead
+        long long l_wait = 0, l_bar = 0, l_issue = 0;
+        for (int ss = 0; ss < NSS; ++ss) {
+            const long long c0 = prof ? clock64() : 0;
+            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? cnt : 0);
+            const long long c1 = prof ? clock64() : 0;
+            __builtin_amdgcn_s_barrier();  // everybody's copies of ss have landed; nobody still reads the buffer re-filled next
+            const long long c2 = prof ? clock64() : 0;
+            if (ss + ahead < NSS && !(CP_ABLATE & 2)) stage(ss + ahead, lds0 + nbuf * stage_bytes, wave, 4);
+            if (prof) { l_wait += c1 - c0; l_bar += c2 - c1; l_issue += clock64() - c2; }
+            nbuf = nbuf + 1 == ring ? 0 : nbuf + 1;
+            if (ss + 1 == NSS && a.epilogue == 1) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (tpos[i] < 0) continue;
+                    int yh, yw;
+                    tile_out(tpos[i], yh, yw);
+                    const unsigned long msrc = (unsigned long)a.mask3 + (unsigned long)out_slot * a.mask_slot +
+                        ((unsigned long)((yh + a.mask_lo_h) * a.mask_Wp + (yw + a.mask_lo_w)) * (3UL * a.mask_C) + ct * 32) * 64;
+                    dma16(lane16, msrc, lds0 + mask_lds + i * 2048);
+                    dma16(lane16, msrc + 1024, lds0 + mask_lds + i * 2048 + 1024);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the mask copies
+        __builtin_amdgcn_s_barrier();
+        if (prof && t == 256) {
+            long long* pr = prof + 8L * 4096 + (long)blockIdx.x * 8;
+            pr[0] = l_wait; pr[1] = l_bar; pr[2] = l_issue; pr[3] = cnt;
+        }
+        return;
+    }
+    // ---- compute waves -------------------------------------------------------------------------------------------
+    // Fragment reads of tile-step u + 1 are issued one per gap BETWEEN the MFMAs of tile-step u (the wave issues an MFMA,
+    // is free for the ~32 cycles it runs, and blocks at the next, dependent one): sched_barrier pins that order.
+    int cbuf = 0;
     for (int ss = 0; ss < NSS; ++ss) {
-        const unsigned cur_off = (ss & 1) * stage_bytes;
-        // this wave's copies of superstep ss have landed; the barrier tells it so has everybody else's, and that
-        // nobody still reads the other buffer (superstep ss - 1), which is re-filled next
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned cur_off = cbuf * stage_bytes;
+        cbuf = cbuf + 1 == ring ? 0 : cbuf + 1;
+        const long long pw = prof ? clock64() : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ss + 1 < NSS) stage(ss + 1, lds0 + ((ss + 1) & 1) * stage_bytes);
+        if (prof) { const long long now = clock64(); pwait += now - pw; if (ss == 0) pt2 = now; }
+        if (CP_ABLATE & 1) continue;
         const unsigned char* cur = lds + cur_off;
-        bf16x8 wf[2][3], af[2][NPA];
+        // Fragments: the activation halves of tile-step u + 2 are requested in the gaps between the MFMAs of tile-step u
+        // (a ring of three register sets), the weight planes of tap q + 1 during the last-but-one tile-step of tap q:
+        // every ds_read has at least one whole tile-step (~190 cycles) to return before an MFMA waits for it.
+        constexpr int U = NQ * NT, NM = NPA == 3 ? 6 : 3, WSTEP = NT >= 2 ? NT - 2 : 0;
+        bf16x8 wf[2][3];
+        s16x4 ah[3][NPA][2];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wf[0][pl] = frag_lin(cur + (ct * 3 + pl) * 1024 + lane16);
 #pragma unroll
-        for (int pl = 0; pl < NPA; ++pl) af[0][pl] = frag_tr(cur + abase[0] + pl * 1024 + lo_tr);
+        for (int u0 = 0; u0 < 2 && u0 < U; ++u0)
+#pragma unroll
+            for (int pl = 0; pl < NPA; ++pl) {
+                const unsigned char* ap = cur + abase[u0 % NT] + (u0 / NT) * BLKA + pl * 1024 + lo_tr;
+                ah[u0][pl][0] = tr_half(ap);
+                ah[u0][pl][1] = tr_half(ap + 256);
+            }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int u = q * NT + i;
-                // fragments of the next tile-step are requested before this one's MFMAs
-                if (i == NT - 1 && q + 1 < NQ) {
+                const bool next_w = (i == WSTEP && q + 1 < NQ), next_a = (u + 2 < U);
+                const int qn = (u + 2) / NT, in_ = (u + 2) % NT;
+                const unsigned char* an = cur + abase[next_a ? in_ : 0] + qn * BLKA + lo_tr;
+                const unsigned char* wn = cur + (((q + 1) * CT + ct) * 3) * 1024 + lane16;
+                bf16x8 A[NPA];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        wf[(q + 1) & 1][pl] = frag_lin(cur + (((q + 1) * CT + ct) * 3 + pl) * 1024 + lane16);
-                }
-                if (u + 1 < NQ * NT) {
-                    const int qn = (u + 1) / NT, in_ = (u + 1) % NT;
-#pragma unroll
-                    for (int pl = 0; pl < NPA; ++pl)
-                        af[(u + 1) & 1][pl] = frag_tr(cur + abase[in_] + qn * BLKA + pl * 1024 + lo_tr);
-                }
-                const bf16x8* A = af[u & 1];
+                for (int pl = 0; pl < NPA; ++pl) A[pl] = join8(ah[u % 3][pl][0], ah[u % 3][pl][1]);
                 const bf16x8* W = wf[q & 1];
+                __builtin_amdgcn_sched_barrier(0);
+#define CF_GAP(m)                                                                                              \
+    {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (next_a && (m) < 2 * NPA) ah[(u + 2) % 3][((m) / 2) % NPA][(m) % 2] = tr_half(an + ((m) / 2) * 1024 + ((m) % 2) * 256); \
+        if (next_w && (m) < 3) wf[(q + 1) & 1][(m) < 3 ? (m) : 0] = frag_lin(wn + (m) * 1024);                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
                 if (NPA == 3) {  // smallest terms first
                     acc[i] = mfma_bf16(A[2], W[0], acc[i]);
+                    CF_GAP(0)
                     acc[i] = mfma_bf16(A[0], W[2], acc[i]);
+                    CF_GAP(1)
                     acc[i] = mfma_bf16(A[1], W[1], acc[i]);
+                    CF_GAP(2)
                     acc[i] = mfma_bf16(A[1], W[0], acc[i]);
+                    CF_GAP(3)
                     acc[i] = mfma_bf16(A[0], W[1], acc[i]);
+                    CF_GAP(4)
                     acc[i] = mfma_bf16(A[0], W[0], acc[i]);
+                    CF_GAP(5)
                 } else {
                     acc[i] = mfma_bf16(A[0], W[2], acc[i]);
+                    CF_GAP(0)
                     acc[i] = mfma_bf16(A[0], W[1], acc[i]);
+                    CF_GAP(1)
                     acc[i] = mfma_bf16(A[0], W[0], acc[i]);
+                    CF_GAP(2)
                 }
+#undef CF_GAP
+                (void)NM;
             }
         }
     }
 
+    const long long pt3 = prof ? clock64() : 0;
     // ---- epilogue: lane = channel co, registers = samples (r & 3) + 8 (r >> 2) + 4 h -------------------------------
-    const int co = ct * 32 + cl;
-    float bias = 0.f;
-    if (a.epilogue == 0) bias = a.wbase[it.net][a.b_off + co];
+    // A lane's values of a tile are 8-byte pieces of 64-byte rows; written straight to HBM every store instruction would
+    // touch 32 rows (measured: ~330 cycles each).  Each wave therefore turns its tile around in LDS (the stage buffers
+    // are free now) and stores whole 1 KiB runs: 16 rows of a plane, or 8 rows of the f32 copy, per instruction.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the loaders' mask copies have landed; every wave is done with the stage buffers
+    unsigned char* R = lds + wave * 10240;  // [3 planes x 2 KB | f32 4 KB]
+    const unsigned wsw = (cl >> 1) & 3;                                      // plane rows: 16-byte slot ^ (row >> 1) & 3
+    const unsigned rsw = (lane * 16) ^ ((((unsigned)lane >> 3) & 3) << 4);   // = row (lane >> 2), slot (lane & 3) ^ swizzle
+    const unsigned fsw = (lane * 16) ^ ((((unsigned)lane >> 3) & 7) << 4);   // f32 rows: slot (lane & 7) ^ (row & 7)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         if (tpos[i] < 0) continue;  // wave-uniform
-        const int p = tpos[i];
-        const int oh = p / OW, ow = p - oh * OW;
-        const int yh = oh * v.out_mul + v.out_add_h, yw = ow * v.out_mul + v.out_add_w;
+        int yh, yw;
+        tile_out(tpos[i], yh, yw);
         float val[16];
         if (a.epilogue == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) val[r] = fmaxf(acc[i][r] + bias, 0.f);
         } else {
-            const unsigned short* M = a.mask3 + ((unsigned long)out_slot * a.mask_slot) / 2 +
-                                      ((long)(yh + a.mask_lo_h) * a.mask_Wp + (yw + a.mask_lo_w)) * (3L * a.mask_C * 32) +
-                                      (long)co * 32 + 4 * h;
-            uint2 mk[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mk[g] = *reinterpret_cast<const uint2*>(M + 8 * g);
+            const unsigned char* M = lds + mask_lds + i * 2048 + cl * 64 + 8 * h;
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const unsigned w0 = mk[g].x, w1 = mk[g].y;
-                const float m0 = __uint_as_float(w0 << 16), m1 = __uint_as_float(w0 & 0xffff0000u);
-                const float m2 = __uint_as_float(w1 << 16), m3 = __uint_as_float(w1 & 0xffff0000u);
+                const u32x2 mk = *LDS_PTR(const u32x2, M + 16 * g);
+                const float m0 = __uint_as_float(mk.x << 16), m1 = __uint_as_float(mk.x & 0xffff0000u);
+                const float m2 = __uint_as_float(mk.y << 16), m3 = __uint_as_float(mk.y & 0xffff0000u);
                 val[4 * g + 0] = m0 > 0.f ? acc[i][4 * g + 0] : 0.f;
                 val[4 * g + 1] = m1 > 0.f ? acc[i][4 * g + 1] : 0.f;
                 val[4 * g + 2] = m2 > 0.f ? acc[i][4 * g + 2] : 0.f;
@@ -199,52 +322,75 @@ __global__ __launch_bounds__(256) void k_cfwd(CFwdArgs a, unsigned stage_bytes) 
             }
         }
         if (a.out3) {
-            unsigned short* O = a.out3 + ((unsigned long)out_slot * a.out_slot) / 2 +
-                                ((long)(yh + a.out_lo_h) * a.out_Wp + (yw + a.out_lo_w)) * (3L * a.CO * 32) + (long)co * 32 + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 unsigned q0a, q1a, q2a, q0b, q1b, q2b;
                 split3_pk(val[4 * g + 0], val[4 * g + 1], q0a, q1a, q2a);
                 split3_pk(val[4 * g + 2], val[4 * g + 3], q0b, q1b, q2b);
-                *reinterpret_cast<uint2*>(O + 8 * g) = make_uint2(q0a, q0b);
-                *reinterpret_cast<uint2*>(O + (long)a.CO * 32 + 8 * g) = make_uint2(q1a, q1b);
-                *reinterpret_cast<uint2*>(O + 2L * a.CO * 32 + 8 * g) = make_uint2(q2a, q2b);
+                unsigned char* wp = R + cl * 64 + ((g ^ wsw) * 16) + 8 * h;
+                *LDS_PTR(u32x2, wp) = (u32x2){q0a, q0b};
+                *LDS_PTR(u32x2, wp + 2048) = (u32x2){q1a, q1b};
+                *LDS_PTR(u32x2, wp + 4096) = (u32x2){q2a, q2b};
             }
         }
         if (a.out_f32) {
-            float* F = a.out_f32 + (long)out_slot * a.f32_slot + (((long)yh * a.f32_W + yw) * a.CO + co) * 32 + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(F + 8 * g) = make_float4(val[4 * g], val[4 * g + 1], val[4 * g + 2], val[4 * g + 3]);
+                *LDS_PTR(f32x4, R + 6144 + cl * 128 + (((2 * g + h) ^ (cl & 7)) * 16)) =
+                    (f32x4){val[4 * g], val[4 * g + 1], val[4 * g + 2], val[4 * g + 3]};
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in order: its writes are visible to its reads
+        if (a.out3) {
+            unsigned char* O = (unsigned char*)a.out3 + (unsigned long)out_slot * a.out_slot +
+                               ((unsigned long)((yh + a.out_lo_h) * a.out_Wp + (yw + a.out_lo_w)) * (3UL * a.CO) + ct * 32) * 64 + lane16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = *LDS_PTR(const u32x4, R + pl * 2048 + j * 1024 + rsw);
+        }
+        if (a.out_f32) {
+            float* F = a.out_f32 + (long)out_slot * a.f32_slot + (((long)yh * a.f32_W + yw) * a.CO + ct * 32) * 32 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(F + j * 256) = *LDS_PTR(const f32x4, R + 6144 + j * 1024 + fsw);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next one overwrites it
+    }
+    if (prof && t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* pr = prof + (long)blockIdx.x * 8;
+        pr[0] = pw0; pr[1] = pt1 - pt0; pr[2] = pt2 - pt1; pr[3] = pt3 - pt2; pr[4] = clock64() - pt3; pr[5] = pwait; pr[6] = wall_clock64();
+        pr[7] = it.np;
     }
 }
 
 template <int NPA, int CT, int NQ, int NT>
-int launch_one(const CFwdArgs& a, int n_items, size_t lds_bytes, hipStream_t q) {
+int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, size_t lds_bytes, hipStream_t q, long long* prof) {
+    const int ring = convp_fwd_ring(stage_bytes, NT, a.epilogue);
     static size_t attr = 0;  // per instantiation
     if (lds_bytes > attr) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cfwd<NPA, CT, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr = lds_bytes;
     }
-    hipLaunchKernelGGL((k_cfwd<NPA, CT, NQ, NT>), dim3((unsigned)n_items), dim3(256), lds_bytes, q, a, (unsigned)(lds_bytes / 2));
+    hipLaunchKernelGGL((k_cfwd<NPA, CT, NQ, NT>), dim3((unsigned)n_items), dim3(512), lds_bytes, q, a, (unsigned)stage_bytes, ring, prof);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
 
 template <int NPA, int CT, int NQ>
-int launch_nt(const CFwdArgs& a, int NT, int n_items, size_t lds_bytes, hipStream_t q) {
+int launch_nt(const CFwdArgs& a, int NT, int n_items, size_t stage_bytes, size_t lds_bytes, hipStream_t q, long long* prof) {
     switch (NT) {
-        case 1: return launch_one<NPA, CT, NQ, 1>(a, n_items, lds_bytes, q);
-        case 2: return launch_one<NPA, CT, NQ, 2>(a, n_items, lds_bytes, q);
-        case 3: return launch_one<NPA, CT, NQ, 3>(a, n_items, lds_bytes, q);
+        case 1: return launch_one<NPA, CT, NQ, 1>(a, n_items, stage_bytes, lds_bytes, q, prof);
+        case 2: return launch_one<NPA, CT, NQ, 2>(a, n_items, stage_bytes, lds_bytes, q, prof);
+        case 3: return launch_one<NPA, CT, NQ, 3>(a, n_items, stage_bytes, lds_bytes, q, prof);
         default: break;
     }
     if (CT == 1) {
         switch (NT) {
-            case 4: return launch_one<NPA, 1, NQ, 4>(a, n_items, lds_bytes, q);
-            case 5: return launch_one<NPA, 1, NQ, 5>(a, n_items, lds_bytes, q);
-            case 6: return launch_one<NPA, 1, NQ, 6>(a, n_items, lds_bytes, q);
+            case 4: return launch_one<NPA, 1, NQ, 4>(a, n_items, stage_bytes, lds_bytes, q, prof);
+            case 5: return launch_one<NPA, 1, NQ, 5>(a, n_items, stage_bytes, lds_bytes, q, prof);
+            case 6: return launch_one<NPA, 1, NQ, 6>(a, n_items, stage_bytes, lds_bytes, q, prof);
             default: break;
         }
     }
@@ -255,11 +401,24 @@ int launch_nt(const CFwdArgs& a, int NT, int n_items, size_t lds_bytes, hipStrea
 
 int convp_fwd_max_nt(int CT) { return CT == 1 ? 6 : 3; }
 
-int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t lds_bytes, hipStream_t q) {
+// two stage buffers, behind them the data gradient's mask tiles (2 KB per tile and wave); the epilogue turns every tile
+// around in 10 KB per wave of the (then free) stage buffers
+int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue) {  // three stage buffers when they fit
+    static const int forced = getenv("IDQN_CONV_RING") ? atoi(getenv("IDQN_CONV_RING")) : 0;
+    if (forced == 2 || forced == 3) return forced;
+    return 3 * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0) <= 160 * 1024 ? 3 : 2;
+}
+size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue) {
+    const size_t need = convp_fwd_ring(stage_bytes, NT, epilogue) * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0);
+    return need < 40960 ? 40960 : need;
+}
+
+int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, size_t lds_bytes,
+                     hipStream_t q, long long* prof) {
     IDQN_REQUIRE(lds_bytes <= 160 * 1024, "plane conv: %zu bytes of LDS per workgroup", lds_bytes);
-    if (NPA == 1 && NQ == 2) return CT == 1 ? launch_nt<1, 1, 2>(a, NT, n_items, lds_bytes, q) : launch_nt<1, 2, 2>(a, NT, n_items, lds_bytes, q);
-    if (NPA == 3 && NQ == 2) return CT == 1 ? launch_nt<3, 1, 2>(a, NT, n_items, lds_bytes, q) : launch_nt<3, 2, 2>(a, NT, n_items, lds_bytes, q);
-    if (NPA == 3 && NQ == 3) return CT == 1 ? launch_nt<3, 1, 3>(a, NT, n_items, lds_bytes, q) : launch_nt<3, 2, 3>(a, NT, n_items, lds_bytes, q);
-    if (NPA == 3 && NQ == 4) return CT == 1 ? launch_nt<3, 1, 4>(a, NT, n_items, lds_bytes, q) : launch_nt<3, 2, 4>(a, NT, n_items, lds_bytes, q);
+    if (NPA == 1 && NQ == 2) return CT == 1 ? launch_nt<1, 1, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<1, 2, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 2) return CT == 1 ? launch_nt<3, 1, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 3) return CT == 1 ? launch_nt<3, 1, 3>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 3>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 4) return CT == 1 ? launch_nt<3, 1, 4>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 4>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
     IDQN_REQUIRE(false, "plane conv: no kernel for %d planes, %d taps per superstep", NPA, NQ);
 }

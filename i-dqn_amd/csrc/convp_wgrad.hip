@@ -20,10 +20,14 @@ __device__ __forceinline__ bf16x8 frag128(const unsigned char* p) {
 }
 
 template <int NPX, int CT, int NTW, int PG>
-__global__ __launch_bounds__(256) void k_cwgrad(CWgradArgs a, unsigned stage_bytes, int MT) {
+__global__ __launch_bounds__(512) void k_cwgrad(CWgradArgs a, unsigned stage_bytes, int MT) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // waves 0-3 compute (one per SIMD), waves 4-7 only issue the LDS-DMA copies (as in convp_fwd.hip)
+    const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    warm_kernargs<sizeof(CWgradArgs)>();
     const CWItem it = a.items[xcd_contiguous_id()];  // the kernel rows of one chunk share an XCD
     const int OW = a.OW, p0 = it.p0, p_end = it.p0 + it.np, k = it.net;
     const int dy_pix = 3 * a.CO * 64;
@@ -70,21 +74,38 @@ __global__ __launch_bounds__(256) void k_cwgrad(CWgradArgs a, unsigned stage_byt
         for (int i = wave; i < ndp; i += 4) dma16(voff, dsrc + (unsigned long)i * 1024, buf + XB + i * 1024);
     };
 
+    if (loader) {
+        // ---- loader waves: copy stage s + 1 while the compute waves work on stage s -----------------------------------
+        int ibb = 0, ipos = p0, par = 0;
+        stage(ibb, ipos, lds0);
+        ipos += cnt_of(ipos);
+        if (ipos >= p_end) { ipos = p0; ++ibb; }
+        int cbb = 0, cpos = p0;  // mirrors the compute waves' progress (same barrier count)
+        while (cbb < a.nb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ibb < a.nb) {
+                stage(ibb, ipos, lds0 + (par ^ 1) * stage_bytes);
+                ipos += cnt_of(ipos);
+                if (ipos >= p_end) { ipos = p0; ++ibb; }
+            }
+            cpos += cnt_of(cpos);
+            if (cpos >= p_end) { cpos = p0; ++cbb; }
+            par ^= 1;
+        }
+        return;
+    }
+
+    // ---- compute waves -----------------------------------------------------------------------------------------------
     f32x16 acc[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    int ibb = 0, ipos = p0, cbb = 0, cpos = p0, par = 0;
-    stage(ibb, ipos, lds0);
-    ipos += cnt_of(ipos);
-    if (ipos >= p_end) { ipos = p0; ++ibb; }
-
     // bias gradient of this chunk: the per-position sums of dy, added in (batch block, position) order
+    // (wave-uniform branch; lanes past CO read a clamped column)
     float bsum = 0.f;
-    // (wave-uniform branch; lanes past CO read a clamped column -- a lane-divergent branch here makes hipcc treat the
-    // loop state below as divergent and the DMA's scalar operands end up in VGPRs)
     const bool bias_wave = a.pb && (NPX == 1 || it.kh == 0) && wave == 0;
     const int bcol = min(lane, a.CO - 1);
     if (bias_wave) {
@@ -102,48 +123,78 @@ __global__ __launch_bounds__(256) void k_cwgrad(CWgradArgs a, unsigned stage_byt
         }
     }
 
+    // Tile-steps of a stage, flattened: u = (position pp, k-step ks, tile i); the x fragments of tile-step u + 2 and the dy
+    // fragments of the next (pp, ks) are requested in the gaps between the MFMAs of tile-step u (sched_barrier pins that);
+    // reads run ahead unconditionally (always inside the stage buffer), only the MFMAs of positions past the stage's
+    // count are skipped (wave-uniform).
+    constexpr int U = PG * 2 * NTW, DSTEP = NTW >= 2 ? NTW - 2 : 0;
+    const unsigned char* zero_blk = lds + 2 * stage_bytes;  // 2 KB of zeros behind the two stages
+    *LDS_PTR(u32x4, lds + 2 * stage_bytes + wave * 512 + cl * 16) = (u32x4){0u, 0u, 0u, 0u};  // published by the first barrier
+    int cbb = 0, cpos = p0, par = 0;
     while (cbb < a.nb) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ibb < a.nb) {
-            stage(ibb, ipos, lds0 + (par ^ 1) * stage_bytes);
-            ipos += cnt_of(ipos);
-            if (ipos >= p_end) { ipos = p0; ++ibb; }
-        }
         const unsigned char* cur = lds + par * stage_bytes;
         const int cnt = cnt_of(cpos);
+        auto xaddr = [&](int u) {  // LDS address of the x fragment rows of tile-step u (plane 0)
+            const int i = u % NTW, g = u / NTW, ks = g & 1, pp = g >> 1;
+            return (pp < cnt ? cur + pp * pos_stride + tbase[i] : zero_blk) + (ks ? rd1 : rd0);
+        };
+        auto xplane = [&](int u) { return (u / NTW >> 1) < cnt ? a.x_plane : 0; };
+        // positions past the stage's count read dy from a block of zeros and x from the same zeros (stale LDS may hold NaN patterns: 0 x NaN would poison the sum): no branch around
+        // the MFMAs -- a conditional accumulator update made hipcc shuffle whole accumulators through v_accvgpr moves
+        auto daddr = [&](int g) {
+            const int ks = g & 1, pp = g >> 1;
+            return (pp < cnt ? cur + XB + pp * dy_pix + ct * 2048 : zero_blk) + (ks ? rd1 : rd0);
+        };
+        auto dplane = [&](int g) { return (g >> 1) < cnt ? a.CO * 64 : 0; };
+        bf16x8 xf[3][NPX], df[2][3];
 #pragma unroll
-        for (int pp = 0; pp < PG; ++pp) {
-            if (pp < cnt) {  // wave-uniform
-                const unsigned char* xp = cur + pp * pos_stride;
-                const unsigned char* dp = cur + XB + pp * dy_pix + ct * 2048;
+        for (int pl = 0; pl < 3; ++pl) df[0][pl] = frag128(daddr(0) + pl * dplane(0));
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const unsigned rd = ks ? rd1 : rd0;
-                    bf16x8 d[3];
+        for (int u0 = 0; u0 < 2 && u0 < U; ++u0)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) d[pl] = frag128(dp + pl * (a.CO * 64) + rd);
+            for (int pl = 0; pl < NPX; ++pl) xf[u0][pl] = frag128(xaddr(u0) + pl * xplane(u0));
 #pragma unroll
-                    for (int i = 0; i < NTW; ++i) {
-                        bf16x8 x[NPX];
-#pragma unroll
-                        for (int pl = 0; pl < NPX; ++pl) x[pl] = frag128(xp + tbase[i] + pl * a.x_plane + rd);
-                        if (NPX == 3) {  // smallest terms first
-                            acc[i] = mfma_bf16(x[2], d[0], acc[i]);
-                            acc[i] = mfma_bf16(x[0], d[2], acc[i]);
-                            acc[i] = mfma_bf16(x[1], d[1], acc[i]);
-                            acc[i] = mfma_bf16(x[1], d[0], acc[i]);
-                            acc[i] = mfma_bf16(x[0], d[1], acc[i]);
-                            acc[i] = mfma_bf16(x[0], d[0], acc[i]);
-                        } else {
-                            acc[i] = mfma_bf16(x[0], d[2], acc[i]);
-                            acc[i] = mfma_bf16(x[0], d[1], acc[i]);
-                            acc[i] = mfma_bf16(x[0], d[0], acc[i]);
-                        }
-                    }
-                }
+        for (int u = 0; u < U; ++u) {
+            const int i = u % NTW, g = u / NTW;
+            const bool next_x = u + 2 < U, next_d = (i == DSTEP && g + 1 < 2 * PG);
+            const unsigned char* xn = xaddr(next_x ? u + 2 : 0);
+            const int xpl = xplane(next_x ? u + 2 : 0);
+            const unsigned char* dn = daddr(next_d ? g + 1 : 0);
+            const int dpl = dplane(next_d ? g + 1 : 0);
+            const bf16x8* X = xf[u % 3];
+            const bf16x8* D = df[g & 1];
+            __builtin_amdgcn_sched_barrier(0);
+#define CW_GAP(m)                                                                                          \
+    {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (next_x && (m) < NPX) xf[(u + 2) % 3][(m) < NPX ? (m) : 0] = frag128(xn + (m) * xpl);      \
+        if (next_d && (m) < 3) df[(g + 1) & 1][(m) < 3 ? (m) : 0] = frag128(dn + (m) * dpl);        \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+            if (NPX == 3) {  // smallest terms first
+                acc[i] = mfma_bf16(X[2], D[0], acc[i]);
+                CW_GAP(0)
+                acc[i] = mfma_bf16(X[0], D[2], acc[i]);
+                CW_GAP(1)
+                acc[i] = mfma_bf16(X[1], D[1], acc[i]);
+                CW_GAP(2)
+                acc[i] = mfma_bf16(X[1], D[0], acc[i]);
+                CW_GAP(3)
+                acc[i] = mfma_bf16(X[0], D[1], acc[i]);
+                CW_GAP(4)
+                acc[i] = mfma_bf16(X[0], D[0], acc[i]);
+                CW_GAP(5)
+            } else {
+                acc[i] = mfma_bf16(X[0], D[2], acc[i]);
+                CW_GAP(0)
+                acc[i] = mfma_bf16(X[0], D[1], acc[i]);
+                CW_GAP(1)
+                acc[i] = mfma_bf16(X[0], D[0], acc[i]);
+                CW_GAP(2)
             }
+#undef CW_GAP
         }
         cpos += cnt;
         if (cpos >= p_end) { cpos = p0; ++cbb; }
@@ -166,10 +217,10 @@ template <int NPX, int CT, int NTW, int PG>
 int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipStream_t q) {
     static size_t attr = 0;
     if (lds_bytes > attr) {
-        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cwgrad<NPX, CT, NTW, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cwgrad<NPX, CT, NTW, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 2048));
         attr = lds_bytes;
     }
-    hipLaunchKernelGGL((k_cwgrad<NPX, CT, NTW, PG>), dim3((unsigned)n_items), dim3(256), lds_bytes, q, a, (unsigned)(lds_bytes / 2), MT);
+    hipLaunchKernelGGL((k_cwgrad<NPX, CT, NTW, PG>), dim3((unsigned)n_items), dim3(512), lds_bytes + 2048, q, a, (unsigned)(lds_bytes / 2), MT);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -178,7 +229,7 @@ int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipSt
 
 // MT = 32-row tiles on the M side of one workgroup (KW * CI / 32, Conv_0: its 8 kernel rows)
 int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q) {
-    IDQN_REQUIRE(lds_bytes <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes);
+    IDQN_REQUIRE(lds_bytes + 2048 <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes + 2048);
     const int ntw = (MT * CT + 3) / 4;
     if (NPX == 1) {
         if (CT == 1 && ntw == 2 && a.PG == 4) return launch_one<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q);

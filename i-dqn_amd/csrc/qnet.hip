@@ -146,7 +146,7 @@ struct NetSet {
 
 // host-side plans of the plane conv launches: the work items of a launch depend only on geometry, net count and batch
 // blocks, so they are built once and kept on the device
-struct FwdPlan { CItem* dev = nullptr; int n_items = 0, NT = 0; size_t lds = 0; };
+struct FwdPlan { int n_items = 0, NT = 0, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
 struct WgradPlan { CWItem* dev = nullptr; int n_items = 0, n_chunks = 0, MT = 0, PG = 0; size_t lds = 0; };
 
 }  // namespace
@@ -168,6 +168,7 @@ struct idqn_handle_s {
     NetSet train, infer;
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
+    const float* infer_pbase = nullptr;  // parameter base of the net the last idqn_q_values call evaluated
     float *infer_hbuf = nullptr, *infer_qpart = nullptr;  // k_hidden outputs of the single inference net
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
     long wt_stride[3] = {0, 0, 0};
@@ -178,6 +179,8 @@ struct idqn_handle_s {
     long wq_stride = 0, wq_fwd[3] = {0, 0, 0}, wq_dg[3] = {0, 0, 0};  // bytes
     std::map<std::tuple<int, int, int>, FwdPlan> fwd_plans;   // (role, n_nets, nb)
     std::map<std::tuple<int, int>, WgradPlan> wgrad_plans;    // (layer, nb)
+    float* cprof = nullptr;  // debug (IDQN_CONV_PROF=role): phase stamps of one plane conv launch
+    int cprof_role = -1;
     int npc[3], pos_per_chunk[3];
     long slab_stride[3], slab_off[3];
     SlabSeg segs[3];  // slab descriptors of the last backward (consumed by the fused Adam launch)
@@ -313,6 +316,10 @@ int cnn_setup(idqn_handle_s* h) {
     }
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
     if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
+    if (h->planes && getenv("IDQN_CONV_PROF")) {
+        h->cprof_role = atoi(getenv("IDQN_CONV_PROF"));
+        if ((rc = alloc_zero(&h->cprof, 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
+    }
     if (h->planes) {
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
         if ((rc = alloc_zero16(&h->da2p, (long)K * nb * h->gda2.block * 3, h, "da2p"))) return rc;
@@ -378,7 +385,7 @@ int cnn_setup(idqn_handle_s* h) {
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
             const int per_chunk = K * (i == 0 ? 1 : cl.K);
-            int nch = (256 + per_chunk / 2) / per_chunk;
+            int nch = 256 / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
             if (const char* e = getenv("IDQN_WCHUNKS")) nch = atoi(e);
             h->npc[i] = std::max(1, std::min(nch, npos));
         }
@@ -514,9 +521,27 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     std::vector<CItem> items;
     int np_all = 0;
     long stage_max = 0;
+    // ranges per variant: proportional to its positions, rounded DOWN (one workgroup more than CUs would run alone after
+    // all the others), leftovers to the variants with the most positions per range
+    int Rv[4] = {1, 1, 1, 1}, used = 0;
+    for (int v = 0; v < g.n_var; ++v) {
+        const long npos = (long)g.var[v].OH * g.var[v].OW;
+        Rv[v] = (int)std::max(1L, std::min(npos, per_slot * npos / npos_total));
+        used += Rv[v];
+    }
+    for (; used < per_slot; ++used) {
+        int best = -1;
+        double worst = 0;
+        for (int v = 0; v < g.n_var; ++v) {
+            const double load = (double)g.var[v].OH * g.var[v].OW / Rv[v];
+            if (Rv[v] < g.var[v].OH * g.var[v].OW && load > worst) { worst = load; best = v; }
+        }
+        if (best < 0) break;
+        ++Rv[best];
+    }
     for (int v = 0; v < g.n_var; ++v) {
         const int OW = g.var[v].OW, npos = g.var[v].OH * OW;
-        int R = std::max(1L, std::min((long)npos, (per_slot * (long)npos + npos_total / 2) / npos_total));
+        int R = Rv[v];
         // limits: tiles per wave, rows spanned, LDS (two stages in 160 KB)
         for (;; ++R) {
             const int np = (npos + R - 1) / R;
@@ -524,11 +549,12 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
             for (int r = 0, p0 = 0; ok && r < R; ++r) {
                 const int n = npos / R + (r < npos % R ? 1 : 0);
                 int rows;
-                if (n > 0 && (fwd_stage_bytes(g, OW, p0, n, &rows) > 80 * 1024 || rows > CP_MAX_STRIPS)) ok = false;
+                if (n > 0 && (fwd_stage_bytes(g, OW, p0, n, &rows) > 68 * 1024 || rows > CP_MAX_STRIPS)) ok = false;
                 p0 += n;
             }
             if (ok || R >= npos) break;
         }
+        Rv[v] = R;
         for (int n = 0; n < n_nets; ++n)
             for (int bb = 0; bb < nb; ++bb)
                 for (int r = 0, p0 = 0; r < R; ++r) {
@@ -545,19 +571,21 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
                     p0 += cnt;
                 }
     }
-    // net-major order: consecutive items (which the XCD-contiguous remap keeps on one XCD) share a net's weights
-    std::stable_sort(items.begin(), items.end(), [](const CItem& x, const CItem& y) {
-        return x.net != y.net ? x.net < y.net : x.bb < y.bb;
-    });
+    // The kernel derives item b arithmetically: slot = b / items_per_slot (net-major: consecutive workgroups, which the
+    // XCD-contiguous remap keeps on one XCD, share a net's weights), then variant and balanced range inside the slot.
     FwdPlan pl;
     pl.n_items = (int)items.size();
+    for (int v = 0; v < g.n_var; ++v) {
+        pl.r_begin[v] = pl.items_per_slot;
+        pl.r_cnt[v] = Rv[v];
+        pl.items_per_slot += Rv[v];
+    }
+    IDQN_REQUIRE(pl.n_items == pl.items_per_slot * n_nets * nb, "plane conv: role %d item count %d does not match its ranges", role, pl.n_items);
     pl.NT = (np_all * g.CT + 3) / 4;
     IDQN_REQUIRE(pl.NT >= 1 && pl.NT <= nt_max, "plane conv: role %d needs %d tiles per wave", role, pl.NT);
-    pl.lds = (size_t)(2 * stage_max);
+    pl.stage = (size_t)stage_max;
+    pl.lds = convp_fwd_lds(pl.stage, pl.NT, role <= 2 ? 0 : 1);
     IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane conv: role %d needs %zu bytes of LDS", role, pl.lds);
-    IDQN_HIP_CHECK(hipMalloc((void**)&pl.dev, sizeof(CItem) * items.size()));
-    h->owned.push_back((void*)pl.dev);
-    IDQN_HIP_CHECK(hipMemcpy(pl.dev, items.data(), sizeof(CItem) * items.size(), hipMemcpyHostToDevice));
     *out = &(h->fwd_plans[key] = pl);
     return IDQN_OK;
 }
@@ -575,10 +603,10 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out) {
     for (pl.PG = layer == 0 ? 4 : 2;; --pl.PG) {  // positions per LDS stage: as many as two stages leave room for
         const long XB = layer == 0 ? (long)l.K * (pl.PG + 1) * 1024 : ((pl.PG - 1) * l.S + l.K) * x_pix;
         pl.lds = (size_t)(2 * (XB + pl.PG * dy_pix));
-        if (pl.lds <= 160 * 1024 || pl.PG == 1) break;
+        if (pl.lds + 2048 <= 160 * 1024 || pl.PG == 1) break;
         if (layer == 0) --pl.PG;  // Conv_0: 4 or 2 positions
     }
-    IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
+    IDQN_REQUIRE(pl.lds + 2048 <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
     std::vector<CWItem> items;
     for (int k = 0; k < K; ++k)
         for (int c = 0, p0 = 0; c < nch; ++c) {
@@ -653,7 +681,12 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     if ((rc = plan_fwd(h, role + (fwd && &s == &h->infer ? 8 : 0), n_nets, nb, g, &pl))) return rc;
     CFwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.items = pl->dev; a.wbase = s.wbase; a.wq = s.wq; a.wq_stride = h->wq_stride; a.nb = nb; a.n_var = g.n_var;
+    a.wq = s.wq;
+    a.items_per_slot = pl->items_per_slot;
+    for (int v = 0; v < 4; ++v) { a.r_begin[v] = pl->r_begin[v]; a.r_cnt[v] = pl->r_cnt[v]; }
+    if (&s == &h->infer) { a.pbase[0] = a.pbase[1] = h->infer_pbase; a.n_first = 1; }
+    else { a.pbase[0] = h->online; a.pbase[1] = h->target; a.n_first = h->cfg.n_heads; }
+    a.pstride = h->L.head_stride; a.wq_stride = h->wq_stride; a.nb = nb; a.n_var = g.n_var;
     a.KH = g.KH; a.NCC = g.NCC; a.S = g.S; a.SX = g.SX;
     for (int v = 0; v < g.n_var; ++v) a.var[v] = g.var[v];
     const ActGeom* gin;   // input planes
@@ -688,7 +721,8 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     a.row_bytes = gin->Wp * a.pix_bytes;
     a.out_slot = gout->block * 6; a.out_Wp = gout->Wp; a.out_lo_h = gout->lo_h; a.out_lo_w = gout->lo_w;
     a.out_W = gout->W; a.out_H = gout->H;
-    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->lds, q);
+    long long* prof = (h->cprof && h->cprof_role == role && &s == &h->train && pl->n_items <= 4096) ? (long long*)h->cprof : nullptr;
+    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->lds, q, prof);
 }
 
 int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
@@ -1219,6 +1253,7 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     if (h->cfg.arch == IDQN_ARCH_CNN) {
         // the acting net's parameter pointer is entry (which * K + head) of the training table: no pointer upload
         h->infer.wbase = h->train.wbase + (which * h->cfg.n_heads + head);
+        h->infer_pbase = params;
         (void)params;
         int rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q);
         if (rc) return rc;
