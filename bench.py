@@ -1,6 +1,6 @@
 """bench.py -- i-DQN gradient-steps/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 300 --warmup 50
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -35,14 +35,15 @@ import numpy as np  # noqa: E402
 
 K_HEADS, BATCH, N_ACTIONS, OBS, FEATURES = 5, 32, 6, (84, 84, 4), [32, 64, 64, 512]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK = 157.3e12  # f32-input MFMA / f32 vector rate; the step's FLOPs are f32 FLOPs whatever the matrix cores run
 
 
-def synthetic(seed):
+def synthetic(seed, n_actions=N_ACTIONS):
     """SURVEY 8d inputs: iid uint8 frames, uniform actions, rewards in {-1,0,1}, 1 % terminals."""
     rng = np.random.default_rng(seed)
     s = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
     s2 = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
-    a = rng.integers(0, N_ACTIONS, size=BATCH).astype(np.int32)
+    a = rng.integers(0, n_actions, size=BATCH).astype(np.int32)
     r = rng.integers(-1, 2, size=BATCH).astype(np.float32)
     t = (rng.random(BATCH) < 0.01).astype(np.uint8)
     return s, a, r, s2, t
@@ -65,7 +66,7 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("IDQN_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=15.0, n_actions=N_ACTIONS):
     """The oracle's torch-CPU fp32 restatement (K heads batched), all host cores, bounded sample."""
     import torch
 
@@ -74,10 +75,10 @@ def cpu_baseline(budget_s=15.0):
 
     cores = usable_cores()
     torch.set_num_threads(cores)
-    p = Q.init_params(0, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
-    pt = Q.init_params(1, "cnn", OBS, N_ACTIONS, FEATURES, K_HEADS)
-    step = T.BatchedStep(p, pt, N_ACTIONS, 0.99, 6.25e-5, 1.5e-4)
-    s, a, r, s2, t = synthetic(0)
+    p = Q.init_params(0, "cnn", OBS, n_actions, FEATURES, K_HEADS)
+    pt = Q.init_params(1, "cnn", OBS, n_actions, FEATURES, K_HEADS)
+    step = T.BatchedStep(p, pt, n_actions, 0.99, 6.25e-5, 1.5e-4)
+    s, a, r, s2, t = synthetic(0, n_actions)
     batch = (s, a, r, s2, t.astype(bool))
     step.step(batch)
     step.step(batch)
@@ -96,7 +97,7 @@ def cpu_baseline(budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--heads-per-gpu", type=int, default=0,
@@ -105,7 +106,25 @@ def main():
                          "and a D-step (neighbour exchange) are timed separately")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
+    ap.add_argument("--actions", type=int, default=N_ACTIONS, help="action count A (SURVEY 8d: 6, repeat with 18)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     args = ap.parse_args()
+
+    if (args.gpus > 1 or args.heads_per_gpu) and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks as fresh child processes (one per GPU, RCCL) and relay rank 0's
+        # line.  Nothing in THIS process has touched torch, HIP or the extension yet, and it never will.
+        import subprocess
+
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(proc.returncode if proc.returncode or lines else 1)
 
     # Everything except the final JSON line goes to stderr -- including what native libraries print on fd 1
     # (RCCL writes a version banner to stdout at communicator creation).
@@ -140,6 +159,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or args.force_dp or args.heads_per_gpu:
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
         assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -150,44 +171,65 @@ def main():
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
     if args.heads_per_gpu:
         return head_parallel_bench(args, rank, world, json_fd, Batch)
-    agent = iDQN(0, OBS, N_ACTIONS, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    A = args.actions
+    agent = iDQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
-    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i))) for i in range(8)]
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i, A))) for i in range(8)]
     it = [0]
     dp = world > 1 or args.force_dp
     global_batch = BATCH * world
+    if dp and rank == 0:  # the first multi-GPU run should show which algorithm / protocol RCCL picks over xGMI
+        print(f"[bench] NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} IDQN_DP_MODE={os.environ.get('IDQN_DP_MODE', 'factored')}",
+              file=sys.stderr, flush=True)
 
-    def step(profile, extra=0):
+    def step(flags=0):
         batch = batches[it[0] % len(batches)]
         it[0] += 1
         if not dp:
-            agent._learn(batch, flags=(_hip.F_PROFILE if profile else 0) | extra)
+            agent._learn(batch, flags=flags)
         else:
-            data_parallel_step(agent, batch, global_batch, extra_flags=(_hip.F_PROFILE if profile else 0) | extra)
+            data_parallel_step(agent, batch, global_batch, extra_flags=flags)
 
     for _ in range(args.warmup):
-        step(False)
+        step()
 
     def barrier():
         if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dp:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # `repeats` timed regions of EXACTLY `steps` steps each, barrier + synchronize on both sides, max over ranks;
+    # the reported region is the median one
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(_hip.F_PROFILE)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dp:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        regions.append(elapsed)
+    elapsed = float(np.median(regions))
 
     import ctypes as C
 
     mean_ms, n_l, name = C.c_double(), C.c_int32(), C.create_string_buffer(64)
     _hip.check(_hip.lib().idqn_profile_read(agent._handle, C.byref(mean_ms), C.byref(n_l), name), "idqn_profile_read")
+    # per-launch table: a short extra run (outside the timed regions) with one hipEvent behind every launch
+    kernels = []
+    if not dp:
+        for _ in range(60):
+            step(_hip.F_PROFILE_ALL)
+        torch.cuda.synchronize()
+        buf = C.create_string_buffer(8192)
+        _hip.check(_hip.lib().idqn_profile_table(agent._handle, buf, 8192), "idqn_profile_table")
+        for ln in buf.value.decode().splitlines():
+            nm, us, cnt = ln.split("\t")
+            kernels.append({"launch": nm, "us": float(us), "n": int(cnt)})
     losses = agent._losses.cpu().numpy()
     assert np.isfinite(losses).all(), losses
     if rank == 0:
@@ -201,13 +243,22 @@ def main():
         per_head = (6 if fused else 1) * P_w0 * 4 + n_blocks * (7744 * 32 * 4 + 512 * 32 * 4)
         alg_bytes = K_HEADS * per_head
         achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
-        traffic = None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh), fused kernel only
+        traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
             if not dp:
                 traffic = pmc["hbm_bytes_per_launch"]
+                traffic_source = f"profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, library {pmc.get('git', '?')}; not this run)"
         except Exception:
             pass
+        # whole-step algorithmic work: FLOPs = K B (2 F_fwd + F_bwd), bytes = K 7 4 P + 2 B 28224 + 9 B
+        macs = 3612672 + 3964928 + 4460544 + 3964928 + 512 * A
+        f_fwd = 2 * macs
+        f_bwd = 2 * f_fwd - 2 * 3612672
+        step_flops = K_HEADS * BATCH * (2 * f_fwd + f_bwd)
+        P = 8 * 8 * 4 * 32 + 32 + 4 * 4 * 32 * 64 + 64 + 3 * 3 * 64 * 64 + 64 + 7744 * 512 + 512 + 512 * A + A
+        step_bytes = K_HEADS * 7 * 4 * P + 2 * BATCH * 28224 + 9 * BATCH
+        ms_step = elapsed / args.steps * 1e3
         out = {
             "metric": "i-DQN grad-steps/sec, Nature-CNN K=5 batch=32",
             "value": args.steps * world / elapsed,
@@ -215,28 +266,38 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Atari synthetic 84x84x4 uint8, i-DQN K=5 Nature-CNN [32,64,64,512] A=6, "
+            "config": {"workload": f"Atari synthetic 84x84x4 uint8, i-DQN K=5 Nature-CNN [32,64,64,512] A={A}, "
                                    f"batch 32 per GPU (global {global_batch}), "
                                    + {"single": "fused wgrad+Adam",
                                       "factored": "Dense_0 factors all-gathered (RCCL), fused wgrad+Adam over the "
                                                   "global batch, small leaves all-reduced",
                                       "allreduce": "grad all-reduce (RCCL) then Adam"}[dp_mode],
-                       "heads": K_HEADS, "batch_per_gpu": BATCH, "global_batch": global_batch,
-                       "parallelism": f"dp{world}" if dp else "single"},
+                       "heads": K_HEADS, "batch_per_gpu": BATCH, "global_batch": global_batch, "actions": A,
+                       "parallelism": f"dp{world}" if dp else "single",
+                       "conv_arithmetic": os.environ.get("IDQN_CONV", "bf16x3") + " (f32-accurate products)"},
+            "timing": {"regions": args.repeats, "steps_per_region": args.steps, "reported": "median region",
+                       "ms_per_step_all": [r / args.steps * 1e3 for r in regions]},
             "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes},
-        "final_losses": [float(x) for x in losses],
+            # the whole step against its two floors (per GPU: every rank does one 32-sample step per global step)
+            "step_roofline": {"flops": step_flops, "bytes": step_bytes,
+                              "floor_us_mfma_f32": step_flops / MFMA_F32_PEAK * 1e6, "floor_us_hbm": step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6,
+                              "frac_mfma": step_flops / MFMA_F32_PEAK / (ms_step * 1e-3),
+                              "frac_hbm": step_bytes / (HBM_PEAK_GBS * 1e9) / (ms_step * 1e-3),
+                              "peaks": "157.3 TFLOP/s f32-rate MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md)"},
+            "kernels": kernels,
+            "final_losses": [float(x) for x in losses],
         }
         if not dp and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(n_actions=A)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
@@ -251,8 +312,8 @@ def head_parallel_bench(args, rank, world, json_fd, Batch):
     from slimdqn.networks.head_parallel import HeadShardedIDQN
 
     K = args.heads_per_gpu * world
-    agent = HeadShardedIDQN(0, OBS, N_ACTIONS, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
-    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i))) for i in range(8)]  # same on all ranks
+    agent = HeadShardedIDQN(0, OBS, args.actions, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i, args.actions))) for i in range(8)]  # same on all ranks
 
     def timed(fn, n):
         dist.barrier()

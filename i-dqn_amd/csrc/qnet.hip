@@ -188,6 +188,11 @@ struct idqn_handle_s {
     FcNet fc;
     float* fc_ws = nullptr;
     FcPlan fc_plan_;  // LDS plan of k_fc_step_lds (BS = 0: the net does not fit and the generic kernel runs)
+    // timeline of a whole step (IDQN_F_PROFILE_ALL): one event after every launch; idqn_profile_table averages per name
+    std::vector<hipEvent_t> tl_ev;
+    std::vector<const char*> tl_name;
+    int tl_used = 0;
+    bool tl_on = false;
     // profiling of the dominant kernel
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -222,6 +227,13 @@ int alloc_zero16(unsigned short** p, long n, idqn_handle_s* h, const char* name)
     h->owned.push_back((void*)*p);
     h->dbg.push_back({name, {(void*)*p, n * 2}});
     return IDQN_OK;
+}
+
+// step timeline: an event on the stream after the launch just made (name = nullptr: start of a step)
+void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
+    if (!h->tl_on || h->tl_used >= (int)h->tl_ev.size()) return;
+    if (hipEventRecord(h->tl_ev[h->tl_used], q) != hipSuccess) return;
+    h->tl_name[h->tl_used++] = name;
 }
 
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
@@ -753,8 +765,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     const int nb = cdiv(B, 32);
     IDQN_REQUIRE(nb <= s.nb_cap, "batch %d exceeds the workspace (%d blocks of 32)", B, s.nb_cap);
     if (h->planes) {
+        static const char* nm[3] = {"conv0 fwd", "conv1 fwd", "conv2 fwd"};
         int rc = planes_stage(h, s, st, st2, B, nb, q);
-        for (int i = 0; i < 3 && !rc; ++i) rc = planes_conv(h, s, i, nb, q);
+        tl_mark(h, q, "stage (pixels + kernel packing)");
+        for (int i = 0; i < 3 && !rc; ++i) { rc = planes_conv(h, s, i, nb, q); tl_mark(h, q, nm[i]); }
         if (rc) return rc;
     } else {
         PrepArgs pa;
@@ -794,6 +808,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.rows_per_split = s.rows_per_split;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -809,6 +824,7 @@ int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e
                  "launch_adam: bad skip range");
     if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
     hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin - (skip_e - skip_b)) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
+    tl_mark(h, q, "adam (small leaves + slab sums)");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -903,6 +919,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     else if (fuse_adam) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else hipExtLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    tl_mark(h, q, fuse_adam ? "dense0 wgrad + adam" : "dense0 wgrad");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -918,6 +935,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
     hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
+    tl_mark(h, q, "hidden");
     TdArgs ta;
     ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
     ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K;
@@ -939,6 +957,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     } else {
         hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     }
+    tl_mark(h, q, "td + loss + dh");
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
     DenseDgradArgs dd;
     dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
@@ -954,6 +973,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
             hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
         }
     }
+    tl_mark(h, q, "dense0 dgrad");
     if (stop_before_dense0_wgrad) {
         h->pend_B = B; h->pend_stage = 1; h->pend_profile = profile;
         IDQN_HIP_CHECK(hipGetLastError());
@@ -980,9 +1000,12 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     long nblk = 0;
     if (h->planes) {
         // data gradients (stride-1 convolutions over the zero-bordered dout planes), then the weight gradients
+        static const char* nw[3] = {"conv0 wgrad", "conv1 wgrad", "conv2 wgrad"};
         int rc = planes_conv(h, s, 3, nb, q);
+        tl_mark(h, q, "conv2 dgrad");
         if (!rc) rc = planes_conv(h, s, 4, nb, q);
-        for (int i = 2; i >= 0 && !rc; --i) rc = planes_wgrad(h, i, nb, q);
+        tl_mark(h, q, "conv1 dgrad");
+        for (int i = 2; i >= 0 && !rc; --i) { rc = planes_wgrad(h, i, nb, q); tl_mark(h, q, nw[i]); }
         if (rc) return rc;
     } else {
         // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
@@ -1098,6 +1121,8 @@ extern "C" int idqn_destroy(idqn_handle_t h) {
     for (void* p : h->owned) (void)hipFree(p);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->tl_ev)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return IDQN_OK;
 }
@@ -1113,6 +1138,13 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
     const bool grads_only = (flags & IDQN_F_GRADS_ONLY) || stop0 || stopb, profile = flags & IDQN_F_PROFILE;
     IDQN_REQUIRE(!(stop0 || stopb) || h->cfg.arch == IDQN_ARCH_CNN, "the IDQN_F_STOP_* flags belong to the cnn path");
     h->pend_B = 0; h->pend_stage = 0;
+    h->tl_on = (flags & IDQN_F_PROFILE_ALL) != 0;
+    if (h->tl_on && h->tl_ev.empty()) {
+        h->tl_ev.resize(2048);
+        h->tl_name.resize(2048);
+        for (auto& e : h->tl_ev) IDQN_HIP_CHECK(hipEventCreate(&e));
+    }
+    tl_mark(h, q, nullptr);
     int rc;
     if (h->cfg.arch == IDQN_ARCH_CNN) {
         if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q))) return rc;
@@ -1297,6 +1329,32 @@ extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_d
             return IDQN_OK;
         }
     IDQN_REQUIRE(false, "idqn_debug_buffer: no buffer named '%s'", name);
+}
+
+extern "C" int idqn_profile_table(idqn_handle_t h, char* out, int32_t out_bytes) {
+    IDQN_REQUIRE(h && out && out_bytes > 0, "idqn_profile_table: null pointer");
+    std::vector<std::pair<std::string, std::pair<double, int>>> rows;  // first-seen order
+    for (int i = 1; i < h->tl_used; ++i) {
+        if (!h->tl_name[i]) continue;  // a step's start marker: nothing was launched before it
+        float ms = 0;
+        IDQN_HIP_CHECK(hipEventSynchronize(h->tl_ev[i]));
+        IDQN_HIP_CHECK(hipEventElapsedTime(&ms, h->tl_ev[i - 1], h->tl_ev[i]));
+        size_t r = 0;
+        for (; r < rows.size(); ++r)
+            if (rows[r].first == h->tl_name[i]) break;
+        if (r == rows.size()) rows.push_back({h->tl_name[i], {0.0, 0}});
+        rows[r].second.first += ms;
+        rows[r].second.second += 1;
+    }
+    std::string txt;
+    char line[160];
+    for (auto& r : rows) {
+        snprintf(line, sizeof line, "%s\t%.3f\t%d\n", r.first.c_str(), 1e3 * r.second.first / r.second.second, r.second.second);
+        txt += line;
+    }
+    snprintf(out, (size_t)out_bytes, "%s", txt.c_str());
+    h->tl_used = 0;
+    return IDQN_OK;
 }
 
 extern "C" int idqn_profile_read(idqn_handle_t h, double* mean_ms, int32_t* n_launches, char* kernel_name) {

@@ -246,12 +246,16 @@ extern "C" int sumtree_query(const double* nodes_dev, int32_t depth, const doubl
 // ---------------------------------------------------------------------------------------------------
 // w_i = (n_items * p_i / root)^(-beta), normalised by the largest weight of the batch (Schaul et al. 2016, eq. 2).
 __global__ __launch_bounds__(1024) void k_per_weights(const double* __restrict__ nodes, int depth,
-                                                      const int32_t* __restrict__ leaves, int n, double n_items,
+                                                      int32_t* __restrict__ leaves, int n, double n_items,
                                                       double beta, float* __restrict__ out) {
     __shared__ double red[1024];
     const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
     const double root = nodes[0];
     double wmax = 0.0;
+    // a descent can land on an empty leaf at or past the item count when rounding in the tree sums leaves a sliver of
+    // mass there: pull it back onto the last live leaf, so that the gather that follows stays inside the store
+    for (int i = threadIdx.x; i < n; i += 1024) leaves[i] = min(max(leaves[i], 0), (int32_t)n_items - 1);
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024) {
         const double p = nodes[first_leaf + (unsigned int)leaves[i]];
         const double w = (p > 0.0 && root > 0.0) ? pow(n_items * p / root, -beta) : 0.0;
@@ -321,7 +325,7 @@ extern "C" int per_sample_leaves(const double* nodes_dev, int32_t depth, const d
     return IDQN_OK;
 }
 
-extern "C" int per_importance_weights(const double* nodes_dev, int32_t depth, const int32_t* leaves_dev, int32_t n,
+extern "C" int per_importance_weights(const double* nodes_dev, int32_t depth, int32_t* leaves_dev, int32_t n,
                                       int64_t n_items, double beta, float* weights_out_dev, void* stream) {
     IDQN_REQUIRE(nodes_dev && leaves_dev && weights_out_dev && n >= 1 && n_items >= 1, "per_importance_weights: bad arguments");
     IDQN_REQUIRE(depth >= 1 && depth <= 31, "per_importance_weights: depth %d out of range", depth);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("IDQN_HIP_LIB") or os.path.join(os.path.dirname(_HERE)
 
 IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
 IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24
-F_GRADS_ONLY, F_PROFILE, F_STOP_AFTER_DENSE0, F_STOP_BEFORE_DENSE0_WGRAD = 1, 2, 4, 8
+F_GRADS_ONLY, F_PROFILE, F_STOP_AFTER_DENSE0, F_STOP_BEFORE_DENSE0_WGRAD, F_PROFILE_ALL = 1, 2, 4, 8, 16
 FACTORED_DENSE0, FACTORED_REST = 1, 2
 E_INVALID, E_HIP, E_RANGE, E_ASSERT = -1, -2, -3, -4
 
@@ -60,6 +60,7 @@ SYMBOLS = {
     "idqn_best_action": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     "idqn_debug_buffer": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "idqn_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p]),
+    "idqn_profile_table": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "sumtree_set": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "sumtree_get": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P]),
     "sumtree_query": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P]),

@@ -245,5 +245,7 @@ class DeviceAgent:
         return out
 
     def get_model(self):
-        """Picklable ``{"params": pytree of numpy arrays}`` (idqn.py:133-134, experiments/base/utils.py:134)."""
-        return self._numpy_tree(self._online)
+        """Picklable ``{"params": self.params}`` with numpy leaves (idqn.py:133-134, experiments/base/utils.py:134).
+        ``self.params`` is already the flax variables dict ``{"params": {"Conv_0": ...}}``, so the pickle holds
+        ``model["params"]["params"]["Dense_0"]["kernel"]`` -- exactly what the reference's checkpoints hold."""
+        return {"params": self._numpy_tree(self._online)}

@@ -85,6 +85,7 @@ class PrioritizedLearner:
         self.beta, self.eps, self.reduce_max, self.stratified = beta, eps, int(reduce == "max"), int(stratified)
         B, K = replay_buffer._batch_size, agent._K
         self._u_pin = torch.empty(B, dtype=torch.float64).pin_memory()
+        self._u_ev = None
         self._u_dev = torch.empty(B, dtype=torch.float64, device="cuda")
         self._leaves = torch.empty(B, dtype=torch.int32, device="cuda")
         self._weights = torch.empty(B, dtype=torch.float32, device="cuda")
@@ -99,8 +100,12 @@ class PrioritizedLearner:
         rb, tree, agent = self.rb, self.sampler._sum_tree, self.agent
         B = rb._batch_size
         assert rb.add_count, "No samples in replay buffer!"
+        if self._u_ev is not None:
+            self._u_ev.synchronize()  # the previous step's upload has left the pinned staging buffer
         self._u_pin.copy_(torch.from_numpy(self.sampler._rng_key.random(B)))
         self._u_dev.copy_(self._u_pin, non_blocking=True)
+        self._u_ev = torch.cuda.Event()
+        self._u_ev.record()
         _hip.check(lib.per_sample_leaves(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._u_dev), B, self.stratified,
                                          _hip.ptr(self._leaves), q), "per_sample_leaves")
         _hip.check(lib.per_importance_weights(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._leaves), B,

@@ -304,25 +304,30 @@ class ReplayBuffer:
     def _staging(self, size: int):
         import torch
 
+        # Two staging sets per batch size, used in turn: the ReplayElement a call returns holds views of one set and stays
+        # valid until the SECOND-next sample of the same size (the reference returns fresh arrays every time; a caller that
+        # keeps more than two batches alive has to copy them).
         if size not in self._stage:
-            self._stage[size] = dict(
+            self._stage[size] = [dict(
                 slots=torch.empty(size, dtype=torch.int32, device="cuda"),
                 state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
                 next_state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
                 action=torch.empty(size, dtype=torch.int32, device="cuda"),
                 reward=torch.empty(size, dtype=torch.float32, device="cuda"),
                 terminal=torch.empty(size, dtype=torch.uint8, device="cuda"),
-            )
-        return self._stage[size]
+            ) for _ in range(2)] + [0]
+        sets = self._stage[size]
+        sets[2] ^= 1
+        return sets[sets[2]]
 
     def _gather(self, slots: np.ndarray) -> ReplayElement:
         import torch
 
         st = self._staging(int(slots.size))
         st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots, np.int32)))
-        return self._gather_device(st["slots"])
+        return self._gather_device(st["slots"], st)
 
-    def _gather_device(self, slots_dev) -> ReplayElement:
+    def _gather_device(self, slots_dev, st=None) -> ReplayElement:
         """Stacked gather for slots that are already on the device (int32 tensor): no host round trip."""
         import torch
 
@@ -330,7 +335,7 @@ class ReplayBuffer:
 
         size = int(slots_dev.numel())
         self._flush_meta()
-        st = self._staging(size)
+        st = st if st is not None else self._staging(size)
         if slots_dev.data_ptr() != st["slots"].data_ptr():
             st["slots"].copy_(slots_dev)
         _hip.check(_hip.lib().replay_gather_stacked(

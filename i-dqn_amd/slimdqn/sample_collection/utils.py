@@ -21,8 +21,8 @@ def linear_schedule(init_value: float, end_value: float, transition_steps):
     span = init_value - end_value
 
     def value_at(count):
-        if transition_steps <= 0:
-            return end_value
+        if transition_steps <= 0:  # optax.linear_schedule: a constant schedule at init_value
+            return init_value
         progress = min(max(count, 0), transition_steps) / transition_steps
         return end_value + span * (1.0 - progress)
 

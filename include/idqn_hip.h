@@ -73,9 +73,9 @@ typedef struct idqn_handle_s* idqn_handle_t;
  * and scratch.  count: optax step counter per head (int32, idqn.py:53); losses: per-head loss of
  * the last step (idqn.py:109); cum_losses: f64 running sum == `cumulated_losses += losses`
  * (idqn.py:72) kept on the device so that no per-step host sync is needed.
- * Environment: IDQN_CONV = "bf16x3" | "bf16x3-forward" selects, at creation, the conv arithmetic that gets
- * f32-accurate products out of the bf16 matrix cores (exact three-way operand splits, csrc/conv3_kernels.h) for all
- * conv forwards and data gradients, or for the forwards only; unset = v_mfma_f32 everywhere.                       */
+ * Environment: IDQN_CONV = "bf16x3" (default) | "f32" selects, at creation, the conv arithmetic: f32-accurate
+ * products on the bf16 matrix cores (exact three-way operand splits, csrc/convp.h) for every conv forward, data
+ * gradient and weight gradient, or v_mfma_f32 everywhere.                                                          */
 int idqn_create(const idqn_config_t* cfg, float* online_dev, float* target_dev, float* mu_dev, float* nu_dev,
                 float* grad_dev, int32_t* count_dev, float* losses_dev, double* cum_losses_dev,
                 idqn_handle_t* out);
@@ -84,6 +84,7 @@ int idqn_destroy(idqn_handle_t h);
 /* flags for idqn_learn_on_batch */
 #define IDQN_F_GRADS_ONLY 1u   /* stop after the gradients are in grad_dev (data-parallel: all-reduce, then idqn_apply_adam) */
 #define IDQN_F_PROFILE 2u      /* bracket the dominant kernel with hipEvents (see idqn_profile_read) */
+#define IDQN_F_PROFILE_ALL 16u /* one hipEvent after every launch of the step (see idqn_profile_table) */
 #define IDQN_F_STOP_AFTER_DENSE0 4u  /* two-call backward, see idqn_backward_rest */
 #define IDQN_F_STOP_BEFORE_DENSE0_WGRAD 8u  /* factored data-parallel step, see idqn_finish_step_factored */
 
@@ -144,6 +145,10 @@ int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t
 /* Mean duration (ms) and launch count of the dominant kernel over the IDQN_F_PROFILE calls since
  * the last read; synchronises the events it reads.                                                 */
 int idqn_profile_read(idqn_handle_t h, double* mean_ms, int32_t* n_launches, char* kernel_name /*[64]*/);
+/* Per-launch table of the IDQN_F_PROFILE_ALL steps since the last read (at most ~100 steps are kept): one line per
+ * launch of a step, "name\tmean microseconds\tcount\n", in launch order.  A launch's time is the span between the
+ * event behind the previous launch and the event behind it (its duration plus its dispatch gap).                    */
+int idqn_profile_table(idqn_handle_t h, char* out, int32_t out_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Sum tree (slimdqn/sample_collection/sum_tree.py).  nodes_dev: float64 [2**depth - 1] in HBM,
@@ -179,8 +184,9 @@ int sumtree_set_one(double* nodes_dev, int32_t depth, int32_t index, double valu
  * (i + u_i) / n * root; same descent as sumtree_query, no host read of the root.                                      */
 int per_sample_leaves(const double* nodes_dev, int32_t depth, const double* uniforms_dev, int32_t n,
                       int32_t stratified, int32_t* leaves_out_dev, void* stream);
-/* w_i = (n_items * p_i / root)^(-beta) / max_j w_j for the sampled leaves (p from the sum tree).                     */
-int per_importance_weights(const double* nodes_dev, int32_t depth, const int32_t* leaves_dev, int32_t n,
+/* w_i = (n_items * p_i / root)^(-beta) / max_j w_j for the sampled leaves (p from the sum tree).  The leaves are first
+ * clamped, in place, to [0, n_items - 1] (a descent can end on an empty leaf through rounding in the sums).            */
+int per_importance_weights(const double* nodes_dev, int32_t depth, int32_t* leaves_dev, int32_t n,
                            int64_t n_items, double beta, float* weights_out_dev, void* stream);
 /* priority_i = (mean_k or max_k |td[k][i]| + eps)^alpha as float64, ready for sumtree_set on the same leaves;
  * max_priority_dev[0] (may be NULL) keeps the running maximum (sum_tree.py:18,32 `max_recorded_priority`).           */

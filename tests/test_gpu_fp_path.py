@@ -311,7 +311,8 @@ def test_entry_points_train_end_to_end(env_name, tmp_path):
     assert logs and all(np.isfinite(r["loss"]) and f"networks/{agent.n_networks - 1}_loss" in r for r in logs)
     assert int(agent._count[0].item()) >= 40
     model = pickle.load(open(os.path.join(p["save_path"], "models", "1"), "rb"))
-    assert set(model) == {"params"} and all(np.isfinite(v).all() for m in model["params"].values() for v in m.values())
+    assert set(model) == {"params"} and set(model["params"]) == {"params"}  # {"params": flax variables dict}, idqn.py:133
+    assert all(np.isfinite(v).all() for m in model["params"]["params"].values() for v in m.values())
 
 
 @pytest.mark.parametrize("env_name", ["lunar_lander", "atari"])

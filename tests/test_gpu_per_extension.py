@@ -83,9 +83,14 @@ def test_per_formulas_against_numpy():
     # importance weights
     lv = leaves.cpu().numpy()
     wts = torch.empty(n, dtype=torch.float32, device="cuda")
-    _hip.check(lib.per_importance_weights(_hip.ptr(a._nodes_dev), a._depth, _hip.ptr(leaves), n, 700, 0.4, _hip.ptr(wts), q), "w")
-    want = (700 * b.nodes[b.first_leaf + lv] / root) ** -0.4
+    _hip.check(lib.per_importance_weights(_hip.ptr(a._nodes_dev), a._depth, _hip.ptr(leaves), n, cap, 0.4, _hip.ptr(wts), q), "w")
+    want = (cap * b.nodes[b.first_leaf + lv] / root) ** -0.4
     np.testing.assert_allclose(wts.cpu().numpy(), want / want.max(), rtol=1e-6)
+    np.testing.assert_array_equal(leaves.cpu().numpy(), lv)  # every leaf was inside [0, n_items): left alone
+    # a leaf at or past the item count (a descent that rounding sent onto an empty leaf) is pulled back, in place
+    stray = torch.tensor([5, cap - 1, 40], dtype=torch.int32, device="cuda")
+    _hip.check(lib.per_importance_weights(_hip.ptr(a._nodes_dev), a._depth, _hip.ptr(stray), 3, 41, 0.4, _hip.ptr(wts), q), "w")
+    assert stray.cpu().numpy().tolist() == [5, 40, 40]
     # priorities from |td|
     td = rng.random((5, n)).astype(np.float32)
     out = torch.empty(n, dtype=torch.float64, device="cuda")
