@@ -263,7 +263,9 @@ struct DenseFwdArgs {
     float* part;      // [n_nets][nb][NS][J][32]
     const float* const* wbase;
     long w_off, n_items;
-    int n_nets, nb, NS, n_jt, F, J, rows_per_split;
+    int n_nets, nb, NS, n_jt, F, J;
+    int net_rot;  // work item n covers net (n + net_rot) % n_nets: the training set runs its target nets first, so that
+                  // the online Dense_0 kernel is the most recently streamed 79 MB when the backward pass re-reads it
 };
 
 __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
@@ -275,9 +277,10 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
     const int s = (int)(item % a.NS);
     item /= a.NS;
     const int bb = (int)(item % a.nb);
-    const int n = (int)(item / a.nb);
-    const int f0 = s * a.rows_per_split;
-    const int f1 = min(a.F, f0 + a.rows_per_split);
+    const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
+    // balanced split-K: the F / 32 row units are dealt as evenly as possible (the first F/32 % NS splits get one more)
+    const int units = a.F / 32, ub = units / a.NS, ur = units - ub * a.NS;
+    const int f0 = 32 * (s * ub + min(s, ur)), f1 = 32 * ((s + 1) * ub + min(s + 1, ur));
     const float* W = a.wbase[n] + a.w_off + (long)(f0 + h) * a.J + jt * 128 + 4 * bl;
     const float* X = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)f0 * 32 + lane;
     f32x16 acc[4];
@@ -316,6 +319,90 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
     }
 #undef D0F_LOAD
 #undef D0F_MMA
+    float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = mfma_row(r, h);
+        P[(4 * i + 0) * 32] = acc[0][r];
+        P[(4 * i + 1) * 32] = acc[1][r];
+        P[(4 * i + 2) * 32] = acc[2][r];
+        P[(4 * i + 3) * 32] = acc[3][r];
+    }
+}
+
+// The same kernel on the bf16 matrix cores (convp.h arithmetic): W and the activations are split into three bf16 planes
+// in registers as they arrive (W is streamed once per net and step, so a packed copy would only add HBM traffic) and
+// every 16-row k-step costs 6 x 32 MFMA cycles per tile instead of 8 x 64.  The f32 version was bound by its serial
+// MFMA chain (704 x 64 cycles per wave on < 1 wave per SIMD: 4.1 TB/s); this one by HBM and the split's VALU work.
+__device__ __forceinline__ bf16x8 planes8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, (u32x4){p[0], p[1], p[2], p[3]}); }
+
+__global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
+    const int jt = (int)(item % a.n_jt);
+    item /= a.n_jt;
+    const int s = (int)(item % a.NS);
+    item /= a.NS;
+    const int bb = (int)(item % a.nb);
+    const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
+    // balanced split-K: the F / 32 row units are dealt as evenly as possible (the first F/32 % NS splits get one more)
+    const int units = a.F / 32, ub = units / a.NS, ur = units - ub * a.NS;
+    const int f0 = 32 * (s * ub + min(s, ur)), f1 = 32 * ((s + 1) * ub + min(s + 1, ur));
+    // lane (bl, h): rows f0 + 16 c + 8 h + jj (jj = 0..7 = the MFMA's k index), W columns jt * 128 + 4 bl .. + 3 (one per
+    // tile q), activation column bl
+    const float* W = a.wbase[n] + a.w_off + (long)(f0 + 8 * h) * a.J + jt * 128 + 4 * bl;
+    const float* X = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(f0 + 8 * h) * 32 + bl;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int NC = (f1 - f0) / 16;  // splits are whole multiples of 32 rows: an even number of k-steps
+    // a ring of four k-steps of W / activation rows per lane (32 KB of loads in flight per wave: with less than one wave
+    // per SIMD the kernel was bound by how many bytes it kept in flight, not by HBM or the matrix cores)
+    float4 wv[4][8];
+    float xv[4][8];
+#define D3_LOAD(c, s)                                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
+        wv[s][jj] = *reinterpret_cast<const float4*>(W + ((long)(c) * 16 + jj) * a.J);         \
+        xv[s][jj] = X[((long)(c) * 16 + jj) * 32];                                             \
+    }
+#define D3_TILE(s, q, comp)                                                                    \
+    {                                                                                          \
+        unsigned p0[4], p1[4], p2[4];                                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(wv[s][2 * m].comp, wv[s][2 * m + 1].comp, p0[m], p1[m], p2[m]); \
+        const bf16x8 w0 = planes8(p0), w1 = planes8(p1), w2 = planes8(p2);                     \
+        acc[q] = mfma_bf16(w2, x0, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x2, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w1, x1, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w1, x0, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x1, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x0, acc[q]);                                                    \
+    }
+#define D3_MMA(s)                                                                              \
+    {                                                                                          \
+        unsigned q0[4], q1[4], q2[4];                                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xv[s][2 * m], xv[s][2 * m + 1], q0[m], q1[m], q2[m]); \
+        const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
+        D3_TILE(s, 0, x) D3_TILE(s, 1, y) D3_TILE(s, 2, z) D3_TILE(s, 3, w)                    \
+    }
+#define D3_STEP(u)                                                                             \
+    D3_LOAD(min(c + (u) + 3, NC - 1), ((u) + 3) & 3)                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (c + (u) < NC) D3_MMA(u)                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    D3_LOAD(0, 0)
+    D3_LOAD(min(1, NC - 1), 1)
+    D3_LOAD(min(2, NC - 1), 2)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < NC; c += 4) {
+        D3_STEP(0) D3_STEP(1) D3_STEP(2) D3_STEP(3)
+    }
+#undef D3_STEP
+#undef D3_LOAD
+#undef D3_TILE
+#undef D3_MMA
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -750,6 +837,7 @@ struct DenseWgradArgs {
     // sample block bb of head k: base + (bb / nb_inner) * outer + k * head + (bb % nb_inner) * inner   (floats)
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
+    float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
 };
 
 // Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
@@ -761,9 +849,19 @@ struct DenseWgradArgs {
 #ifndef D0W_DEPTH
 #define D0W_DEPTH 4  // row groups of theta / m / v in flight per thread in the fused kernel's streaming phase
 #endif
-template <bool FUSE_ADAM, int NQ>  // column tile JT = 128 * NQ (256 when the dense width allows it)
-__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats */) {
+// FUSE_DG (with FUSE_ADAM): the workgroup also produces its column tile's share of the Dense_0 DATA gradient,
+//   dL/da3[f][b] += sum over its 256 columns j of theta_old[f][j] * dh[j][b],
+// from the theta rows that stream through its registers anyway -- the separate data-gradient kernel re-read all of
+// theta (79 MB per step at K = 5; a pure read stream runs at ~4 TB/s on this chip: 24 us).  Each thread parks the
+// pre-update theta float4 in the LDS slot whose gradient it has just consumed; after the streaming phase the four waves
+// run D'[b][f] over 64 columns each on the MFMA (B operand = theta from LDS, A operand = dh rows from L2), add their four
+// tiles in LDS and write the 4 KB partial.  k_da3_finalize sums the column tiles' partials and applies the ReLU mask.
+// The LDS tile's columns are rotated by 4 * row: the MFMA reads one column of 32 rows per instruction, which would hit a
+// single bank with a 256-float pitch (rotated: 4-way, 8 cycles per 64-cycle MFMA); float4 accesses stay aligned.
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats (+ 4096 FUSE_DG) */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
+    static_assert(!FUSE_DG || (FUSE_ADAM && NQ == 2), "the fused data gradient rides on the fused 256-column kernel");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     const int jt = item % a.n_jt;
     item /= a.n_jt;
@@ -774,6 +872,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
     const int prow = wave * (64 / LPR) + lane / LPR, pcol = (lane % LPR) * 4;
     const long o0 = base + (long)prow * a.J + pcol;
+    auto rot = [&](int row, int col) { return FUSE_DG ? row * JT + ((col + 4 * row) & (JT - 1)) : row * JT + col; };
     // phase-2 state runs DEPTH row groups ahead (a ring of named-index registers): the rows of the first DEPTH
     // iterations are requested before the MFMA phase, so the workgroup keeps streaming while it computes its tile
     constexpr int DEPTH = D0W_DEPTH;
@@ -814,15 +913,17 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gs[mfma_row(r, h) * JT + jw + 32 * q + bl] = acc[q][r];
+        for (int r = 0; r < 16; ++r) gs[rot(mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
     __syncthreads();
     if (FUSE_ADAM) {
         const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int s = i % DEPTH;
-            const float4 g = *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
+            float* gp = &gs[rot(RPI * i + prow, pcol)];
+            const float4 g = *reinterpret_cast<const float4*>(gp);
             float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
+            if (FUSE_DG) *reinterpret_cast<float4*>(gp) = t4;  // theta BEFORE the update takes the consumed gradient's place
             if (i + DEPTH < NIT) {  // the slot just read is re-filled DEPTH row groups ahead, before the (may-alias) stores
                 const long on = o0 + (long)(RPI * (i + DEPTH)) * a.J;
                 th[s] = *reinterpret_cast<const float4*>(a.theta + on);
@@ -845,11 +946,105 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             *reinterpret_cast<float4*>(a.grad + g0 + (long)(RPI * i) * a.J) =
                 *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
+    if (FUSE_DG) {
+        __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
+        float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
+        for (int bb = 0; bb < a.nb; ++bb) {
+            const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
+            // A operand: dh^T, lane (b = bl, k = h) reads dh[j0 + jw + 2 t + h][b]; B operand: theta_old[f = bl][j = jw + 2 t + h]
+            const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + h) * 32 + bl;
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            float dv[2][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[0][u] = Dp[(long)(2 * u) * 32];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 MFMA steps (16 columns each)
+                if (c + 1 < 4) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dv[(c + 1) & 1][u] = Dp[(long)(16 * (c + 1) + 2 * u) * 32];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int col = jw + 16 * c + 2 * u + h;
+                    d = mfma32(dv[c & 1][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
+                }
+            }
+            // this wave's tile -> LDS: lane = row f (bl), 4 x 4 consecutive samples per register quad
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&red[wave * 1024 + bl * 32 + (((2 * g + h) ^ (bl & 7)) * 4)]) =
+                    make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+            __syncthreads();
+            {   // all 256 threads: float4 t of the 32 x 32 tile = row t >> 3, slot t & 7; the four waves' tiles in wave order
+                const int row = t >> 3, slot = ((t & 7) ^ (row & 7)) * 4;
+                float4 s4 = *reinterpret_cast<const float4*>(&red[row * 32 + slot]);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 y = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
+                    s4.x += y.x; s4.y += y.y; s4.z += y.z; s4.w += y.w;
+                }
+                float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
+                *reinterpret_cast<float4*>(O + t * 4) = s4;
+            }
+            __syncthreads();  // red is reused by the next batch block
+        }
+    }
 }
-template <bool FUSE_ADAM, int NQ>
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float gs[32 * 128 * NQ];
-    dense0_wgrad_body<FUSE_ADAM, NQ>(a, blockIdx.x, gs);
+    __shared__ __attribute__((aligned(16))) float gs[32 * 128 * NQ + (FUSE_DG ? 4096 : 0)];
+    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG>(a, blockIdx.x, gs);
+}
+
+// Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes
+// (zero-bordered, the Conv_2 gradients read them), the per-position sums over the samples (Conv_2 bias gradient), f32 rows
+// (f32 conv path).  One thread = 4 samples of one row f; 8 threads = a row; a wave = 8 rows = 512 contiguous plane bytes.
+struct Da3FinalizeArgs {
+    const float* dpart;  // [n_jt][K * nb][F][32]
+    const float* a3;     // [2K][nb][F * 32] (online nets first)
+    float* da3;          // f32 rows [K][nb][g.block] or nullptr
+    unsigned short* da3p;
+    float* pb;           // [K * nb][H * W][C] or nullptr
+    long n_rows;         // K * nb * F
+    int n_jt, F, C, K, nb;
+    ActGeom g;
+};
+__global__ __launch_bounds__(256) void k_da3_finalize(Da3FinalizeArgs a) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;  // float4 index
+    const long row = e >> 3;
+    const int slot = (int)(e & 7);
+    if (row >= a.n_rows) return;
+    const long slab = a.n_rows * 32;
+    float4 s = *reinterpret_cast<const float4*>(a.dpart + e * 4);
+    for (int j = 1; j < a.n_jt; ++j) {
+        const float4 y = *reinterpret_cast<const float4*>(a.dpart + j * slab + e * 4);
+        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+    }
+    const float4 m = *reinterpret_cast<const float4*>(a.a3 + e * 4);  // online nets are the first K * nb slots
+    s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f; s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
+    const long sl = row / a.F;
+    const int f = (int)(row - sl * a.F), pos = f / a.C, c = f - pos * a.C;
+    const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
+    const long pix = (long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w);
+    if (a.da3) *reinterpret_cast<float4*>(a.da3 + sl * a.g.block + (pix * a.C + c) * 32 + slot * 4) = s;
+    if (a.da3p) {
+        unsigned short* O = a.da3p + sl * a.g.block * 3 + pix * (3L * a.C * 32) + (long)c * 32 + slot * 4;
+        unsigned q0a, q1a, q2a, q0b, q1b, q2b;
+        split3_pk(s.x, s.y, q0a, q1a, q2a);
+        split3_pk(s.z, s.w, q0b, q1b, q2b);
+        *reinterpret_cast<uint2*>(O) = make_uint2(q0a, q0b);
+        *reinterpret_cast<uint2*>(O + (long)a.C * 32) = make_uint2(q1a, q1b);
+        *reinterpret_cast<uint2*>(O + 2L * a.C * 32) = make_uint2(q2a, q2b);
+    }
+    if (a.pb) {  // sum over the row's 32 samples: 4 in this thread, then its 8 neighbours (fixed order)
+        float r = (s.x + s.y) + (s.z + s.w);
+        r += __shfl_xor(r, 1);
+        r += __shfl_xor(r, 2);
+        r += __shfl_xor(r, 4);
+        if (slot == 0) a.pb[(sl * (a.g.H * a.g.W) + pos) * a.C + c] = r;
+    }
 }
 
 // --------------------------------------------------------------------------------------------

@@ -136,7 +136,7 @@ int build_layout(const idqn_config_t& c, Layout& L) {
 // One set of nets that run forward together: the 2K training nets, or the single inference net.
 struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
-    int NS = 0, rows_per_split = 0;  // split-K of this set's Dense_0 forward
+    int NS = 0;  // split-K of this set's Dense_0 forward
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -163,9 +163,10 @@ struct idqn_handle_s {
     // cnn
     ConvL conv[3];
     ActGeom gx, ga1, ga2, ga3, gda3, gda2, gda1;
-    int F = 0, J = 0, NS = 0, rows_per_split = 0;
+    int F = 0, J = 0, NS = 0;
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
+    float* dpart = nullptr;  // partial Dense_0 data gradients of the fused weight-gradient kernel [n_jt][K * nb][F][32]
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
     const float* infer_pbase = nullptr;  // parameter base of the net the last idqn_q_values call evaluated
@@ -238,10 +239,9 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
 
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
-    s.NS = h->NS; s.rows_per_split = h->rows_per_split;
+    s.NS = h->NS;
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
         const int units = h->F / 32;
-        s.rows_per_split = units_per_split * 32;
         s.NS = (units + units_per_split - 1) / units_per_split;
     }
     IDQN_HIP_CHECK(hipMalloc((void**)&s.wbase, sizeof(float*) * n_nets));
@@ -299,18 +299,15 @@ int cnn_setup(idqn_handle_s* h) {
     h->gda1 = make_geom(c0->OH, c0->OW, c0->CO, 0, 0, 0, 0);
     h->F = c2->OH * c2->OW * c2->CO;
     h->J = c.features[3];
-    // split-K of Dense_0 forward: splits are whole multiples of 32 rows (= 2 register chunks of 8 k-steps,
-    // so the double-buffered loop always sees an even chunk count); prefer an even split of F/32 units
+    // split-K of the Dense_0 forward: a weight-streaming kernel is bound by ~10 B/clk per CU (MI355X_MICROARCH.md), so
+    // what matters is that EVERY CU streams and that they all stream the same amount: as many 4-wave workgroups as CUs,
+    // never more (a 257th would stream alone after the others), with balanced splits of the F / 32 row units
     {
-        const int units = h->F / 32;
-        int best_ns = 1, best_waste = 1 << 30;
-        // ~16-24 splits (measured: 49 splits = 1960 waves ran slower, 46 vs 40 us, and slowed k_hidden)
-        for (int ns = 12; ns <= 24; ++ns) {
-            int per = (units + ns - 1) / ns, real_ns = (units + per - 1) / per;
-            int waste = real_ns * per - units;
-            if (waste < best_waste) { best_waste = waste; best_ns = real_ns; h->rows_per_split = per * 32; }
-        }
-        h->NS = best_ns;
+        const int units = h->F / 32, wgs_per_split = 2 * c.n_heads * (c.features[3] / 128) / 4 > 0 ? 2 * c.n_heads * (c.features[3] / 128) : 1;
+        int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
+        (void)wgs_per_split;
+        if (const char* e = getenv("IDQN_D0_SPLITS")) ns = atoi(e);
+        h->NS = std::max(1, std::min(std::min(ns, 64), units));
     }
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
@@ -352,6 +349,7 @@ int cnn_setup(idqn_handle_s* h) {
     IDQN_HIP_CHECK(hipMemcpy(h->train.in_set, is.data(), sizeof(int) * 2 * K, hipMemcpyHostToDevice));
     IDQN_HIP_CHECK(hipMemset(h->infer.in_set, 0, sizeof(int)));
     if ((rc = alloc_zero(&h->dh, (long)K * nb * h->J * 32, h, "dh"))) return rc;
+    if (h->J % 256 == 0 && (rc = alloc_zero(&h->dpart, (long)(h->J / 256) * K * nb * h->F * 32, h, "dpart"))) return rc;
     if (!h->planes) {
         if ((rc = alloc_zero(&h->da3, (long)K * nb * h->gda3.block, h, "da3"))) return rc;
         if ((rc = alloc_zero(&h->da2, (long)K * nb * h->gda2.block, h, "da2"))) return rc;
@@ -805,9 +803,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
-    d.rows_per_split = s.rows_per_split;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
-    hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
+    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
@@ -895,9 +894,10 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
 int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
                         long a3_head, long a3_inner, long dh_outer, long dh_head, long dh_inner, bool fuse_adam,
-                        bool profile, hipStream_t q) {
+                        bool profile, hipStream_t q, bool fuse_dg = false) {
     const int K = h->cfg.n_heads;
     DenseWgradArgs dw;
+    dw.dpart = h->dpart;
     dw.a3 = a3; dw.dh = dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
     dw.bcinv = h->bcinv; dw.ad = h->ad; dw.g_w0_base = h->g_w0_base; dw.g_w0_stride = h->g_w0_end - h->g_w0_begin;
     dw.w_off = h->off_w0; dw.P = h->L.head_stride;
@@ -915,11 +915,12 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    if (fuse_adam && nq == 2 && fuse_dg) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2, true>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    else if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (fuse_adam) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else if (nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
     else hipExtLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-    tl_mark(h, q, fuse_adam ? "dense0 wgrad + adam" : "dense0 wgrad");
+    tl_mark(h, q, fuse_dg ? "dense0 wgrad + dgrad + adam" : fuse_adam ? "dense0 wgrad + adam" : "dense0 wgrad");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -958,11 +959,16 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
     }
     tl_mark(h, q, "td + loss + dh");
-    // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient)
-    DenseDgradArgs dd;
-    dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
-    dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
-    {  // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
+    // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient).  On the fused single-device path it is
+    // computed INSIDE the weight-gradient + Adam kernel (theta streams once) and finished by k_da3_finalize; the two-call
+    // paths of the data-parallel step need it before the weight gradient and keep the separate kernel.
+    static const bool no_fuse_dg = getenv("IDQN_NO_FUSE_DGRAD") != nullptr;
+    const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg;
+    if (!fuse_dg) {
+        DenseDgradArgs dd;
+        dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+        dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
+        // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
         const long wg4 = (long)K * nb * cdiv(dd.n_ft, 4), wg3 = (long)K * nb * cdiv(dd.n_ft, 3);
         const long busy4 = cdiv(wg4, 256) * 4, busy3 = wg3 <= 512 ? cdiv(wg3, 256) * 3 : 1 << 30;
         if (busy3 < busy4) {
@@ -972,8 +978,8 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
             dd.n_items = wg4;
             hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
         }
+        tl_mark(h, q, "dense0 dgrad");
     }
-    tl_mark(h, q, "dense0 dgrad");
     if (stop_before_dense0_wgrad) {
         h->pend_B = B; h->pend_stage = 1; h->pend_profile = profile;
         IDQN_HIP_CHECK(hipGetLastError());
@@ -981,8 +987,15 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     }
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
     int rcw = launch_dense0_wgrad(h, s.a3, h->dh, nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
-                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q);
+                                  (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
+    if (fuse_dg) {
+        Da3FinalizeArgs fa;
+        fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
+        fa.n_rows = (long)K * nb * h->F; fa.n_jt = h->J / 256; fa.F = h->F; fa.C = c2->CO; fa.K = K; fa.nb = nb; fa.g = h->gda3;
+        hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
+        tl_mark(h, q, "da3 finalize (sum, mask, planes)");
+    }
     if (stop_after_dense0) {
         h->pend_B = B; h->pend_stage = 2;
         IDQN_HIP_CHECK(hipGetLastError());
