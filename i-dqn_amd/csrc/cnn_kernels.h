@@ -510,6 +510,7 @@ struct TdArgs {
     double* cum;           // [K] running f64 sum of the per-head losses (idqn.py:72)
     int finish_step;       // 1: this launch also does count += 1 and cum += loss (every later kernel of the step
                            //    reads bcinv, not count); 0: two-phase step, idqn_apply_adam's epilogue does it
+    int bcinv_done;          // 1: the staging launch of this step already wrote bcinv (plane path)
     const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr = plain mean
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
 };
@@ -627,9 +628,11 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
         if (t < a.A) G[a.g_b1_off + t] = gb1;
         if (t == 0) {
             a.losses[k] = loss_acc / (float)a.Bdiv;
-            const double tt = (double)(a.count[k] + 1);
-            a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
-            a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+            if (!a.bcinv_done) {
+                const double tt = (double)(a.count[k] + 1);
+                a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
+                a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+            }
             if (a.finish_step) {
                 a.count[k] += 1;
                 a.cum[k] = a.cum[k] + (double)(loss_acc / (float)a.Bdiv);
@@ -1255,20 +1258,28 @@ struct AdamArgs {
 };
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int k = blockIdx.y;
-    // the grid covers [begin, end) minus the skipped range (the fused kernel's Dense_0/kernel: 98 % of the head),
-    // compacted -- not one mostly-empty workgroup per 1024 skipped elements
-    long e = a.begin + ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    // FOUR lanes per float4 of parameters: where the gradient is still per-chunk slabs (the conv leaves on the fused path),
+    // each lane sums every fourth chunk, up to 8 loads in flight, and the four partial sums are combined in a
+    // fixed order, ((l0 + l1) + (l2 + l3)) -- one latency round instead of npc / 8 (Conv_0 has 51 chunks).  Lane 0 of the
+    // quad then does the update.  The grid covers [begin, end) minus the skipped range (the fused kernel's
+    // Dense_0/kernel: 98 % of the head), compacted.
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int sub = (int)(gid & 3);
+    long e = a.begin + (gid >> 2) * 4;
     if (e >= a.skip_begin) e += a.skip_end - a.skip_begin;
-    if (e >= a.end) return;
+    if (e >= a.end) return;  // whole quads leave together
     const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const long o = (long)k * a.P + e;
     const long w0n = a.w0_end - a.w0_begin;
     const long go = e < a.w0_begin ? (long)k * a.gP + e
                     : (e < a.w0_end ? a.g_w0_base + (long)k * w0n + (e - a.w0_begin) : (long)k * a.gP + e - w0n);
-    float4 th = *reinterpret_cast<float4*>(a.theta + o);  // independent of the gradient assembly below: issue first
-    float4 m = *reinterpret_cast<float4*>(a.mu + o);
-    float4 v = *reinterpret_cast<float4*>(a.nu + o);
-    float4 g = *reinterpret_cast<const float4*>(a.grad + go);
+    float4 th = make_float4(0.f, 0.f, 0.f, 0.f), m = th, v = th, g = th;
+    if (sub == 0) {  // independent of the gradient assembly below: issue first
+        th = *reinterpret_cast<float4*>(a.theta + o);
+        m = *reinterpret_cast<float4*>(a.mu + o);
+        v = *reinterpret_cast<float4*>(a.nu + o);
+    }
+    bool from_slab = false;
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
         if (si >= a.n_seg) break;
@@ -1277,27 +1288,27 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
         if (e >= sg.w_off && e < sg.w_off + sg.wsize) se = e - sg.w_off;
         else if (e >= sg.b_off && e < sg.b_off + sg.bsize) se = sg.wsize + (e - sg.b_off);
         if (se >= 0) {
+            from_slab = true;
             const float* sp = sg.slab + (long)k * sg.slab_stride + se;
             const long pstride = (long)a.K * sg.slab_stride;
-            g = make_float4(0.f, 0.f, 0.f, 0.f);
-            int pc = 0;
-            for (; pc + 8 <= sg.npc; pc += 8) {  // 8 independent loads in flight, added in chunk order
+            for (int pc0 = sub; pc0 < sg.npc; pc0 += 32) {  // 8 chunks per lane and round (32 per quad), no load past the last chunk
                 float4 x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(sp + (pc + u) * pstride);
+                for (int u = 0; u < 8; ++u)
+                    if (pc0 + 4 * u < sg.npc) x[u] = *reinterpret_cast<const float4*>(sp + (pc0 + 4 * u) * pstride);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
-            }
-            if (pc < sg.npc) {  // tail of up to 7 chunks: every load issued, out-of-range ones re-read the last chunk
-                float4 x[7];
-#pragma unroll
-                for (int u = 0; u < 7; ++u) x[u] = *reinterpret_cast<const float4*>(sp + min(pc + u, sg.npc - 1) * pstride);
-#pragma unroll
-                for (int u = 0; u < 7; ++u)
-                    if (pc + u < sg.npc) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
+                for (int u = 0; u < 8; ++u)
+                    if (pc0 + 4 * u < sg.npc) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
             }
         }
     }
+    if (from_slab) {  // quad-uniform: the four lanes share e
+        g.x += __shfl_xor(g.x, 1); g.y += __shfl_xor(g.y, 1); g.z += __shfl_xor(g.z, 1); g.w += __shfl_xor(g.w, 1);
+        g.x += __shfl_xor(g.x, 2); g.y += __shfl_xor(g.y, 2); g.z += __shfl_xor(g.z, 2); g.w += __shfl_xor(g.w, 2);
+    } else if (sub == 0) {
+        g = *reinterpret_cast<const float4*>(a.grad + go);
+    }
+    if (sub != 0) return;
     adam_elem(a.ad, bc1, bc2, g.x, th.x, m.x, v.x);
     adam_elem(a.ad, bc1, bc2, g.y, th.y, m.y, v.y);
     adam_elem(a.ad, bc1, bc2, g.z, th.z, m.z, v.z);

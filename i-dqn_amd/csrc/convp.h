@@ -108,7 +108,12 @@ struct StageArgs {
     const float* const* wbase;
     unsigned short* wq;
     long wq_stride;         // bytes per net
-    int n_jobs, pad;
+    int n_jobs, K;
+    // Adam bias corrections of THIS step, 1 / (1 - b^t) with t = count + 1 (optax, idqn.py:52), written for the K heads by
+    // the first pack block: off the critical path of the loss kernel, which did it before (two double pows)
+    const int32_t* count;
+    float* bcinv;
+    float b1, b2;
     PackJob job[8];
 };
 
@@ -139,12 +144,19 @@ __device__ __forceinline__ void dma16(unsigned voff, unsigned long sbase, unsign
 // round trips (measured ~4000 cycles); after this warm-up they all hit the scalar cache.
 template <int BYTES>
 __device__ __forceinline__ void warm_kernargs() {
-    static_assert(BYTES <= 8 * 64, "kernel arguments longer than 8 cache lines");
+    static_assert(BYTES <= 16 * 64, "kernel arguments longer than 16 cache lines");
     auto kp = (const __attribute__((address_space(4))) u32x4*)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int L = (BYTES + 63) / 64;  // lines; all loads are issued before the one wait the asm statement forces
-    const u32x4 v0 = kp[0], v1 = kp[L > 1 ? 4 : 0], v2 = kp[L > 2 ? 8 : 0], v3 = kp[L > 3 ? 12 : 0];
-    const u32x4 v4 = kp[L > 4 ? 16 : 0], v5 = kp[L > 5 ? 20 : 0], v6 = kp[L > 6 ? 24 : 0], v7 = kp[L > 7 ? 28 : 0];
-    asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+    constexpr int L = (BYTES + 63) / 64;  // lines; all loads of a group are issued before the one wait its asm statement forces
+    {
+        const u32x4 v0 = kp[0], v1 = kp[L > 1 ? 4 : 0], v2 = kp[L > 2 ? 8 : 0], v3 = kp[L > 3 ? 12 : 0];
+        const u32x4 v4 = kp[L > 4 ? 16 : 0], v5 = kp[L > 5 ? 20 : 0], v6 = kp[L > 6 ? 24 : 0], v7 = kp[L > 7 ? 28 : 0];
+        asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+    }
+    if (L > 8) {
+        const u32x4 v0 = kp[32], v1 = kp[L > 9 ? 36 : 32], v2 = kp[L > 10 ? 40 : 32], v3 = kp[L > 11 ? 44 : 32];
+        const u32x4 v4 = kp[L > 12 ? 48 : 32], v5 = kp[L > 13 ? 52 : 32], v6 = kp[L > 14 ? 56 : 32], v7 = kp[L > 15 ? 60 : 32];
+        asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+    }
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits until at most n of this

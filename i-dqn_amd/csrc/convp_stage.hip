@@ -14,6 +14,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
     __shared__ unsigned short tile[64][40];  // [element][sample], 80-byte rows keep the 16-byte reads aligned
     const int t = threadIdx.x;
+    warm_kernargs<sizeof(StageArgs)>();
     if ((int)blockIdx.x < a.n_prep_blocks) {
         const int n_et = (int)((a.E + 63) / 64);
         int b = blockIdx.x;
@@ -50,6 +51,11 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
         return;
     }
     const long pb = (long)blockIdx.x - a.n_prep_blocks;
+    if (pb == 0 && a.bcinv && t < a.K) {
+        const double tt = (double)(a.count[t] + 1);
+        a.bcinv[2 * t] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
+        a.bcinv[2 * t + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+    }
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
@@ -69,20 +75,21 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
     const int hh = lane >> 5, col = ct * 32 + (lane & 31);
     const float* W = a.wbase[net] + j.src_off;
     float v[8];
+    if (j.mode == 0) {  // k runs over kernel rows (stride CO); lanes over out channels: 8 coalesced loads
+        const int rho0 = (j.CI >= 16 ? q * j.CI + cc * 16 : q * 16) + 8 * hh;
+        const float* src = W + ((long)khv * j.KW * j.CI + rho0) * j.CO + col;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int kk = 8 * hh + i;
-        long idx;
-        if (j.mode == 0) {
-            const int rho = j.CI >= 16 ? q * j.CI + cc * 16 + kk : q * 16 + kk;
-            idx = ((long)khv * j.KW * j.CI + rho) * j.CO + col;
-        } else {
-            const int kh = (j.rh + j.PLh) % j.S + j.S * (j.KHs - 1 - khv);
-            const int kw = (j.rw + j.PLw) % j.S + j.S * (j.KHs - 1 - q);
-            idx = ((long)(kh * j.KW + kw) * j.CI + col) * j.CO + (cc * 16 + kk);
-        }
-        v[i] = W[idx];
-        if (j.div255) v[i] = v[i] / 255.0f;
+        for (int i = 0; i < 8; ++i) v[i] = src[(long)i * j.CO];
+    } else {  // re-indexed kernel: k runs over the layer's OUT channels, contiguous in HWIO: two 16-byte loads
+        const int kh = (j.rh + j.PLh) % j.S + j.S * (j.KHs - 1 - khv);
+        const int kw = (j.rw + j.PLw) % j.S + j.S * (j.KHs - 1 - q);
+        const float* src = W + ((long)(kh * j.KW + kw) * j.CI + col) * j.CO + cc * 16 + 8 * hh;
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+    if (j.div255) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] / 255.0f;
     }
     unsigned p0[4], p1[4], p2[4];
 #pragma unroll

@@ -677,6 +677,10 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
         }
     }
     a.n_jobs = nj;
+    if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; }
+    static const int part = getenv("IDQN_STAGE_PART") ? atoi(getenv("IDQN_STAGE_PART")) : 0;  // timing experiments only
+    if (part == 1) return convp_launch_stage(a, a.n_prep_blocks, q);
+    if (part == 2) { const int np = a.n_prep_blocks; a.n_prep_blocks = 0; (void)np; return convp_launch_stage(a, (int)blocks, q); }
     return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q);
 }
 
@@ -822,7 +826,7 @@ int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e
     IDQN_REQUIRE(skip_b == skip_e || (skip_b >= begin && skip_e <= end && skip_b % 4 == 0 && skip_e % 4 == 0),
                  "launch_adam: bad skip range");
     if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
-    hipLaunchKernelGGL(k_adam, dim3(cdiv((end - begin - (skip_e - skip_b)) / 4, 256), h->cfg.n_heads), dim3(256), 0, q, a);
+    hipLaunchKernelGGL(k_adam, dim3(cdiv(end - begin - (skip_e - skip_b), 256), h->cfg.n_heads), dim3(256), 0, q, a);  // 4 lanes per float4
     tl_mark(h, q, "adam (small leaves + slab sums)");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
@@ -949,6 +953,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
+    ta.bcinv_done = h->planes ? 1 : 0;
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
         WtBuildArgs wb;
