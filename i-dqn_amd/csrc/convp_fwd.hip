@@ -22,8 +22,6 @@
 #define CP_ABLATE 0  // timing experiments only (results are wrong): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA in the loop
 #endif
 
-int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue);
-
 namespace {
 
 __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* p) {
@@ -366,8 +364,7 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
 }
 
 template <int NPA, int CT, int NQ, int NT>
-int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, size_t lds_bytes, hipStream_t q, long long* prof) {
-    const int ring = convp_fwd_ring(stage_bytes, NT, a.epilogue);
+int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, int ring, size_t lds_bytes, hipStream_t q, long long* prof) {
     static size_t attr = 0;  // per instantiation
     if (lds_bytes > attr) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cfwd<NPA, CT, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -379,18 +376,18 @@ int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, size_t lds_by
 }
 
 template <int NPA, int CT, int NQ>
-int launch_nt(const CFwdArgs& a, int NT, int n_items, size_t stage_bytes, size_t lds_bytes, hipStream_t q, long long* prof) {
+int launch_nt(const CFwdArgs& a, int NT, int n_items, size_t stage_bytes, int ring, size_t lds_bytes, hipStream_t q, long long* prof) {
     switch (NT) {
-        case 1: return launch_one<NPA, CT, NQ, 1>(a, n_items, stage_bytes, lds_bytes, q, prof);
-        case 2: return launch_one<NPA, CT, NQ, 2>(a, n_items, stage_bytes, lds_bytes, q, prof);
-        case 3: return launch_one<NPA, CT, NQ, 3>(a, n_items, stage_bytes, lds_bytes, q, prof);
+        case 1: return launch_one<NPA, CT, NQ, 1>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
+        case 2: return launch_one<NPA, CT, NQ, 2>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
+        case 3: return launch_one<NPA, CT, NQ, 3>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
         default: break;
     }
     if (CT == 1) {
         switch (NT) {
-            case 4: return launch_one<NPA, 1, NQ, 4>(a, n_items, stage_bytes, lds_bytes, q, prof);
-            case 5: return launch_one<NPA, 1, NQ, 5>(a, n_items, stage_bytes, lds_bytes, q, prof);
-            case 6: return launch_one<NPA, 1, NQ, 6>(a, n_items, stage_bytes, lds_bytes, q, prof);
+            case 4: return launch_one<NPA, 1, NQ, 4>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
+            case 5: return launch_one<NPA, 1, NQ, 5>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
+            case 6: return launch_one<NPA, 1, NQ, 6>(a, n_items, stage_bytes, ring, lds_bytes, q, prof);
             default: break;
         }
     }
@@ -403,22 +400,22 @@ int convp_fwd_max_nt(int CT) { return CT == 1 ? 6 : 3; }
 
 // two stage buffers, behind them the data gradient's mask tiles (2 KB per tile and wave); the epilogue turns every tile
 // around in 10 KB per wave of the (then free) stage buffers
-int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue) {  // three stage buffers when they fit
+int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue, size_t budget) {  // three stage buffers when they fit
     static const int forced = getenv("IDQN_CONV_RING") ? atoi(getenv("IDQN_CONV_RING")) : 0;
     if (forced == 2 || forced == 3) return forced;
-    return 3 * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0) <= 160 * 1024 ? 3 : 2;
+    return 3 * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0) <= budget ? 3 : 2;
 }
-size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue) {
-    const size_t need = convp_fwd_ring(stage_bytes, NT, epilogue) * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0);
+size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring) {
+    const size_t need = ring * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0);
     return need < 40960 ? 40960 : need;
 }
 
-int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, size_t lds_bytes,
-                     hipStream_t q, long long* prof) {
+int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, int ring,
+                     size_t lds_bytes, hipStream_t q, long long* prof) {
     IDQN_REQUIRE(lds_bytes <= 160 * 1024, "plane conv: %zu bytes of LDS per workgroup", lds_bytes);
-    if (NPA == 1 && NQ == 2) return CT == 1 ? launch_nt<1, 1, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<1, 2, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
-    if (NPA == 3 && NQ == 2) return CT == 1 ? launch_nt<3, 1, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 2>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
-    if (NPA == 3 && NQ == 3) return CT == 1 ? launch_nt<3, 1, 3>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 3>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
-    if (NPA == 3 && NQ == 4) return CT == 1 ? launch_nt<3, 1, 4>(a, NT, n_items, stage_bytes, lds_bytes, q, prof) : launch_nt<3, 2, 4>(a, NT, n_items, stage_bytes, lds_bytes, q, prof);
+    if (NPA == 1 && NQ == 2) return CT == 1 ? launch_nt<1, 1, 2>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof) : launch_nt<1, 2, 2>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 2) return CT == 1 ? launch_nt<3, 1, 2>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof) : launch_nt<3, 2, 2>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 3) return CT == 1 ? launch_nt<3, 1, 3>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof) : launch_nt<3, 2, 3>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof);
+    if (NPA == 3 && NQ == 4) return CT == 1 ? launch_nt<3, 1, 4>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof) : launch_nt<3, 2, 4>(a, NT, n_items, stage_bytes, ring, lds_bytes, q, prof);
     IDQN_REQUIRE(false, "plane conv: no kernel for %d planes, %d taps per superstep", NPA, NQ);
 }

@@ -146,7 +146,7 @@ struct NetSet {
 
 // host-side plans of the plane conv launches: the work items of a launch depend only on geometry, net count and batch
 // blocks, so they are built once and kept on the device
-struct FwdPlan { int n_items = 0, NT = 0, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
+struct FwdPlan { int n_items = 0, NT = 0, ring = 2, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
 struct WgradPlan { CWItem* dev = nullptr; int n_items = 0, n_chunks = 0, MT = 0, PG = 0; size_t lds = 0; };
 
 }  // namespace
@@ -518,15 +518,11 @@ long fwd_stage_bytes(const RoleGeom& g, int OW, int p0, int np, int* n_rows) {
     return bytes;
 }
 
-int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
-    auto key = std::make_tuple(role, n_nets, nb);
-    auto itp = h->fwd_plans.find(key);
-    if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
+// one candidate plan: about `target` workgroups per launch, `budget` bytes of LDS each (160 KB: one per CU, 80 KB: two)
+int plan_fwd_target(int role, int n_nets, int nb, const RoleGeom& g, int target, size_t budget, FwdPlan& pl) {
     const int nt_max = convp_fwd_max_nt(g.CT);
     long npos_total = 0;
     for (int v = 0; v < g.n_var; ++v) npos_total += (long)g.var[v].OH * g.var[v].OW;
-    // about one workgroup per CU and launch (they are all co-resident, one per CU: equal work = no tail)
-    static const int target = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 256;
     const int per_slot = std::max(1, target / (n_nets * nb));
     std::vector<CItem> items;
     int np_all = 0;
@@ -556,10 +552,11 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
         for (;; ++R) {
             const int np = (npos + R - 1) / R;
             bool ok = (np * g.CT + 3) / 4 <= nt_max;
+            const long masks = role >= 3 ? 4L * ((np * g.CT + 3) / 4) * 2048 : 0;  // the data gradient's mask tiles
             for (int r = 0, p0 = 0; ok && r < R; ++r) {
                 const int n = npos / R + (r < npos % R ? 1 : 0);
                 int rows;
-                if (n > 0 && (fwd_stage_bytes(g, OW, p0, n, &rows) > 68 * 1024 || rows > CP_MAX_STRIPS)) ok = false;
+                if (n > 0 && (2 * fwd_stage_bytes(g, OW, p0, n, &rows) + masks > (long)budget - 8 * 1024 || rows > CP_MAX_STRIPS)) ok = false;
                 p0 += n;
             }
             if (ok || R >= npos) break;
@@ -583,7 +580,7 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     }
     // The kernel derives item b arithmetically: slot = b / items_per_slot (net-major: consecutive workgroups, which the
     // XCD-contiguous remap keeps on one XCD, share a net's weights), then variant and balanced range inside the slot.
-    FwdPlan pl;
+    pl = FwdPlan();
     pl.n_items = (int)items.size();
     for (int v = 0; v < g.n_var; ++v) {
         pl.r_begin[v] = pl.items_per_slot;
@@ -594,8 +591,29 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     pl.NT = (np_all * g.CT + 3) / 4;
     IDQN_REQUIRE(pl.NT >= 1 && pl.NT <= nt_max, "plane conv: role %d needs %d tiles per wave", role, pl.NT);
     pl.stage = (size_t)stage_max;
-    pl.lds = convp_fwd_lds(pl.stage, pl.NT, role <= 2 ? 0 : 1);
-    IDQN_REQUIRE(pl.lds <= 160 * 1024, "plane conv: role %d needs %zu bytes of LDS", role, pl.lds);
+    pl.ring = convp_fwd_ring(pl.stage, pl.NT, role <= 2 ? 0 : 1, budget);
+    pl.lds = convp_fwd_lds(pl.stage, pl.NT, role <= 2 ? 0 : 1, pl.ring);
+    IDQN_REQUIRE(pl.lds <= budget, "plane conv: role %d needs %zu bytes of LDS", role, pl.lds);
+    return IDQN_OK;
+}
+
+// The launch plan of a role: one workgroup per CU, all co-resident, equal work.  IDQN_CONV_WGS=512 plans two smaller
+// workgroups per CU instead (80 KB of LDS each), so that one's prologue / first fill / epilogue overlaps the other's main
+// loop -- measured: Conv_0 forward 18.8 -> 18.5 us, Conv_1 data gradient 16.9 -> 21.7 us (more weight re-staging per
+// MFMA, a two-deep ring); not the default.
+int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
+    auto key = std::make_tuple(role, n_nets, nb);
+    auto itp = h->fwd_plans.find(key);
+    if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
+    static const int forced = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 0;
+    FwdPlan pl;
+    int rc = IDQN_E_INVALID;
+    if (forced > 256) {
+        rc = plan_fwd_target(role, n_nets, nb, g, forced ? forced : 512, 80 * 1024, pl);
+        if (!rc && pl.NT < 2 && !forced) rc = IDQN_E_INVALID;  // items too small to be worth two per CU
+    }
+    if (rc) rc = plan_fwd_target(role, n_nets, nb, g, forced && forced <= 256 ? forced : 256, 160 * 1024, pl);
+    if (rc) return rc;
     *out = &(h->fwd_plans[key] = pl);
     return IDQN_OK;
 }
@@ -736,7 +754,7 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     a.out_slot = gout->block * 6; a.out_Wp = gout->Wp; a.out_lo_h = gout->lo_h; a.out_lo_w = gout->lo_w;
     a.out_W = gout->W; a.out_H = gout->H;
     long long* prof = (h->cprof && h->cprof_role == role && &s == &h->train && pl->n_items <= 4096) ? (long long*)h->cprof : nullptr;
-    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->lds, q, prof);
+    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->ring, pl->lds, q, prof);
 }
 
 int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {

@@ -31,7 +31,7 @@ import torch.distributed as dist
 from slimdqn import _hip
 
 
-def _factored_step(agent, shard, global_batch, group, extra_flags):
+def _factored_step(agent, shard, global_batch, group, extra_flags, serial=False):
     import torch
 
     lib, q = _hip.lib(), _hip.current_stream
@@ -52,8 +52,16 @@ def _factored_step(agent, shard, global_batch, group, extra_flags):
     _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()),
                "idqn_export_dense0_factors")
     work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)  # ONE collective for both factors
+    if serial:  # test mode: no collective overlaps any kernel (the stream-race stress compares the two bit for bit)
+        work.wait()
+        torch.cuda.synchronize()
     _hip.check(lib.idqn_backward_rest(agent._handle, q()), "idqn_backward_rest")  # conv backward, under the gather
+    if serial:
+        torch.cuda.synchronize()
     small = dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group, async_op=True)  # small leaves + K losses
+    if serial:
+        small.wait()
+        torch.cuda.synchronize()
     work.wait()
     args = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), world * nb, nb, n_a3 + n_dh, nb * X, X,
             n_a3 + n_dh, nb * Y, Y)
@@ -64,13 +72,14 @@ def _factored_step(agent, shard, global_batch, group, extra_flags):
     return agent._losses
 
 
-def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags: int = 0, overlap=None, mode=None):
+def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags: int = 0, overlap=None, mode=None,
+                       serial: bool = False):
     """One global gradient step; ``shard`` is this rank's ReplayElement-like slice of the global batch."""
     on_gpu_cnn = agent._grad.is_cuda and getattr(agent, "_arch", "") == "cnn"
     if mode is None:
         mode = os.environ.get("IDQN_DP_MODE", "factored")
     if mode == "factored" and on_gpu_cnn and overlap is None:
-        return _factored_step(agent, shard, global_batch, group, extra_flags)
+        return _factored_step(agent, shard, global_batch, group, extra_flags, serial)
     if overlap is None:
         overlap = (os.environ.get("IDQN_DP_OVERLAP", "1") != "0" and agent._grad.is_cuda
                    and getattr(agent, "_arch", "") == "cnn")
@@ -84,6 +93,11 @@ def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags:
     # forward, head, Dense_0 data + weight gradient are queued; the conv backward is not yet
     agent._learn(shard, flags=_hip.F_STOP_AFTER_DENSE0 | extra_flags, mean_divisor=global_batch)
     big = dist.all_reduce(agent._grad_w0, op=dist.ReduceOp.SUM, group=group, async_op=True)  # 79.3 MB, 98 %
+    if serial:
+        import torch
+
+        big.wait()
+        torch.cuda.synchronize()
     _hip.check(_hip.lib().idqn_backward_rest(agent._handle, _hip.current_stream()), "idqn_backward_rest")
     dist.all_reduce(agent._grad_small, op=dist.ReduceOp.SUM, group=group)  # 1.6 MB of small leaves + the K losses
     big.wait()  # the compute stream waits for the Dense_0 region

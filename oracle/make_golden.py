@@ -155,6 +155,9 @@ FP_CASES = {
     "cnn_atari_k5": ("cnn", (84, 84, 4), 6, [32, 64, 64, 512], 5, 32, 2),
     "cnn_atari_a18_b64": ("cnn", (84, 84, 4), 18, [32, 64, 64, 512], 2, 64, 1),
     "fc_lunar_k3": ("fc", 8, 4, [100, 100], 3, 32, 3),
+    # BASELINE configs 4 and 5 at their full single-device workload (one step each; probe indices keep the fixtures small)
+    "cnn_atari_k5_b256": ("cnn", (84, 84, 4), 6, [32, 64, 64, 512], 5, 256, 1),
+    "cnn_atari_k64": ("cnn", (84, 84, 4), 6, [32, 64, 64, 512], 64, 32, 1),
 }
 FP_HYPER = {"gamma": 0.99, "n": 1, "lr": 6.25e-5, "eps": 1.5e-4}
 

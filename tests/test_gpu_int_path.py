@@ -47,6 +47,13 @@ def test_prioritized_known_answers():
     kat.check_prioritized_kat(_classes()[2])
 
 
+@pytest.mark.parametrize("ci", range(3))
+def test_uniform_reference_traces(ci):
+    """The reference-captured uniform add / remove / sample traces (u0..u2) on the PRODUCT sampler, not only the oracle."""
+    z, meta = kat.load_sampler_traces()
+    kat.replay_uniform_trace(_classes()[1], z, meta, ci)
+
+
 @pytest.mark.parametrize("pi", range(3))
 def test_prioritized_reference_traces(pi):
     z, meta = kat.load_sampler_traces()
