@@ -181,7 +181,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, int ring,
                      size_t lds_bytes, hipStream_t q, long long* prof = nullptr);
 int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue, size_t budget);  // stage buffers: 3 when they fit the budget
-size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring);  // prof: per-workgroup phase stamps [n_items][8] (debugging) or nullptr
+size_t convp_fwd_mask_off(size_t stage_bytes, int NT, int ring, bool planes_out, bool f32_out);
+size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring, bool planes_out, bool f32_out);  // prof: per-workgroup phase stamps [n_items][8] (debugging) or nullptr
 int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
 int convp_fwd_max_nt(int CT);

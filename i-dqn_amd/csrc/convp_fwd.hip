@@ -14,6 +14,7 @@
 // double-buffered, one s_barrier per superstep, then NQ x NT tile-steps of 6 (Conv_0: 3) MFMAs from LDS fragments.
 // Orientation: A = activations (rows = samples), B = weights (columns = channels), so a lane ends up with 4 x 4
 // consecutive samples of ONE channel: plane rows are written as 8-byte pieces, the bias / mask is one value per lane.
+#include <algorithm>
 #include <cstdlib>
 
 #include "convp.h"
@@ -41,7 +42,7 @@ __device__ __forceinline__ bf16x8 frag_lin(const unsigned char* p) {
 }
 
 template <int NPA, int CT, int NQ, int NT>
-__global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, int ring, long long* prof) {
+__global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, int ring, unsigned mask_off, long long* prof) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int WB = NQ * CT * 3 * 1024, BLKA = NPA * 1024, NWP = NQ * CT * 3;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
         bias = (it.net < a.n_first ? a.pbase[0] + (long)it.net * a.pstride : a.pbase[1] + (long)(it.net - a.n_first) * a.pstride)[a.b_off + co];
     // data gradient: the ReLU mask = plane 0 of the forward activation at the output pixel, 2 KB per tile, copied into
     // LDS behind the stage buffers while the last superstep computes
-    const unsigned mask_lds = ring * stage_bytes + wave * (NT * 2048);
+    const unsigned mask_lds = mask_off + wave * (NT * 2048);
     auto tile_out = [&](int p, int& yh, int& yw) {
         const int oh = p / OW, ow = p - oh * OW;
         yh = oh * v.out_mul + v.out_add_h;
@@ -195,18 +196,16 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the mask copies
-        __builtin_amdgcn_s_barrier();
         if (prof && t == 256) {
             long long* pr = prof + 8L * 4096 + (long)blockIdx.x * 8;
             pr[0] = l_wait; pr[1] = l_bar; pr[2] = l_issue; pr[3] = cnt;
         }
-        return;
     }
     // ---- compute waves -------------------------------------------------------------------------------------------
     // Fragment reads of tile-step u + 1 are issued one per gap BETWEEN the MFMAs of tile-step u (the wave issues an MFMA,
     // is free for the ~32 cycles it runs, and blocks at the next, dependent one): sched_barrier pins that order.
     int cbuf = 0;
-    for (int ss = 0; ss < NSS; ++ss) {
+    for (int ss = 0; ss < NSS && !loader; ++ss) {
         const unsigned cur_off = cbuf * stage_bytes;
         cbuf = cbuf + 1 == ring ? 0 : cbuf + 1;
         const long long pw = prof ? clock64() : 0;
@@ -282,23 +281,51 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
     const long long pt3 = prof ? clock64() : 0;
     // ---- epilogue: lane = channel co, registers = samples (r & 3) + 8 (r >> 2) + 4 h -------------------------------
     // A lane's values of a tile are 8-byte pieces of 64-byte rows; written straight to HBM every store instruction would
-    // touch 32 rows (measured: ~330 cycles each).  Each wave therefore turns its tile around in LDS (the stage buffers
+    // touch 32 rows (measured: ~330 cycles each).  Each wave therefore turns a tile around in LDS (the stage buffers
     // are free now) and stores whole 1 KiB runs: 16 rows of a plane, or 8 rows of the f32 copy, per instruction.
+    // The work (bias / mask, the 3-way bf16 split: ~120 VALU instructions per tile) is shared with the loader waves, idle
+    // by now: compute wave w keeps its first KEEP tiles and hands the others, as raw accumulators through LDS, to loader
+    // wave w + 4, which has the same tile table.
+    constexpr int KEEP = (NT + 1) / 2, NH = NT - KEEP;
+    const unsigned r_f32 = a.out3 ? 6144 : 0, rsz = r_f32 + (a.out_f32 ? 4096 : 0);
+    unsigned char* R = lds + wave8 * rsz;                       // this wave's turn-around tile: [3 planes x 2 KB][f32 4 KB]
+    unsigned char* H = lds + 8 * rsz + wave * (NH * 4096);      // hand-off tiles of compute wave `wave`
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the loaders' mask copies have landed; every wave is done with the stage buffers
-    unsigned char* R = lds + wave * 10240;  // [3 planes x 2 KB | f32 4 KB]
+    if (NH > 0) {
+        if (!loader) {
+#pragma unroll
+            for (int i = KEEP; i < NT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *LDS_PTR(f32x4, H + (i - KEEP) * 4096 + g * 1024 + lane16) =
+                        (f32x4){acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     const unsigned wsw = (cl >> 1) & 3;                                      // plane rows: 16-byte slot ^ (row >> 1) & 3
     const unsigned rsw = (lane * 16) ^ ((((unsigned)lane >> 3) & 3) << 4);   // = row (lane >> 2), slot (lane & 3) ^ swizzle
     const unsigned fsw = (lane * 16) ^ ((((unsigned)lane >> 3) & 7) << 4);   // f32 rows: slot (lane & 7) ^ (row & 7)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        if (tpos[i] < 0) continue;  // wave-uniform
+        if (tpos[i] < 0 || loader != (i >= KEEP)) continue;  // wave-uniform
+        f32x16 av;
+        if (i >= KEEP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 x = *LDS_PTR(const f32x4, H + (i >= KEEP ? i - KEEP : 0) * 4096 + g * 1024 + lane16);
+                av[4 * g] = x[0]; av[4 * g + 1] = x[1]; av[4 * g + 2] = x[2]; av[4 * g + 3] = x[3];
+            }
+        } else {
+            av = acc[i];
+        }
         int yh, yw;
         tile_out(tpos[i], yh, yw);
         float val[16];
         if (a.epilogue == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) val[r] = fmaxf(acc[i][r] + bias, 0.f);
+            for (int r = 0; r < 16; ++r) val[r] = fmaxf(av[r] + bias, 0.f);
         } else {
             const unsigned char* M = lds + mask_lds + i * 2048 + cl * 64 + 8 * h;
             float s = 0.f;
@@ -307,10 +334,10 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
                 const u32x2 mk = *LDS_PTR(const u32x2, M + 16 * g);
                 const float m0 = __uint_as_float(mk.x << 16), m1 = __uint_as_float(mk.x & 0xffff0000u);
                 const float m2 = __uint_as_float(mk.y << 16), m3 = __uint_as_float(mk.y & 0xffff0000u);
-                val[4 * g + 0] = m0 > 0.f ? acc[i][4 * g + 0] : 0.f;
-                val[4 * g + 1] = m1 > 0.f ? acc[i][4 * g + 1] : 0.f;
-                val[4 * g + 2] = m2 > 0.f ? acc[i][4 * g + 2] : 0.f;
-                val[4 * g + 3] = m3 > 0.f ? acc[i][4 * g + 3] : 0.f;
+                val[4 * g + 0] = m0 > 0.f ? av[4 * g + 0] : 0.f;
+                val[4 * g + 1] = m1 > 0.f ? av[4 * g + 1] : 0.f;
+                val[4 * g + 2] = m2 > 0.f ? av[4 * g + 2] : 0.f;
+                val[4 * g + 3] = m3 > 0.f ? av[4 * g + 3] : 0.f;
             }
             if (a.pb) {  // sum over the 32 samples, fixed order: registers, then the two half-waves
 #pragma unroll
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
         if (a.out_f32) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *LDS_PTR(f32x4, R + 6144 + cl * 128 + (((2 * g + h) ^ (cl & 7)) * 16)) =
+                *LDS_PTR(f32x4, R + r_f32 + cl * 128 + (((2 * g + h) ^ (cl & 7)) * 16)) =
                     (f32x4){val[4 * g], val[4 * g + 1], val[4 * g + 2], val[4 * g + 3]};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave, LDS is in order: its writes are visible to its reads
@@ -351,7 +378,7 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
             float* F = a.out_f32 + (long)out_slot * a.f32_slot + (((long)yh * a.f32_W + yw) * a.CO + ct * 32) * 32 + lane * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(F + j * 256) = *LDS_PTR(const f32x4, R + 6144 + j * 1024 + fsw);
+                *reinterpret_cast<f32x4*>(F + j * 256) = *LDS_PTR(const f32x4, R + r_f32 + j * 1024 + fsw);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next one overwrites it
     }
@@ -365,12 +392,13 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
 
 template <int NPA, int CT, int NQ, int NT>
 int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, int ring, size_t lds_bytes, hipStream_t q, long long* prof) {
+    const unsigned mask_off = (unsigned)convp_fwd_mask_off(stage_bytes, NT, ring, a.out3 != nullptr, a.out_f32 != nullptr);
     static size_t attr = 0;  // per instantiation
     if (lds_bytes > attr) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cfwd<NPA, CT, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr = lds_bytes;
     }
-    hipLaunchKernelGGL((k_cfwd<NPA, CT, NQ, NT>), dim3((unsigned)n_items), dim3(512), lds_bytes, q, a, (unsigned)stage_bytes, ring, prof);
+    hipLaunchKernelGGL((k_cfwd<NPA, CT, NQ, NT>), dim3((unsigned)n_items), dim3(512), lds_bytes, q, a, (unsigned)stage_bytes, ring, mask_off, prof);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
@@ -405,9 +433,14 @@ int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue, size_t budget) {  /
     if (forced == 2 || forced == 3) return forced;
     return 3 * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0) <= budget ? 3 : 2;
 }
-size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring) {
-    const size_t need = ring * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0);
-    return need < 40960 ? 40960 : need;
+// LDS map: [ring stage buffers | ...] reused by the epilogue as [8 turn-around tiles | hand-off tiles]; the data gradient's
+// mask tiles sit behind whichever of the two is larger
+size_t convp_fwd_mask_off(size_t stage_bytes, int NT, int ring, bool planes_out, bool f32_out) {
+    const size_t rsz = (planes_out ? 6144 : 0) + (f32_out ? 4096 : 0), nh = NT - (NT + 1) / 2;
+    return std::max(ring * stage_bytes, 8 * rsz + 4 * nh * 4096);
+}
+size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring, bool planes_out, bool f32_out) {
+    return convp_fwd_mask_off(stage_bytes, NT, ring, planes_out, f32_out) + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0);
 }
 
 int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, size_t stage_bytes, int ring,

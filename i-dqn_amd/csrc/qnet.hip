@@ -592,7 +592,7 @@ int plan_fwd_target(int role, int n_nets, int nb, const RoleGeom& g, int target,
     IDQN_REQUIRE(pl.NT >= 1 && pl.NT <= nt_max, "plane conv: role %d needs %d tiles per wave", role, pl.NT);
     pl.stage = (size_t)stage_max;
     pl.ring = convp_fwd_ring(pl.stage, pl.NT, role <= 2 ? 0 : 1, budget);
-    pl.lds = convp_fwd_lds(pl.stage, pl.NT, role <= 2 ? 0 : 1, pl.ring);
+    pl.lds = convp_fwd_lds(pl.stage, pl.NT, role <= 2 ? 0 : 1, pl.ring, role != 2, role == 2);
     IDQN_REQUIRE(pl.lds <= budget, "plane conv: role %d needs %zu bytes of LDS", role, pl.lds);
     return IDQN_OK;
 }
