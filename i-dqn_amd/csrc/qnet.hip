@@ -18,6 +18,7 @@
 #include <map>
 #include <tuple>
 
+#include "act_kernels.h"
 #include "cnn_kernels.h"
 #include "fc_kernels.h"
 
@@ -169,6 +170,11 @@ struct idqn_handle_s {
     float* dpart = nullptr;  // partial Dense_0 data gradients of the fused weight-gradient kernel [n_jt][K * nb][F][32]
     float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
+    float *act_a[3] = {nullptr, nullptr, nullptr}, *act_part = nullptr;  // single-state acting path (act_kernels.h)
+    hipStream_t act_stream = nullptr;  // capture stream of the acting graphs
+    uint8_t* act_state = nullptr;     // the state of idqn_act_host on the device
+    int32_t* act_action = nullptr;
+    std::map<std::tuple<int, const void*, void*, void*>, hipGraphExec_t> act_graphs;  // (net, host state, q out, host action)
     const float* infer_pbase = nullptr;  // parameter base of the net the last idqn_q_values call evaluated
     float *infer_hbuf = nullptr, *infer_qpart = nullptr;  // k_hidden outputs of the single inference net
     float* wt[3] = {nullptr, nullptr, nullptr};  // transformed weights of the Conv_1 / Conv_2 data gradients
@@ -348,6 +354,19 @@ int cnn_setup(idqn_handle_s* h) {
     IDQN_HIP_CHECK(hipMemcpy(h->train.wbase, wb.data(), sizeof(float*) * 2 * K, hipMemcpyHostToDevice));
     IDQN_HIP_CHECK(hipMemcpy(h->train.in_set, is.data(), sizeof(int) * 2 * K, hipMemcpyHostToDevice));
     IDQN_HIP_CHECK(hipMemset(h->infer.in_set, 0, sizeof(int)));
+    for (int i = 0; i < 3; ++i) {
+        char nm[12];
+        snprintf(nm, sizeof nm, "act_a%d", i + 1);
+        if ((rc = alloc_zero(&h->act_a[i], (long)h->conv[i].OH * h->conv[i].OW * h->conv[i].CO, h, nm))) return rc;
+    }
+    if ((rc = alloc_zero(&h->act_part, 256L * h->J, h, "act_part"))) return rc;
+    {
+        float* p = nullptr;
+        if ((rc = alloc_zero(&p, ((long)c.obs_h * c.obs_w * c.obs_c + 3) / 4 + 16, h, "act_state"))) return rc;
+        h->act_state = (uint8_t*)p;
+        if ((rc = alloc_zero(&p, 16, h, "act_action"))) return rc;
+        h->act_action = (int32_t*)p;
+    }
     if ((rc = alloc_zero(&h->dh, (long)K * nb * h->J * 32, h, "dh"))) return rc;
     if (h->J % 256 == 0 && (rc = alloc_zero(&h->dpart, (long)(h->J / 256) * K * nb * h->F * 32, h, "dpart"))) return rc;
     if (!h->planes) {
@@ -1159,6 +1178,8 @@ extern "C" int idqn_destroy(idqn_handle_t h) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : h->tl_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& g : h->act_graphs) (void)hipGraphExecDestroy(g.second);
+    if (h->act_stream) (void)hipStreamDestroy(h->act_stream);
     delete h;
     return IDQN_OK;
 }
@@ -1318,6 +1339,39 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_q_values: n = %d, must be in [1, 32]", n);
     hipStream_t q = (hipStream_t)stream;
     const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
+    static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
+    if (h->cfg.arch == IDQN_ARCH_CNN && n == 1 && !act_generic && h->J <= 512 && h->cfg.n_actions <= 32) {
+        // one state: the latency path (act_kernels.h) -- pixels and parameter leaves as they are, five small launches
+        const float* in = nullptr;
+        int ih = h->cfg.obs_h, iw = h->cfg.obs_w;
+        for (int i = 0; i < 3; ++i) {
+            const ConvL& l = h->conv[i];
+            ActConvArgs a;
+            a.in_u8 = i == 0 ? (const uint8_t*)states_dev : nullptr; a.in = in; a.params = params; a.out = h->act_a[i];
+            a.w_off = l.w_off; a.b_off = l.b_off; a.IH = ih; a.IW = iw; a.CI = l.CI; a.OH = l.OH; a.OW = l.OW; a.CO = l.CO;
+            a.K = l.K; a.S = l.S; a.PLh = l.PLh; a.PLw = l.PLw;
+            a.KS = i == 0 ? 8 : 16;  // lane slices: layer 0 has 64 units of 4 channels, the others K*K*CI/32 units of 32
+            const int per = 256 / a.KS;
+            const dim3 grid(cdiv((long)l.OH * l.OW * l.CO, per));
+            const int units = l.K * l.K * (l.CI % 32 == 0 ? l.CI / 32 : l.CI / 4), upt = cdiv(units, a.KS);
+            IDQN_REQUIRE(l.CI % 32 == 0 || (l.CI == 4 && upt <= 8), "acting path: Conv_%d has %d input channels", i, l.CI);
+            if (l.CI % 32 != 0) hipLaunchKernelGGL((k_act_conv<4, 8>), grid, dim3(256), 0, q, a);
+            else if (upt <= 1) hipLaunchKernelGGL((k_act_conv<32, 1>), grid, dim3(256), 0, q, a);
+            else if (upt <= 2) hipLaunchKernelGGL((k_act_conv<32, 2>), grid, dim3(256), 0, q, a);
+            else { IDQN_REQUIRE(upt <= 4, "acting path: %d units per lane slice", upt); hipLaunchKernelGGL((k_act_conv<32, 4>), grid, dim3(256), 0, q, a); }
+            in = h->act_a[i]; ih = l.OH; iw = l.OW;
+        }
+        ActDenseArgs d;
+        d.a3 = h->act_a[2]; d.params = params; d.part = h->act_part; d.w_off = h->off_w0; d.F = h->F; d.J = h->J;
+        d.NRG = std::max(1, 256 / (h->J / 128));  // one workgroup per CU
+        hipLaunchKernelGGL(k_act_dense0, dim3(d.NRG * (h->J / 128)), dim3(256), 0, q, d);
+        ActHeadArgs ha;
+        ha.part = h->act_part; ha.params = params; ha.b0_off = h->off_b0; ha.w1_off = h->off_w1; ha.b1_off = h->off_b1;
+        ha.NP = d.NRG; ha.J = h->J; ha.A = h->cfg.n_actions; ha.q_out = q_out_dev; ha.action = action_out_dev;
+        hipLaunchKernelGGL(k_act_head, dim3(1), dim3(1024), 0, q, ha);
+        IDQN_HIP_CHECK(hipGetLastError());
+        return IDQN_OK;
+    }
     if (h->cfg.arch == IDQN_ARCH_CNN) {
         // the acting net's parameter pointer is entry (which * K + head) of the training table: no pointer upload
         h->infer.wbase = h->train.wbase + (which * h->cfg.n_heads + head);
@@ -1354,6 +1408,53 @@ extern "C" int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, co
                                 float* q_out_dev, int32_t* action_out_dev, void* stream) {
     IDQN_REQUIRE(action_out_dev, "idqn_best_action: null pointer");
     return q_values_impl(h, which, head, states_dev, n, q_out_dev, action_out_dev, stream);
+}
+
+// select_action's greedy branch for ONE state that lives on the host (slimdqn/sample_collection/utils.py:8-21: the
+// reference uploads the state, runs best_action and blocks on `.item()`): upload from pinned memory, the five launches of
+// the single-state path, the action back into pinned memory, one stream synchronisation -- replayed as ONE hipGraph per
+// (net, buffers) after the first call (seven eager API calls cost more host time than the ~35 us of GPU work).
+extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                             int32_t* action_host_pinned, void* stream) {
+    IDQN_REQUIRE(h && state_host_pinned && q_out_dev && action_host_pinned, "idqn_act_host: null pointer");
+    IDQN_REQUIRE(h->cfg.arch == IDQN_ARCH_CNN, "idqn_act_host: the cnn path only (fc states are a few floats: idqn_best_action)");
+    IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_act_host: bad head / which");
+    hipStream_t q = (hipStream_t)stream;
+    const size_t E = (size_t)h->cfg.obs_h * h->cfg.obs_w * h->cfg.obs_c;
+    auto issue = [&](hipStream_t qs) -> int {
+        IDQN_HIP_CHECK(hipMemcpyAsync(h->act_state, state_host_pinned, E, hipMemcpyHostToDevice, qs));
+        int rc = q_values_impl(h, which, head, h->act_state, 1, q_out_dev, h->act_action, (void*)qs);
+        if (rc) return rc;
+        IDQN_HIP_CHECK(hipMemcpyAsync(action_host_pinned, h->act_action, 4, hipMemcpyDeviceToHost, qs));
+        return IDQN_OK;
+    };
+    static const bool use_graph = !(getenv("IDQN_ACT_GRAPH") && atoi(getenv("IDQN_ACT_GRAPH")) == 0);
+    int rc = IDQN_OK;
+    if (use_graph) {
+        auto key = std::make_tuple(which * h->cfg.n_heads + head, state_host_pinned, (void*)q_out_dev, (void*)action_host_pinned);
+        auto it = h->act_graphs.find(key);
+        if (it == h->act_graphs.end()) {
+            // (captured on a stream of the handle's own: the caller's may be the legacy default stream, which cannot
+            // capture; the instantiated graph is then launched on the caller's stream like any other work)
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (!h->act_stream) IDQN_HIP_CHECK(hipStreamCreateWithFlags(&h->act_stream, hipStreamNonBlocking));
+            IDQN_HIP_CHECK(hipStreamBeginCapture(h->act_stream, hipStreamCaptureModeRelaxed));
+            rc = issue(h->act_stream);
+            const hipError_t e = hipStreamEndCapture(h->act_stream, &graph);
+            if (rc) return rc;
+            IDQN_HIP_CHECK(e);
+            IDQN_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            IDQN_HIP_CHECK(hipGraphDestroy(graph));
+            it = h->act_graphs.emplace(key, exec).first;
+        }
+        IDQN_HIP_CHECK(hipGraphLaunch(it->second, q));
+    } else {
+        rc = issue(q);
+        if (rc) return rc;
+    }
+    IDQN_HIP_CHECK(hipStreamSynchronize(q));
+    return IDQN_OK;
 }
 
 extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {

@@ -164,3 +164,14 @@ extern "C" int replay_gather_scalars(const int32_t* action_store_dev, const floa
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
+
+// ReplayBuffer.add's device half (slimdqn/sample_collection/replay_buffer.py:206-213: the reference stores the
+// transition on the host): the newest frame goes from a PINNED host staging slot to its slot of the frame ring in HBM,
+// asynchronously on the caller's stream.  The caller owns the reuse discipline of the staging slots.
+extern "C" int replay_add_frame(void* frame_ring_dev, int64_t slot, int64_t frame_bytes, const void* frame_host_pinned,
+                                void* stream) {
+    IDQN_REQUIRE(frame_ring_dev && frame_host_pinned && slot >= 0 && frame_bytes > 0, "replay_add_frame: bad arguments");
+    IDQN_HIP_CHECK(hipMemcpyAsync((char*)frame_ring_dev + slot * frame_bytes, frame_host_pinned, (size_t)frame_bytes,
+                                  hipMemcpyHostToDevice, (hipStream_t)stream));
+    return IDQN_OK;
+}

@@ -58,6 +58,7 @@ SYMBOLS = {
     "idqn_target_sync": (C.c_int, [_P, _P]),
     "idqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "idqn_best_action": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    "idqn_act_host": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "idqn_debug_buffer": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "idqn_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p]),
     "idqn_profile_table": (C.c_int, [_P, C.c_char_p, C.c_int32]),
@@ -67,6 +68,7 @@ SYMBOLS = {
     "replay_gather_stacked": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P,
                                        _P, _P]),
     "replay_gather": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P]),
+    "replay_add_frame": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "replay_gather_scalars": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
 }
 

@@ -13,6 +13,10 @@ class SyntheticAtari:
         self.rng = np.random.default_rng(seed)
         self.n_actions, self.episode_length = n_actions, episode_length
         self.state_height, self.state_width, self.n_stacked_frames = 84, 84, 4
+        # a pool of random frames: drawing 7056 fresh integers per step cost more host time than the rest of a step
+        self._pool = self.rng.integers(0, 256, (256, 84, 84), dtype=np.uint8)
+        self._rewards = self.rng.integers(-1, 2, 4096).astype(np.float64)
+        self._n = 0
 
     @property
     def observation(self):  # newest frame only; the replay accumulator rebuilds stacks (atari.py:40-41)
@@ -20,14 +24,16 @@ class SyntheticAtari:
 
     def reset(self):
         self.state = np.zeros((84, 84, 4), np.uint8)
-        self.state[:, :, -1] = self.rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        self.state[:, :, -1] = self._pool[self._n % 256]
+        self._n += 1
         self.n_steps = 0
 
     def step(self, action):
-        frame = self.rng.integers(0, 256, (84, 84), dtype=np.uint8)
+        frame = self._pool[self._n % 256]
+        self._n += 1
         self.state = np.concatenate([self.state[:, :, 1:], frame[:, :, None]], axis=2)
         self.n_steps += 1
-        return float(self.rng.integers(-1, 2)), bool(self.n_steps >= self.episode_length)
+        return float(self._rewards[self._n % 4096]), bool(self.n_steps >= self.episode_length)
 
 
 class SyntheticVector:

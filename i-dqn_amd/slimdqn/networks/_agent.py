@@ -24,6 +24,14 @@ def _obs_triplet(observation_dim, arch):
     return (int(np.prod(dims)), 1, 1)
 
 
+class _HostAction(int):
+    """The greedy action as a host integer that still answers ``.item()`` like the device scalar the reference returns
+    (``select_action`` calls ``.item()`` on it, slimdqn/sample_collection/utils.py:21)."""
+
+    def item(self):
+        return int(self)
+
+
 class DeviceAgent:
     def __init__(self, key, observation_dim, n_actions, n_heads, features, architecture_type, learning_rate, gamma,
                  update_horizon, adam_eps, stacked, init_heads=None):
@@ -171,22 +179,25 @@ class DeviceAgent:
         dt = torch.uint8 if self._arch == "cnn" else torch.float32
         if isinstance(state, torch.Tensor) and state.is_cuda:
             s = self._dev(state, dt)
-        else:
-            if not hasattr(self, "_state_pin"):
+        elif self._arch == "cnn":
+            # a host state: ONE C call uploads it from pinned memory, runs the single-state path, brings the action back
+            # and synchronises (what the reference's select_action does with its blocking `.item()`)
+            if not hasattr(self, "_act_pin"):
                 n = int(np.prod(self._obs))
-                self._state_pin = torch.empty(n, dtype=dt).pin_memory()
-                self._state_pin_np = self._state_pin.numpy()
-                self._state_dev = torch.empty(n, dtype=dt, device="cuda")
-                self._state_ev = None
+                self._act_pin = torch.empty(n, dtype=torch.uint8).pin_memory()
+                self._act_pin_np = self._act_pin.numpy()
+                self._act_out = torch.zeros(4, dtype=torch.int32).pin_memory()
+                self._act_out_np = self._act_out.numpy()
             src = np.asarray(getattr(state, "tensor", state))
-            assert src.size == self._state_pin_np.size, "best_action takes a single state"
-            if self._state_ev is not None:
-                self._state_ev.synchronize()  # the previous upload has left the staging buffer
-            self._state_pin_np[:] = src.reshape(-1)  # casts like the array conversion of the reference's jit would
-            self._state_dev.copy_(self._state_pin, non_blocking=True)
-            self._state_ev = torch.cuda.Event()
-            self._state_ev.record()
-            s = self._state_dev
+            assert src.size == self._act_pin_np.size, "best_action takes a single state"
+            self._act_pin_np[:] = src.reshape(-1)  # casts like the array conversion of the reference's jit would
+            self._ensure_handle(32)
+            _hip.check(_hip.lib().idqn_act_host(self._handle, int(which), int(head), C.c_void_p(self._act_pin.data_ptr()),
+                                                _hip.ptr(self._q_out), C.c_void_p(self._act_out.data_ptr()),
+                                                _hip.current_stream()), "idqn_act_host")
+            return _HostAction(int(self._act_out_np[0]))
+        else:
+            s = self._dev(state, dt)  # fc: a handful of floats
         assert s.numel() == int(np.prod(self._obs)), "best_action takes a single state"
         self._ensure_handle(32)
         self._keep_q = s

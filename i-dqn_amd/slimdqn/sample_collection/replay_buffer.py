@@ -167,7 +167,7 @@ class _MemoryView:
 
 
 class ReplayBuffer:
-    STAGING = 32  # pinned host frames in flight towards the ring
+    STAGING = 64  # pinned host frames in flight towards the ring
 
     def __init__(self, sampling_distribution, batch_size: int, max_capacity: int, stack_size: int = 4,
                  update_horizon: int = 1, gamma: float = 0.99, checkpoint_duration: int = 4, compress: bool = True,
@@ -212,7 +212,8 @@ class ReplayBuffer:
         self._reward64 = np.zeros(cap, np.float64)
         self._pin = torch.empty((self.STAGING, self._frame_bytes), dtype=torch.uint8).pin_memory()
         self._pin_np = self._pin.numpy()
-        self._pin_events = [None] * self.STAGING
+        self._pin_events = [None, None]  # one per half of the staging ring
+        self._pin_ptr = self._pin.data_ptr()
 
     def _grow_ring(self, oldest_needed: int) -> None:
         """Doubles the frame ring, keeping frames [oldest_needed, _t) (transition indices) in place modulo the new size."""
@@ -248,14 +249,22 @@ class ReplayBuffer:
             oldest_needed = int(self._first_frame[oldest_key % self._max_capacity])
             if t - oldest_needed >= self._n_frames:  # the slot still holds a frame an alive element needs
                 self._grow_ring(oldest_needed)
-        i = t % self.STAGING
-        if self._pin_events[i] is not None:
-            self._pin_events[i].synchronize()  # that staging slot's previous copy has long finished
+        # one C call (hipMemcpyAsync) per frame; the staging ring is guarded by ONE event per half: before the first slot
+        # of a half is rewritten, the copies of that half's previous round (issued >= STAGING / 2 frames ago) have passed
+        from slimdqn import _hip
+
+        i, half = t % self.STAGING, self.STAGING // 2
+        if i % half == 0:
+            h = i // half
+            if self._pin_events[h] is not None:
+                self._pin_events[h].synchronize()
         self._pin_np[i] = frame.view(np.uint8).reshape(-1)
-        self._frames[t % self._n_frames].copy_(self._pin[i], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pin_events[i] = ev
+        _hip.check(_hip.lib().replay_add_frame(_hip.ptr(self._frames), t % self._n_frames, self._frame_bytes,
+                                               self._pin_ptr + i * self._frame_bytes, _hip.current_stream()), "replay_add_frame")
+        if i % half == half - 1:  # last slot of a half: mark the point the stream has to pass before the half is reused
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pin_events[i // half] = ev
         self._t = t + 1
         return t
 

@@ -140,6 +140,13 @@ int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* stat
 int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
                      float* q_out_dev, int32_t* action_out_dev, void* stream);
 
+/* The greedy branch of select_action for ONE uint8 state in PINNED host memory (slimdqn/sample_collection/utils.py:8-21:
+ * upload, `best_action`, blocking `.item()`): the action of head `head` lands in action_host_pinned[0] and the stream has
+ * been synchronised when the call returns; q_out_dev receives the A Q-values.  cnn only.  After the first call per (net,
+ * buffers) the whole sequence is replayed as one hipGraph (IDQN_ACT_GRAPH=0: eager).                                   */
+int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                  int32_t* action_host_pinned, void* stream);
+
 /* Test / debug access to internal activation buffers by name (device pointer + byte size).        */
 int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes);
 /* Mean duration (ms) and launch count of the dominant kernel over the IDQN_F_PROFILE calls since
@@ -220,6 +227,10 @@ int replay_gather_scalars(const int32_t* action_store_dev, const float* reward_s
                           const uint8_t* terminal_store_dev, const int32_t* slots_dev, int32_t n,
                           int32_t* action_out_dev, float* reward_out_dev, uint8_t* terminal_out_dev,
                           void* stream);
+/* ReplayBuffer.add, device half (replay_buffer.py:206-213 keeps transitions on the host): the newest frame, staged in
+ * PINNED host memory, is copied asynchronously into slot `slot` of the frame ring in HBM.  The staging slot may be
+ * reused once the stream has passed this copy.                                                                        */
+int replay_add_frame(void* frame_ring_dev, int64_t slot, int64_t frame_bytes, const void* frame_host_pinned, void* stream);
 
 #ifdef __cplusplus
 }
