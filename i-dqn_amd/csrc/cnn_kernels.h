@@ -346,27 +346,29 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
     item /= a.NS;
     const int bb = (int)(item % a.nb);
     const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
-    // balanced split-K: the F / 32 row units are dealt as evenly as possible (the first F/32 % NS splits get one more)
-    const int units = a.F / 32, ub = units / a.NS, ur = units - ub * a.NS;
-    const int f0 = 32 * (s * ub + min(s, ur)), f1 = 32 * ((s + 1) * ub + min(s + 1, ur));
-    // lane (bl, h): rows f0 + 16 c + 8 h + jj (jj = 0..7 = the MFMA's k index), W columns jt * 128 + 4 bl .. + 3 (one per
+    // INTERLEAVED split-K: split s takes the 16-row k-steps s, s + NS, s + 2 NS, ...  The NS workgroups of a net then
+    // read one contiguous NS x 32 KB window of the kernel at any time, like a grid-stride copy does (6.1-6.4 TB/s for a
+    // pure read, tools/probes/read_bw_probe.hip); with a contiguous row range per split the chip ran 250 separate
+    // streams, each in its own DRAM pages, and topped out at 3.7-4.1 TB/s.
+    const int NU = a.F / 16, NC = (NU - s + a.NS - 1) / a.NS;  // k-steps of this split (NU >= NS)
+    const long step_rows = 16L * a.NS;
+    // lane (bl, h): rows 16 (s + NS c) + 8 h + jj (jj = 0..7 = the MFMA's k index), W columns jt * 128 + 4 bl .. + 3 (one per
     // tile q), activation column bl
-    const float* W = a.wbase[n] + a.w_off + (long)(f0 + 8 * h) * a.J + jt * 128 + 4 * bl;
-    const float* X = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(f0 + 8 * h) * 32 + bl;
+    const float* W = a.wbase[n] + a.w_off + (long)(16 * s + 8 * h) * a.J + jt * 128 + 4 * bl;
+    const float* X = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(16 * s + 8 * h) * 32 + bl;
     f32x16 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    const int NC = (f1 - f0) / 16;  // splits are whole multiples of 32 rows: an even number of k-steps
     // a ring of four k-steps of W / activation rows per lane (32 KB of loads in flight per wave: with less than one wave
     // per SIMD the kernel was bound by how many bytes it kept in flight, not by HBM or the matrix cores)
     float4 wv[4][8];
     float xv[4][8];
 #define D3_LOAD(c, s)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
-        wv[s][jj] = *reinterpret_cast<const float4*>(W + ((long)(c) * 16 + jj) * a.J);         \
-        xv[s][jj] = X[((long)(c) * 16 + jj) * 32];                                             \
+        wv[s][jj] = *reinterpret_cast<const float4*>(W + ((long)(c) * step_rows + jj) * a.J);         \
+        xv[s][jj] = X[((long)(c) * step_rows + jj) * 32];                                             \
     }
 #define D3_TILE(s, q, comp)                                                                    \
     {                                                                                          \
@@ -387,8 +389,14 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
         const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
         D3_TILE(s, 0, x) D3_TILE(s, 1, y) D3_TILE(s, 2, z) D3_TILE(s, 3, w)                    \
     }
+#ifdef D3_ABLATE  /* timing experiment: loads only (results are wrong) -- same duration: the kernel is bound by how fast
+                     a CU can stream (~10 B/clk at the clock it holds here), not by its split / MFMA work */
+#undef D3_MMA
+#define D3_MMA(s) { _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) acc[0][0] += wv[s][jj].x + wv[s][jj].y + wv[s][jj].z + wv[s][jj].w + xv[s][jj]; }
+#endif
+#define D3_AHEAD 3
 #define D3_STEP(u)                                                                             \
-    D3_LOAD(min(c + (u) + 3, NC - 1), ((u) + 3) & 3)                                           \
+    D3_LOAD(min(c + (u) + D3_AHEAD, NC - 1), ((u) + D3_AHEAD) & 3)                             \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     if (c + (u) < NC) D3_MMA(u)                                                                \
     __builtin_amdgcn_sched_barrier(0);

@@ -21,7 +21,7 @@ for d in glob.glob("gpurun_out/pmc_*/"):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in agg.items():
-    if not (k.startswith("k_") or k.startswith("void k_")):
+    if not (k.startswith("k_") or k.startswith("void k_") or "::k_" in k):
         continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     e = {"launches": max(len(v) for v in c.values()), "counters_mean_per_launch": m}
@@ -34,11 +34,15 @@ for k, c in agg.items():
         e["mfma_util"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m["GRBM_GUI_ACTIVE"] / 8)
     if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
         e["lds_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+    if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
+        e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     out[k] = e
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 dom = [k for k in out if "k_dense0_wgrad<true" in k]
 if dom:
-    json.dump({"kernel": dom[0], "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
+    import subprocess
+    git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    json.dump({"kernel": dom[0], "git": git, "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
                "read": out[dom[0]]["hbm_read_bytes"], "write": out[dom[0]]["hbm_write_bytes"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md)"},
