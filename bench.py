@@ -241,6 +241,8 @@ def main():
         # (factored data-parallel: the factors of all `world` ranks)
         n_blocks = world if dp_mode == "factored" else 1
         per_head = (6 if fused else 1) * P_w0 * 4 + n_blocks * (7744 * 32 * 4 + 512 * 32 * 4)
+        if not dp and os.environ.get("IDQN_NO_FUSE_DGRAD") is None:
+            per_head += 7744 * 32 * 4  # single-device path: the kernel also emits dL/da3 (counted once; it writes two partials)
         alg_bytes = K_HEADS * per_head
         achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
         traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh)

@@ -449,26 +449,14 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
     const long sstride = (long)a.J * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) sv[i] = p[a.b0_off + jc * 32 + jj + 8 * i];
-    int sp = 0;
-    for (; sp + 8 <= a.NS; sp += 8) {
-        float v[8][4];
+    for (int sp = 0; sp < a.NS; sp += 16) {  // 16 splits per round, every load of a round in flight (none past the last split)
+        float v[16][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = pr[(sp + u) * sstride + i * 256];
+            for (int i = 0; i < 4; ++i) v[u][i] = sp + u < a.NS ? pr[(sp + u) * sstride + i * 256] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
-    }
-    if (sp < a.NS) {  // tail of up to 7 splits: all loads issued together (clamped), added in split order
-        float v[7][4];
-#pragma unroll
-        for (int u = 0; u < 7; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = pr[min(sp + u, a.NS - 1) * sstride + i * 256];
-#pragma unroll
-        for (int u = 0; u < 7; ++u)
+        for (int u = 0; u < 16; ++u)
             if (sp + u < a.NS) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
@@ -547,16 +535,15 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             float vo = 0.f, vt = 0.f;
             const float* qo_ = a.qpart + so * NJC * 1024 + e;
             const float* qt_ = a.qpart + st * NJC * 1024 + e;
-            for (int c = 0; c < NJC; c += 8) {  // NJC = J / 32 is a multiple of 4; 8 (or the last 4) partials of each net at once
-                float x[8], y[8];
+            for (int c = 0; c < NJC; c += 16) {  // NJC = J / 32 <= 16: all chunk partials of both nets in one round
+                float x[16], y[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int cc = min(c + u, NJC - 1);
-                    x[u] = qo_[cc * 1024];
-                    y[u] = qt_[cc * 1024];
+                for (int u = 0; u < 16; ++u) {
+                    x[u] = c + u < NJC ? qo_[(c + u) * 1024] : 0.f;
+                    y[u] = c + u < NJC ? qt_[(c + u) * 1024] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 16; ++u)
                     if (c + u < NJC) { vo += x[u]; vt += y[u]; }
             }
             vo += po[a.b1_off + ac];
