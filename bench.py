@@ -159,7 +159,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or args.force_dp or args.heads_per_gpu:
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        # the GPU boxes export NCCL_DEBUG=VERSION, so setdefault would never take: rank 0 logs RCCL's topology / algorithm
+        # choice (stderr only; the JSON line goes to stdout), IDQN_NCCL_DEBUG overrides
+        os.environ["NCCL_DEBUG"] = os.environ.get("IDQN_NCCL_DEBUG", "INFO" if rank == 0 else "WARN")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
         assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -3,15 +3,16 @@
 //   data gradient  jax.value_and_grad, idqn.py:105: a stride-1 convolution over the zero-bordered dout planes with the
 //                  re-indexed kernel (packed by k_stage), one variant per output parity; ReLU mask of the layer below
 //
-// Work decomposition: a workgroup (4 waves, one per SIMD, ONE workgroup per CU) owns `np` consecutive output positions of
-// one (net, batch block) for all CO channels: np * CT tiles of 32 samples x 32 channels, dealt round-robin to the waves
-// (<= NT each).  The host sizes the items so that one launch is (about) one workgroup per CU with equal work.
-// K loop: a superstep = one kernel row kh and one 16-channel chunk.  Per superstep the workgroup stages by LDS-DMA
+// Work decomposition: a workgroup (512 threads, ONE per CU: waves 0-3 compute, one per SIMD; waves 4-7 only issue the
+// LDS-DMA copies) owns `np` consecutive output positions of one (net, batch block) for all CO channels: np * CT tiles of
+// 32 samples x 32 channels, dealt round-robin to the compute waves (<= NT each).  The host sizes the items so that one
+// launch is at most one workgroup per CU with equal work.
+// K loop: a superstep = one kernel row kh and one 16-channel chunk.  Per superstep the loader waves stage
 //   * the NQ taps x CT tiles x 3 planes of packed weights (one contiguous run), and
 //   * for every input row its positions touch, the STRIP of pixel chunks they read -- neighbouring output positions
-//     share pixels (3x3 stride 1: each staged chunk serves 3 taps), which is what keeps the L2 -> LDS traffic per MFMA
-//     low enough (~25 B/clk/CU) for the matrix cores to be the limit;
-// double-buffered, one s_barrier per superstep, then NQ x NT tile-steps of 6 (Conv_0: 3) MFMAs from LDS fragments.
+//     share pixels (3x3 stride 1: each staged chunk serves 3 taps), which keeps the L2 -> LDS traffic per MFMA low;
+// into a ring of 2-3 stage buffers, two supersteps ahead (counted s_waitcnt vmcnt + one s_barrier per superstep), while
+// the compute waves run NQ x NT tile-steps of 6 (Conv_0: 3) MFMAs from LDS fragments.
 // Orientation: A = activations (rows = samples), B = weights (columns = channels), so a lane ends up with 4 x 4
 // consecutive samples of ONE channel: plane rows are written as 8-byte pieces, the bias / mask is one value per lane.
 #include <algorithm>
