@@ -59,6 +59,7 @@ struct CFwdArgs {
     // r_cnt[v] balanced ranges of its OH * OW positions, the ranges of variant v start at r_begin[v]
     int items_per_slot, r_begin[4], r_cnt[4];
     int in_split;   // input slot of net n: (in_split > 0 ? n >= in_split : n) * nb + bb
+    int range_major;  // 1: consecutive workgroups walk the nets of one position range (nets share the input: Conv_0)
     int nb, n_var, epilogue;
     int KH, NCC, S, SX, CO;           // NCC = 16-channel chunks per tap (1 for Conv_0); SX = pixel chunks per output step
     int pix_bytes, plane_bytes, xstep, row_bytes;  // input geometry in bytes (xstep: between consecutive pixel chunks)

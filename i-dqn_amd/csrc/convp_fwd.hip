@@ -60,7 +60,18 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
     int vi = 0;
     {
         const int b = xcd_contiguous_id();
-        const int slot = b / a.items_per_slot, rr = b - slot * a.items_per_slot;
+        // net-major by default: an XCD walks consecutive ranges of one net and shares its packed kernels through L2.
+        // Range-major where the nets read the SAME input (Conv_0: K nets per staged minibatch): an XCD then holds a few
+        // position ranges of every net, so a pixel strip crosses the fabric once per XCD instead of once per net.
+        int slot, rr;
+        if (a.range_major) {
+            const int n_slots = (int)gridDim.x / a.items_per_slot;
+            rr = b / n_slots;
+            slot = b - rr * n_slots;
+        } else {
+            slot = b / a.items_per_slot;
+            rr = b - slot * a.items_per_slot;
+        }
 #pragma unroll
         for (int i = 1; i < 4; ++i)
             if (i < a.n_var && rr >= a.r_begin[i]) vi = i;

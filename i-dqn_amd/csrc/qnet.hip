@@ -633,6 +633,10 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     }
     if (rc) rc = plan_fwd_target(role, n_nets, nb, g, forced && forced <= 256 ? forced : 256, 160 * 1024, pl);
     if (rc) return rc;
+    if (getenv("IDQN_PLAN_PRINT"))
+        fprintf(stderr, "[plan] fwd role %d nets %d nb %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
+                "ranges/slot %d (NPA %d CT %d NQ %d)\n", role, n_nets, nb, pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds,
+                g.KH * g.NCC, pl.items_per_slot, g.NPA, g.CT, g.NQ);
     *out = &(h->fwd_plans[key] = pl);
     return IDQN_OK;
 }
@@ -654,23 +658,32 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out) {
         if (layer == 0) --pl.PG;  // Conv_0: 4 or 2 positions
     }
     IDQN_REQUIRE(pl.lds + 2048 <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
+    // item order = workgroup order (the XCD-contiguous remap gives an XCD consecutive items): head-major, so that the kernel
+    // rows of one chunk share its x / dy strips through L2; Conv_0 chunk-major, because its K heads read the SAME staged
+    // minibatch and a pixel strip then crosses the fabric once per XCD instead of once per head
     std::vector<CWItem> items;
-    for (int k = 0; k < K; ++k)
-        for (int c = 0, p0 = 0; c < nch; ++c) {
-            const int cnt = npos / nch + (c < npos % nch ? 1 : 0);
+    static const bool net_major = getenv("IDQN_NET_MAJOR") != nullptr;  // A/B switch
+    const bool chunk_major = layer == 0 && !net_major;
+    std::vector<int> p0s(nch + 1, 0);
+    for (int c = 0; c < nch; ++c) p0s[c + 1] = p0s[c] + npos / nch + (c < npos % nch ? 1 : 0);
+    for (int o = 0; o < (chunk_major ? nch : K); ++o)
+        for (int i = 0; i < (chunk_major ? K : nch); ++i) {
+            const int k = chunk_major ? i : o, c = chunk_major ? o : i;
             for (int kh = 0; kh < (layer == 0 ? 1 : l.K); ++kh) {
                 CWItem it;
                 memset(&it, 0, sizeof(it));
-                it.net = k; it.kh = kh; it.chunk = c; it.p0 = p0; it.np = cnt;
+                it.net = k; it.kh = kh; it.chunk = c; it.p0 = p0s[c]; it.np = p0s[c + 1] - p0s[c];
                 items.push_back(it);
             }
-            p0 += cnt;
         }
     pl.n_items = (int)items.size();
     IDQN_HIP_CHECK(hipMalloc((void**)&pl.dev, sizeof(CWItem) * items.size()));
     h->owned.push_back((void*)pl.dev);
     IDQN_HIP_CHECK(hipMemcpy(pl.dev, items.data(), sizeof(CWItem) * items.size(), hipMemcpyHostToDevice));
     (void)nb;
+    if (getenv("IDQN_PLAN_PRINT"))
+        fprintf(stderr, "[plan] wgrad layer %d: %d workgroups, %d chunks of ~%d positions, PG %d, MT %d, lds %zu B\n", layer,
+                pl.n_items, nch, npos / nch, pl.PG, pl.MT, pl.lds);
     *out = &(h->wgrad_plans[key] = pl);
     return IDQN_OK;
 }
@@ -751,6 +764,8 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
         gin = gi[role]; gout = go[role];
         a.in = ins[role]; a.out3 = outs[role]; a.epilogue = 0; a.b_off = l.b_off; a.CO = l.CO;
         a.in_split = role == 0 ? (s.n_in_sets > 1 ? s.n_nets / 2 : s.n_nets + 1) : 0;
+        static const bool net_major = getenv("IDQN_NET_MAJOR") != nullptr;  // A/B switch
+        a.range_major = role == 0 && !net_major;
         if (role == 2) { a.out_f32 = s.a3; a.f32_slot = h->ga3.block; a.f32_W = l.OW; }
         a.pix_bytes = g.NPA * l.CI * 64; a.plane_bytes = l.CI * 64;
         a.xstep = role == 0 ? 1024 : a.pix_bytes;

@@ -175,3 +175,34 @@ extern "C" int replay_add_frame(void* frame_ring_dev, int64_t slot, int64_t fram
                                   hipMemcpyHostToDevice, (hipStream_t)stream));
     return IDQN_OK;
 }
+
+// Growing the frame ring (rare: element-less transitions used up the slack): the live frames, transition indices
+// [first_t, first_t + count), move from slot t % old_n of the old ring to slot t % new_n of the new one.
+__global__ __launch_bounds__(256) void k_ring_regrow(const uint8_t* __restrict__ old_ring, long old_n,
+                                                     uint8_t* __restrict__ new_ring, long new_n, long first_t,
+                                                     long frame_bytes) {
+    const long t = first_t + blockIdx.x;
+    const uint8_t* src = old_ring + (t % old_n) * frame_bytes;
+    uint8_t* dst = new_ring + (t % new_n) * frame_bytes;
+    if ((frame_bytes & 15) == 0 && (((uintptr_t)old_ring | (uintptr_t)new_ring) & 15) == 0) {
+        for (long i = threadIdx.x; i < frame_bytes / 16; i += 256)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    } else {
+        for (long i = threadIdx.x; i < frame_bytes; i += 256) dst[i] = src[i];
+    }
+}
+
+extern "C" int replay_ring_regrow(const void* old_ring_dev, int64_t old_n, void* new_ring_dev, int64_t new_n,
+                                  int64_t first_t, int64_t count, int64_t frame_bytes, void* stream) {
+    IDQN_REQUIRE(old_ring_dev && new_ring_dev && old_ring_dev != new_ring_dev, "replay_ring_regrow: two distinct rings required");
+    IDQN_REQUIRE(old_n >= 1 && new_n >= old_n && first_t >= 0 && count >= 0 && count <= old_n && frame_bytes >= 1,
+                 "replay_ring_regrow: old_n = %ld, new_n = %ld, first_t = %ld, count = %ld, frame_bytes = %ld", (long)old_n,
+                 (long)new_n, (long)first_t, (long)count, (long)frame_bytes);
+    for (int64_t done = 0; done < count; done += 1 << 30) {  // grid.x limit; one launch in practice
+        const int64_t n = std::min<int64_t>(count - done, 1 << 30);
+        hipLaunchKernelGGL(k_ring_regrow, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)old_ring_dev,
+                           (long)old_n, (uint8_t*)new_ring_dev, (long)new_n, (long)(first_t + done), (long)frame_bytes);
+        IDQN_HIP_CHECK(hipGetLastError());
+    }
+    return IDQN_OK;
+}

@@ -69,6 +69,7 @@ SYMBOLS = {
                                        _P, _P]),
     "replay_gather": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P]),
     "replay_add_frame": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "replay_ring_regrow": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P]),
     "replay_gather_scalars": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
 }
 

@@ -219,19 +219,21 @@ class ReplayBuffer:
         """Doubles the frame ring, keeping frames [oldest_needed, _t) (transition indices) in place modulo the new size."""
         import torch
 
-        new_n = 2 * self._n_frames
+        from slimdqn import _hip
+
+        old_n, new_n = self._n_frames, 2 * self._n_frames
         new = torch.empty((new_n, self._frame_bytes), dtype=torch.uint8, device="cuda")
-        live = torch.arange(oldest_needed, self._t, dtype=torch.int64, device="cuda")
-        if live.numel():
-            new[live % new_n] = self._frames[live % self._n_frames]
-        # frame slots are stored in the element rows: re-derive them for the alive elements
-        for key in self._memory.keys():
-            slot = key % self._max_capacity
-            first_s = int(self._first_frame[slot])
-            newest_s = first_s + int(self._meta[slot, 1]) - 1
-            horizon = (int(self._meta[slot, 2]) - int(self._meta[slot, 0])) % self._n_frames
-            self._meta[slot, 0] = newest_s % new_n
-            self._meta[slot, 2] = (newest_s + horizon) % new_n
+        _hip.check(_hip.lib().replay_ring_regrow(_hip.ptr(self._frames), old_n, _hip.ptr(new), new_n, oldest_needed,
+                                                 self._t - oldest_needed, self._frame_bytes, _hip.current_stream()),
+                   "replay_ring_regrow")
+        # frame slots are stored in the element rows: re-derive them for the alive elements (all at once)
+        keys = np.arange(max(0, self.add_count - self._max_capacity), self.add_count, dtype=np.int64)
+        if keys.size:
+            slots = keys % self._max_capacity
+            newest_s = self._first_frame[slots] + self._meta[slots, 1] - 1
+            horizon = (self._meta[slots, 2].astype(np.int64) - self._meta[slots, 0]) % old_n
+            self._meta[slots, 0] = newest_s % new_n
+            self._meta[slots, 2] = (newest_s + horizon) % new_n
         self._frames, self._n_frames = new, new_n
         self._flushed = max(0, self.add_count - self._max_capacity)  # every alive row goes to the device again
 

@@ -231,6 +231,11 @@ int replay_gather_scalars(const int32_t* action_store_dev, const float* reward_s
  * PINNED host memory, is copied asynchronously into slot `slot` of the frame ring in HBM.  The staging slot may be
  * reused once the stream has passed this copy.                                                                        */
 int replay_add_frame(void* frame_ring_dev, int64_t slot, int64_t frame_bytes, const void* frame_host_pinned, void* stream);
+/* Growth of the frame ring (no reference counterpart: the reference's host dict grows by itself,
+ * replay_buffer.py:206-213): the live frames, transition indices [first_t, first_t + count), are copied from slot
+ * t % old_n of the old ring to slot t % new_n of the new one (count <= old_n <= new_n, distinct buffers).             */
+int replay_ring_regrow(const void* old_ring_dev, int64_t old_n, void* new_ring_dev, int64_t new_n, int64_t first_t,
+                       int64_t count, int64_t frame_bytes, void* stream);
 
 #ifdef __cplusplus
 }

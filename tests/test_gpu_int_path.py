@@ -171,7 +171,8 @@ def test_frame_ring_buffer_equals_the_reference_elements(shape, dtype, stack, n,
         assert got.is_terminal == want.is_terminal and got.episode_end == want.episode_end
 
 
-def test_frame_ring_grows_when_elementless_transitions_pile_up():
+@pytest.mark.parametrize("frame", [(6, 6), (8, 8)])  # 36-byte frames (byte copies) and 64-byte frames (16-byte copies)
+def test_frame_ring_grows_when_elementless_transitions_pile_up(frame):
     """Episodes shorter than the horizon that are truncated make no elements, so alive elements can refer to frames
     arbitrarily many transitions back; the ring must grow rather than overwrite them."""
     from oracle.replay_ref import ReplayRef, Transition as TRef
@@ -191,7 +192,7 @@ def test_frame_ring_grows_when_elementless_transitions_pile_up():
 
     n0 = None
     for i in range(1300):
-        obs, act, rew, term, trunc = _stream(rng, i, (6, 6), np.uint8, pattern)
+        obs, act, rew, term, trunc = _stream(rng, i, frame, np.uint8, pattern)
         a.add(Transition(obs, act, rew, term, trunc))
         b.add(TRef(obs, act, rew, term, trunc))
         n0 = n0 or a._n_frames
