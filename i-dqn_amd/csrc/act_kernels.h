@@ -127,6 +127,11 @@ struct ActHeadArgs {
     int NP, J, A;
     float* q_out;       // [A]
     int32_t* action;    // [1] or nullptr
+    // host mailbox (idqn_act_host) or nullptr: {action, sequence number} in mapped, coherent host memory.  The kernel
+    // bumps the device-side counter and writes the action, then the number; the host polls the number instead of paying
+    // for a device-to-host copy node and a stream synchronisation.
+    volatile int32_t* mail;
+    unsigned* seq;
 };
 // one workgroup of 1024: h = relu(b0 + sum of the partials), q = b1 + h W1, first maximum (jnp.argmax).  The NP = F / 32
 // partial rows are summed by 4 row groups x 256 column pairs (float2, 32 loads in flight), groups combined in order.
@@ -174,5 +179,12 @@ __global__ __launch_bounds__(1024) void k_act_head(ActHeadArgs a) {
         for (int ac = 1; ac < a.A; ++ac)
             if (qs[ac] > bv) { bv = qs[ac]; best = ac; }
         a.action[0] = best;
+        if (a.mail) {
+            const unsigned n = a.seq[0] + 1u;
+            a.seq[0] = n;
+            a.mail[0] = best;
+            __threadfence_system();  // the action is visible to the host before the number that announces it
+            a.mail[1] = (int32_t)n;
+        }
     }
 }

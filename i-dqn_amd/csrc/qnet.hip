@@ -174,6 +174,14 @@ struct idqn_handle_s {
     hipStream_t act_stream = nullptr;  // capture stream of the acting graphs
     uint8_t* act_state = nullptr;     // the state of idqn_act_host on the device
     int32_t* act_action = nullptr;
+    int32_t* act_mail = nullptr;      // host mailbox {action, sequence} (hipHostMalloc, mapped + coherent) of idqn_act_host
+    int32_t* act_mail_dev = nullptr;  // its device address
+    unsigned* act_seq = nullptr;      // device-side sequence counter
+    unsigned act_expected = 0;        // sequence number the next idqn_act_host call waits for
+    bool act_use_mail = false;        // set while idqn_act_host issues / captures its launches
+    // IDQN_STEP_GRAPH=1: the plain cnn step replayed as a hipGraph per (batch buffers, size); value = calls seen, graph
+    std::map<std::tuple<const void*, const void*, const void*, const void*, const void*, int, int, const void*, const void*>,
+             std::pair<int, hipGraphExec_t>> step_graphs;
     std::map<std::tuple<int, const void*, void*, void*>, hipGraphExec_t> act_graphs;  // (net, host state, q out, host action)
     const float* infer_pbase = nullptr;  // parameter base of the net the last idqn_q_values call evaluated
     float *infer_hbuf = nullptr, *infer_qpart = nullptr;  // k_hidden outputs of the single inference net
@@ -184,8 +192,9 @@ struct idqn_handle_s {
     unsigned short *da3p = nullptr, *da2p = nullptr, *da1p = nullptr;
     float* pbuf[3] = {nullptr, nullptr, nullptr};  // [K * nb][OH * OW][CO] of conv layer i
     long wq_stride = 0, wq_fwd[3] = {0, 0, 0}, wq_dg[3] = {0, 0, 0};  // bytes
-    std::map<std::tuple<int, int, int>, FwdPlan> fwd_plans;   // (role, n_nets, nb)
-    std::map<std::tuple<int, int>, WgradPlan> wgrad_plans;    // (layer, nb)
+    std::map<std::tuple<int, int, int, int>, FwdPlan> fwd_plans;  // (role, n_nets, nb, target workgroups)
+    std::map<std::tuple<int, int, int>, WgradPlan> wgrad_plans;   // (layer, nb, position chunks)
+    int npc_used[3] = {0, 0, 0};  // position chunks (= slabs per head) the weight-gradient launches of THIS step wrote
     float* cprof = nullptr;  // debug (IDQN_CONV_PROF=role): phase stamps of one plane conv launch
     int cprof_role = -1;
     int npc[3], pos_per_chunk[3];
@@ -416,6 +425,7 @@ int cnn_setup(idqn_handle_s* h) {
             const int per_chunk = K * (i == 0 ? 1 : cl.K);
             int nch = 256 / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
             if (const char* e = getenv("IDQN_WCHUNKS")) nch = atoi(e);
+            if (const char* e = getenv("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
             h->npc[i] = std::max(1, std::min(nch, npos));
         }
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
@@ -620,33 +630,34 @@ int plan_fwd_target(int role, int n_nets, int nb, const RoleGeom& g, int target,
 // workgroups per CU instead (80 KB of LDS each), so that one's prologue / first fill / epilogue overlaps the other's main
 // loop -- measured: Conv_0 forward 18.8 -> 18.5 us, Conv_1 data gradient 16.9 -> 21.7 us (more weight re-staging per
 // MFMA, a two-deep ring); not the default.
-int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
-    auto key = std::make_tuple(role, n_nets, nb);
+int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out, int target = 256) {
+    auto key = std::make_tuple(role, n_nets, nb, target);
     auto itp = h->fwd_plans.find(key);
     if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
     static const int forced = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 0;
     FwdPlan pl;
     int rc = IDQN_E_INVALID;
-    if (forced > 256) {
-        rc = plan_fwd_target(role, n_nets, nb, g, forced ? forced : 512, 80 * 1024, pl);
+    if (forced > 256 && target == 256) {
+        rc = plan_fwd_target(role & 7, n_nets, nb, g, forced ? forced : 512, 80 * 1024, pl);
         if (!rc && pl.NT < 2 && !forced) rc = IDQN_E_INVALID;  // items too small to be worth two per CU
     }
-    if (rc) rc = plan_fwd_target(role, n_nets, nb, g, forced && forced <= 256 ? forced : 256, 160 * 1024, pl);
+    if (rc) rc = plan_fwd_target(role & 7, n_nets, nb, g, target != 256 ? target : (forced && forced <= 256 ? forced : 256), 160 * 1024, pl);
     if (rc) return rc;
     if (getenv("IDQN_PLAN_PRINT"))
-        fprintf(stderr, "[plan] fwd role %d nets %d nb %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
-                "ranges/slot %d (NPA %d CT %d NQ %d)\n", role, n_nets, nb, pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds,
+        fprintf(stderr, "[plan] fwd role %d nets %d nb %d target %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
+                "ranges/slot %d (NPA %d CT %d NQ %d)\n", role, n_nets, nb, target, pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds,
                 g.KH * g.NCC, pl.items_per_slot, g.NPA, g.CT, g.NQ);
     *out = &(h->fwd_plans[key] = pl);
     return IDQN_OK;
 }
 
-int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out) {
-    auto key = std::make_tuple(layer, nb);
+int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunks = 0) {
+    if (n_chunks <= 0) n_chunks = h->npc[layer];
+    auto key = std::make_tuple(layer, nb, n_chunks);
     auto itp = h->wgrad_plans.find(key);
     if (itp != h->wgrad_plans.end()) { *out = &itp->second; return IDQN_OK; }
     const ConvL& l = h->conv[layer];
-    const int K = h->cfg.n_heads, npos = l.OH * l.OW, nch = h->npc[layer];
+    const int K = h->cfg.n_heads, npos = l.OH * l.OW, nch = std::min(n_chunks, std::min(h->npc[layer], npos));  // (the slab region holds npc chunks)
     WgradPlan pl;
     pl.n_chunks = nch;
     pl.MT = layer == 0 ? l.K : l.K * l.CI / 32;
@@ -735,15 +746,13 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
 }
 
 // one plane conv launch: role 0..2 forward of Conv_0..2 for net set s, 3 / 4 data gradient of Conv_2 / Conv_1
-int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
-    RoleGeom g;
+// launch arguments + plan of a forward / data-gradient role, planned for about `target` workgroups
+int conv_args(idqn_handle_s* h, NetSet& s, int role, int nb, int target, CFwdArgs& a, RoleGeom& g, FwdPlan*& pl) {
     int rc = role_geom(h, role, g);
     if (rc) return rc;
     const bool fwd = role <= 2;
     const int n_nets = fwd ? s.n_nets : h->cfg.n_heads;
-    FwdPlan* pl;
-    if ((rc = plan_fwd(h, role + (fwd && &s == &h->infer ? 8 : 0), n_nets, nb, g, &pl))) return rc;
-    CFwdArgs a;
+    if ((rc = plan_fwd(h, role + (fwd && &s == &h->infer ? 8 : 0), n_nets, nb, g, &pl, target))) return rc;
     memset(&a, 0, sizeof(a));
     a.wq = s.wq;
     a.items_per_slot = pl->items_per_slot;
@@ -787,21 +796,32 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     a.row_bytes = gin->Wp * a.pix_bytes;
     a.out_slot = gout->block * 6; a.out_Wp = gout->Wp; a.out_lo_h = gout->lo_h; a.out_lo_w = gout->lo_w;
     a.out_W = gout->W; a.out_H = gout->H;
-    long long* prof = (h->cprof && h->cprof_role == role && &s == &h->train && pl->n_items <= 4096) ? (long long*)h->cprof : nullptr;
-    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->ring, pl->lds, q, prof);
+    return IDQN_OK;
 }
 
-int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
+long long* conv_prof(idqn_handle_s* h, NetSet& s, int role, const FwdPlan* pl) {
+    return (h->cprof && h->cprof_role == role && &s == &h->train && pl->n_items <= 4096) ? (long long*)h->cprof : nullptr;
+}
+
+int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
+    CFwdArgs a;
+    RoleGeom g;
+    FwdPlan* pl;
+    int rc = conv_args(h, s, role, nb, 256, a, g, pl);
+    if (rc) return rc;
+    return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->ring, pl->lds, q, conv_prof(h, s, role, pl));
+}
+
+// launch arguments + plan of a weight-gradient layer cut into n_chunks position chunks (0: the layer's default)
+int wgrad_args(idqn_handle_s* h, int layer, int nb, int n_chunks, CWgradArgs& a, WgradPlan*& pl) {
     NetSet& s = h->train;
     const ConvL& l = h->conv[layer];
-    WgradPlan* pl;
-    int rc = plan_wgrad(h, layer, nb, &pl);
+    int rc = plan_wgrad(h, layer, nb, &pl, n_chunks);
     if (rc) return rc;
     const unsigned short* xs[3] = {s.x1, s.a1p, s.a2p};
     const unsigned short* dys[3] = {h->da1p, h->da2p, h->da3p};
     const ActGeom* gx[3] = {&h->gx, &h->ga1, &h->ga2};
     const ActGeom* gd[3] = {&h->gda1, &h->gda2, &h->gda3};
-    CWgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = xs[layer]; a.dy = dys[layer]; a.pb = h->pbuf[layer]; a.items = pl->dev; a.slab = h->slab + h->slab_off[layer];
     const int npx = layer == 0 ? 1 : 3;
@@ -811,7 +831,52 @@ int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
     a.x_pix = npx * l.CI * 64; a.x_plane = l.CI * 64; a.x_row = gx[layer]->Wp * a.x_pix;
     a.dy_pix = 3 * l.CO * 64; a.dy_Wp = gd[layer]->Wp; a.dy_lo_h = gd[layer]->lo_h; a.dy_lo_w = gd[layer]->lo_w;
     a.PG = pl->PG; a.out_div = layer == 0 ? 255.0f : 1.0f;
-    return convp_launch_wgrad(a, npx, pl->MT, l.CO / 32, pl->n_items, pl->lds, q);
+    return IDQN_OK;
+}
+
+int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
+    CWgradArgs a;
+    WgradPlan* pl;
+    int rc = wgrad_args(h, layer, nb, 0, a, pl);
+    if (rc) return rc;
+    h->npc_used[layer] = pl->n_chunks;
+    return convp_launch_wgrad(a, layer == 0 ? 1 : 3, pl->MT, h->conv[layer].CO / 32, pl->n_items, pl->lds, q);
+}
+
+// Data gradient of conv `layer` and weight gradient of the same layer in ONE launch (convp_pair.hip) when that pair of
+// kernels is built for the plans; *done = false: nothing was launched, the caller runs them one after the other.
+int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) {
+    *done = false;
+    static const bool no_pair = getenv("IDQN_NO_PAIR") != nullptr;  // A/B switch
+    if (no_pair || layer < 1 || layer > 2) return IDQN_OK;
+    // experiment knobs: IDQN_PAIR_D<layer> = workgroups planned for the data gradient, IDQN_PAIR_C<layer> = position chunks
+    // of the weight gradient (default: what the data gradient leaves of the 256 CUs)
+    auto knob = [&](const char* stem, int dflt) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "%s%d", stem, layer);
+        const char* e = getenv(nm);
+        return e ? atoi(e) : dflt;
+    };
+    const int d_target = knob("IDQN_PAIR_D", 128);
+    NetSet& s = h->train;
+    const int role = layer == 2 ? 3 : 4, K = h->cfg.n_heads;
+    const ConvL& l = h->conv[layer];
+    CFwdArgs f;
+    RoleGeom g;
+    FwdPlan* pf;
+    int rc = conv_args(h, s, role, nb, d_target, f, g, pf);
+    if (rc) return rc;
+    const int n_chunks = std::min(knob("IDQN_PAIR_C", 1 << 20), (256 - pf->n_items) / (K * l.K));  // what is left of the chip, in whole position chunks
+    if (n_chunks < 1) return IDQN_OK;
+    CWgradArgs w;
+    WgradPlan* pw;
+    if ((rc = wgrad_args(h, layer, nb, n_chunks, w, pw))) return rc;
+    const int WCT = l.CO / 32, ntw = (pw->MT * WCT + 3) / 4;
+    if (pf->n_items + pw->n_items > 256 || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
+    h->npc_used[layer] = pw->n_chunks;
+    *done = true;
+    return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT, pw->n_items,
+                             pw->lds, q, conv_prof(h, s, role, pf));
 }
 
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
@@ -971,11 +1036,18 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1];
         h->ev_used += 2;
     }
-    if (fuse_adam && nq == 2 && fuse_dg) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2, true>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-    else if (fuse_adam && nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-    else if (fuse_adam) hipExtLaunchKernelGGL((k_dense0_wgrad<true, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-    else if (nq == 2) hipExtLaunchKernelGGL((k_dense0_wgrad<false, 2>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-    else hipExtLaunchKernelGGL((k_dense0_wgrad<false, 1>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+    // (the extended launch only when there is something to time: it is not a capturable node of a step graph)
+#define D0W_LAUNCH(...)                                                                                   \
+    do {                                                                                                  \
+        if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, e0, e1, 0, dw); \
+        else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, dw);               \
+    } while (0)
+    if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
+    else if (fuse_adam) D0W_LAUNCH(true, 1);
+    else if (nq == 2) D0W_LAUNCH(false, 2);
+    else D0W_LAUNCH(false, 1);
+#undef D0W_LAUNCH
     tl_mark(h, q, fuse_dg ? "dense0 wgrad + dgrad + adam" : fuse_adam ? "dense0 wgrad + adam" : "dense0 wgrad");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
@@ -1070,12 +1142,19 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     long nblk = 0;
     if (h->planes) {
         // data gradients (stride-1 convolutions over the zero-bordered dout planes), then the weight gradients
+        // per layer, top down: its data gradient and its weight gradient read the same dy and are independent of each other --
+        // one launch for both where that pair of kernels is built (planes_pair), else one after the other
+        static const char* nd[3] = {"", "conv1 dgrad", "conv2 dgrad"};
         static const char* nw[3] = {"conv0 wgrad", "conv1 wgrad", "conv2 wgrad"};
-        int rc = planes_conv(h, s, 3, nb, q);
-        tl_mark(h, q, "conv2 dgrad");
-        if (!rc) rc = planes_conv(h, s, 4, nb, q);
-        tl_mark(h, q, "conv1 dgrad");
-        for (int i = 2; i >= 0 && !rc; --i) { rc = planes_wgrad(h, i, nb, q); tl_mark(h, q, nw[i]); }
+        static const char* np[3] = {"", "conv1 dgrad + wgrad", "conv2 dgrad + wgrad"};
+        int rc = IDQN_OK;
+        for (int i = 2; i >= 0 && !rc; --i) {
+            bool paired = false;
+            if (i >= 1) rc = planes_pair(h, i, nb, q, &paired);
+            if (paired) { tl_mark(h, q, np[i]); continue; }
+            if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
+            if (!rc) { rc = planes_wgrad(h, i, nb, q); tl_mark(h, q, nw[i]); }
+        }
         if (rc) return rc;
     } else {
         // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
@@ -1106,7 +1185,7 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
         }
         SlabSeg& g = r.seg[2 - i];
         g.slab = h->slab + h->slab_off[i]; g.slab_stride = h->slab_stride[i]; g.w_off = l.w_off; g.b_off = l.b_off;
-        g.wsize = (long)l.K * l.K * l.CI * l.CO; g.npc = h->npc[i]; g.bsize = l.CO;
+        g.wsize = (long)l.K * l.K * l.CI * l.CO; g.npc = h->planes ? h->npc_used[i] : h->npc[i]; g.bsize = l.CO;
         g.first_block = nblk;
         nblk += cdiv(g.wsize + g.bsize, 256);
     }
@@ -1194,7 +1273,10 @@ extern "C" int idqn_destroy(idqn_handle_t h) {
     for (auto& e : h->tl_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& g : h->act_graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : h->step_graphs)
+        if (g.second.second) (void)hipGraphExecDestroy(g.second.second);
     if (h->act_stream) (void)hipStreamDestroy(h->act_stream);
+    if (h->act_mail) (void)hipHostFree(h->act_mail);
     delete h;
     return IDQN_OK;
 }
@@ -1219,14 +1301,43 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
     tl_mark(h, q, nullptr);
     int rc;
     if (h->cfg.arch == IDQN_ARCH_CNN) {
-        if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q))) return rc;
-        if ((rc = cnn_backward(h, action_dev, reward_dev, terminal_dev, batch, batch_mean_divisor, !grads_only, profile, stop0, stopb, q)))
-            return rc;
-        if (!grads_only) {
-            // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
-            const long w0_b = h->off_w0, w0_e = h->off_b0;
-            if ((rc = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, q))) return rc;
+        auto issue = [&](hipStream_t qs) -> int {
+            int r;
+            if ((r = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, qs))) return r;
+            if ((r = cnn_backward(h, action_dev, reward_dev, terminal_dev, batch, batch_mean_divisor, !grads_only, profile, stop0, stopb, qs)))
+                return r;
+            if (!grads_only) {
+                // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
+                const long w0_b = h->off_w0, w0_e = h->off_b0;
+                if ((r = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, qs))) return r;
+            }
+            return IDQN_OK;
+        };
+        // A whole plain step is 15 launches whose arguments are pointers and sizes only: for a given set of batch buffers it
+        // can be replayed as ONE hipGraph (opt-in).  The first call of a key runs eagerly (it builds the launch plans, which
+        // allocate), the second is captured on the handle's private stream, every call from then on is one graph launch.
+        static const bool step_graph = getenv("IDQN_STEP_GRAPH") && atoi(getenv("IDQN_STEP_GRAPH")) != 0;
+        if (step_graph && flags == 0) {
+            auto key = std::make_tuple(state_dev, next_state_dev, (const void*)action_dev, (const void*)reward_dev,
+                                       (const void*)terminal_dev, (int)batch, (int)batch_mean_divisor,
+                                       (const void*)h->is_weight, (const void*)h->td_abs);
+            auto& ent = h->step_graphs[key];
+            if (ent.first++ == 0) return issue(q);
+            if (!ent.second) {
+                hipGraph_t graph = nullptr;
+                if (!h->act_stream) IDQN_HIP_CHECK(hipStreamCreateWithFlags(&h->act_stream, hipStreamNonBlocking));
+                IDQN_HIP_CHECK(hipStreamBeginCapture(h->act_stream, hipStreamCaptureModeRelaxed));
+                rc = issue(h->act_stream);
+                const hipError_t e = hipStreamEndCapture(h->act_stream, &graph);
+                if (rc) return rc;
+                IDQN_HIP_CHECK(e);
+                IDQN_HIP_CHECK(hipGraphInstantiate(&ent.second, graph, nullptr, nullptr, 0));
+                IDQN_HIP_CHECK(hipGraphDestroy(graph));
+            }
+            IDQN_HIP_CHECK(hipGraphLaunch(ent.second, q));
+            return IDQN_OK;
         }
+        if ((rc = issue(q))) return rc;
     } else {
         FcArgs a;
         a.net = h->fc; a.online = h->online; a.target = h->target; a.grad = h->grad; a.P = h->L.head_stride;
@@ -1383,6 +1494,7 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         ActHeadArgs ha;
         ha.part = h->act_part; ha.params = params; ha.b0_off = h->off_b0; ha.w1_off = h->off_w1; ha.b1_off = h->off_b1;
         ha.NP = d.NRG; ha.J = h->J; ha.A = h->cfg.n_actions; ha.q_out = q_out_dev; ha.action = action_out_dev;
+        ha.mail = h->act_use_mail ? h->act_mail_dev : nullptr; ha.seq = h->act_seq;
         hipLaunchKernelGGL(k_act_head, dim3(1), dim3(1024), 0, q, ha);
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
@@ -1436,11 +1548,26 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
     IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_act_host: bad head / which");
     hipStream_t q = (hipStream_t)stream;
     const size_t E = (size_t)h->cfg.obs_h * h->cfg.obs_w * h->cfg.obs_c;
+    // The single-state path ends in a kernel that can write the action straight into mapped host memory, followed by a
+    // sequence number the host polls (IDQN_ACT_POLL=0: a device-to-host copy and a stream synchronisation instead).
+    static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
+    static const bool no_poll = getenv("IDQN_ACT_POLL") && atoi(getenv("IDQN_ACT_POLL")) == 0;
+    const bool poll = !no_poll && !act_generic && h->J <= 512 && h->cfg.n_actions <= 32;
+    if (poll && !h->act_mail) {
+        IDQN_HIP_CHECK(hipHostMalloc((void**)&h->act_mail, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h->act_mail, 0, 64);
+        IDQN_HIP_CHECK(hipHostGetDevicePointer((void**)&h->act_mail_dev, h->act_mail, 0));
+        IDQN_HIP_CHECK(hipMalloc((void**)&h->act_seq, 4));
+        IDQN_HIP_CHECK(hipMemset(h->act_seq, 0, 4));
+        h->owned.push_back((void*)h->act_seq);
+    }
     auto issue = [&](hipStream_t qs) -> int {
         IDQN_HIP_CHECK(hipMemcpyAsync(h->act_state, state_host_pinned, E, hipMemcpyHostToDevice, qs));
+        h->act_use_mail = poll;
         int rc = q_values_impl(h, which, head, h->act_state, 1, q_out_dev, h->act_action, (void*)qs);
+        h->act_use_mail = false;
         if (rc) return rc;
-        IDQN_HIP_CHECK(hipMemcpyAsync(action_host_pinned, h->act_action, 4, hipMemcpyDeviceToHost, qs));
+        if (!poll) IDQN_HIP_CHECK(hipMemcpyAsync(action_host_pinned, h->act_action, 4, hipMemcpyDeviceToHost, qs));
         return IDQN_OK;
     };
     static const bool use_graph = !(getenv("IDQN_ACT_GRAPH") && atoi(getenv("IDQN_ACT_GRAPH")) == 0);
@@ -1467,6 +1594,26 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
     } else {
         rc = issue(q);
         if (rc) return rc;
+    }
+    if (poll) {
+        const unsigned want = ++h->act_expected;
+        volatile int32_t* mail = h->act_mail;
+        bool seen = false;
+        for (long spin = 0; spin < (1L << 34); ++spin) {  // far longer than any step queued in front of the launch
+            if ((unsigned)mail[1] == want) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(q) != hipErrorNotReady) {  // the stream ran dry (or failed) without the number
+                seen = (unsigned)mail[1] == want;
+                break;
+            }
+        }
+        if (!seen) {  // resynchronise the two counters, then report
+            hipStreamSynchronize(q);
+            hipMemcpy(&h->act_expected, h->act_seq, 4, hipMemcpyDeviceToHost);
+            IDQN_REQUIRE(false, "idqn_act_host: the acting launch finished without delivering its action");
+        }
+        *action_host_pinned = mail[0];
+        return IDQN_OK;
     }
     IDQN_HIP_CHECK(hipStreamSynchronize(q));
     return IDQN_OK;
