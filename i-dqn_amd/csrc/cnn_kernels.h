@@ -516,6 +516,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     __shared__ float qo[32 * 32], qt[32 * 32];
     __shared__ float qmax[32], cs[32], red[1];
     __shared__ int acts[32];
+    __shared__ float w1s[32 * 32];  // this chunk's rows of W1 ([32 hidden units][A]), loaded while the q partials arrive
     const int t = threadIdx.x, lane = t & 63, bl = lane & 31, h = lane >> 5;
     const int b = t & 31, jj = t >> 5, NJC = a.J / 32;
     const float* po = a.wbase[k];
@@ -530,6 +531,19 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
         float hreg[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) hreg[i] = hb[(jj + 8 * i) * 32 + b];
+        // nor do the batch's scalars (wave 0 consumes them after the reduction) and this chunk's 32 rows of W1
+        int s_act = 0;
+        float s_rew = 0.f, s_wgt = 1.0f;
+        unsigned s_term = 0;
+        const int bg0 = bb * 32 + bl;
+        if (t < 64 && bg0 < a.B) {
+            s_act = a.action[bg0];
+            s_rew = a.reward[bg0];
+            s_term = a.terminal[bg0];
+            if (a.is_weight) s_wgt = a.is_weight[bg0];
+        }
+        if (bb == 0)
+            for (int e = t; e < 32 * a.A; e += 256) w1s[e] = w1[(long)jc * 32 * a.A + e];
         for (int e = t; e < a.A * 32; e += 256) {
             const int ac = e >> 5;
             float vo = 0.f, vt = 0.f;
@@ -560,16 +574,16 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             float m = -INFINITY;
             for (int ac = h; ac < a.A; ac += 2) m = fmaxf(m, qt[ac * 32 + bl]);
             m = fmaxf(m, __shfl_xor(m, 32));
-            const int bg = bb * 32 + bl;
+            const int bg = bg0;
             const bool valid = bg < a.B;
-            const int ac = valid ? a.action[bg] : 0;
+            const int ac = valid ? s_act : 0;
             float td = 0.f;
             if (valid) {
                 // idqn.py:122  r + (1 - terminal) * gamma**n * max_a Q_target(s')
-                const float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * m;
+                const float tgt = s_rew + (float)(1 - (int)s_term) * a.gamma_n * m;
                 td = qo[ac * 32 + bl] - tgt;
             }
-            const float wgt = (valid && a.is_weight) ? a.is_weight[bg] : 1.0f;
+            const float wgt = valid ? s_wgt : 1.0f;
             if (h == 0) {
                 cs[bl] = 2.0f * wgt * td / (float)a.Bdiv;
                 acts[bl] = ac;
@@ -588,7 +602,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int jl = jj + 8 * i;
-            float d = hs[jl][b] > 0.f ? w1[(long)(jc * 32 + jl) * a.A + acts[b]] * cs[b] : 0.f;
+            float d = hs[jl][b] > 0.f ? w1s[jl * a.A + acts[b]] * cs[b] : 0.f;
             dh[jl * 32 + b] = d;
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
@@ -836,7 +850,48 @@ struct DenseWgradArgs {
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
+    // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
+    // dhp[plane][bb][k][J * 32]
+    const unsigned short *a3p, *dhp;
 };
+
+// f32 factors of the Dense_0 gradient -> three exact bf16 planes (convp.h arithmetic), compact per (sample block, head).
+// The factored data-parallel step runs the fused update over the GLOBAL batch: its MFMA work grows with the number of
+// ranks while its HBM traffic does not (f32 MFMA: +16 us per extra sample block), so there the contraction runs on the
+// bf16 matrix cores from planes that are split ONCE here instead of in every one of the 2420 workgroups.
+struct SplitFactorsArgs {
+    const float *a3, *dh;
+    long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
+    int K, nb, nb_inner, F, J;
+    unsigned short *a3p, *dhp;
+};
+__global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
+    const int slot = blockIdx.y, bb = slot / a.K, k = slot - bb * a.K;
+    const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
+    const long na = (long)a.F * 8, nd = (long)a.J * 8;  // float4 per (block, head)
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const float* src;
+    unsigned short* dst;
+    long plane;
+    if (e < na) {
+        src = a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner;
+        dst = a.a3p + (long)slot * a.F * 32;
+        plane = (long)a.nb * a.K * a.F * 32;
+    } else {
+        e -= na;
+        if (e >= nd) return;
+        src = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner;
+        dst = a.dhp + (long)slot * a.J * 32;
+        plane = (long)a.nb * a.K * a.J * 32;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(src + e * 4);
+    unsigned q0a, q1a, q2a, q0b, q1b, q2b;
+    split3_pk(v.x, v.y, q0a, q1a, q2a);
+    split3_pk(v.z, v.w, q0b, q1b, q2b);
+    *reinterpret_cast<uint2*>(dst + e * 4) = make_uint2(q0a, q0b);
+    *reinterpret_cast<uint2*>(dst + plane + e * 4) = make_uint2(q1a, q1b);
+    *reinterpret_cast<uint2*>(dst + 2 * plane + e * 4) = make_uint2(q2a, q2b);
+}
 
 // Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
 // on the MFMA (2 accumulators, k = the 32 samples per batch block) and parks it in LDS.  Phase 2: all 256
@@ -856,7 +911,7 @@ struct DenseWgradArgs {
 // tiles in LDS and write the 4 KB partial.  k_da3_finalize sums the column tiles' partials and applies the ReLU mask.
 // The LDS tile's columns are rotated by 4 * row: the MFMA reads one column of 32 rows per instruction, which would hit a
 // single bank with a 256-float pitch (rotated: 4-way, 8 cycles per 64-cycle MFMA); float4 accesses stay aligned.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats (+ 4096 FUSE_DG) */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
     static_assert(!FUSE_DG || (FUSE_ADAM && NQ == 2), "the fused data gradient rides on the fused 256-column kernel");
@@ -890,6 +945,35 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     for (int bb = 0; bb < a.nb; ++bb) {
+        if (BF3) {
+            // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
+            const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
+            const unsigned short* Ap = a.a3p + slot * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
+            const unsigned short* Dp = a.dhp + slot * a.J * 32 + (long)(j0 + jw + bl) * 32 + 16 * h;
+            bf16x8 A[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) A[pl][s] = *reinterpret_cast<const bf16x8*>(Ap + pl * pa + 8 * s);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                bf16x8 B[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) B[pl][s] = *reinterpret_cast<const bf16x8*>(Dp + (long)q * 32 * 32 + pl * pd + 8 * s);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc[q] = mfma_bf16(A[2][s], B[0][s], acc[q]);
+                    acc[q] = mfma_bf16(A[0][s], B[2][s], acc[q]);
+                    acc[q] = mfma_bf16(A[1][s], B[1][s], acc[q]);
+                    acc[q] = mfma_bf16(A[1][s], B[0][s], acc[q]);
+                    acc[q] = mfma_bf16(A[0][s], B[1][s], acc[q]);
+                    acc[q] = mfma_bf16(A[0][s], B[0][s], acc[q]);
+                }
+            }
+            continue;
+        }
         const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
         const float* Ap = a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner + (long)(f0 + bl) * 32 + 16 * h;
         float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
@@ -990,10 +1074,10 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         }
     }
 }
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false>
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 128 * NQ + (FUSE_DG ? 4096 : 0)];
-    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG>(a, blockIdx.x, gs);
+    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3>(a, blockIdx.x, gs);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

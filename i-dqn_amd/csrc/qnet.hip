@@ -190,6 +190,8 @@ struct idqn_handle_s {
     // plane conv path (convp.h; the default): packed weight planes per net, plane dout buffers, per-position dy sums
     bool planes = true;
     unsigned short *da3p = nullptr, *da2p = nullptr, *da1p = nullptr;
+    unsigned short* fact_planes = nullptr;  // bf16 planes of the gathered Dense_0 factors (factored data-parallel step)
+    long fact_planes_cap = 0;               // in sample blocks
     float* pbuf[3] = {nullptr, nullptr, nullptr};  // [K * nb][OH * OW][CO] of conv layer i
     long wq_stride = 0, wq_fwd[3] = {0, 0, 0}, wq_dg[3] = {0, 0, 0};  // bytes
     std::map<std::tuple<int, int, int, int>, FwdPlan> fwd_plans;  // (role, n_nets, nb, target workgroups)
@@ -1019,6 +1021,27 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     const int K = h->cfg.n_heads;
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
+    dw.a3p = dw.dhp = nullptr;
+    // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
+    // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
+    static const bool dp_f32 = getenv("IDQN_DP_F32") != nullptr;
+    static const int dp_bf3_min = getenv("IDQN_DP_BF3_MIN") ? atoi(getenv("IDQN_DP_BF3_MIN")) : 2;
+    const bool bf3 = h->planes && fuse_adam && !fuse_dg && !dp_f32 && nb_total >= dp_bf3_min && h->J % 256 == 0;
+    if (bf3) {
+        if (h->fact_planes_cap < nb_total) {  // (first step of a job, or a larger world: outside any timed region)
+            if (h->fact_planes) { IDQN_HIP_CHECK(hipStreamSynchronize(q)); IDQN_HIP_CHECK(hipFree(h->fact_planes)); }
+            IDQN_HIP_CHECK(hipMalloc((void**)&h->fact_planes, (size_t)3 * nb_total * K * (h->F + h->J) * 32 * 2));
+            h->fact_planes_cap = nb_total;
+        }
+        SplitFactorsArgs sa;
+        sa.a3 = a3; sa.dh = dh; sa.a3_outer = a3_outer; sa.a3_head = a3_head; sa.a3_inner = a3_inner;
+        sa.dh_outer = dh_outer; sa.dh_head = dh_head; sa.dh_inner = dh_inner;
+        sa.K = K; sa.nb = nb_total; sa.nb_inner = nb_inner; sa.F = h->F; sa.J = h->J;
+        sa.a3p = h->fact_planes; sa.dhp = h->fact_planes + (long)3 * nb_total * K * h->F * 32;
+        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)(h->F + h->J) * 8, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
+        tl_mark(h, q, "factor planes");
+        dw.a3p = sa.a3p; dw.dhp = sa.dhp;
+    }
     dw.a3 = a3; dw.dh = dh; dw.grad = h->grad; dw.theta = h->online; dw.mu = h->mu; dw.nu = h->nu;
     dw.bcinv = h->bcinv; dw.ad = h->ad; dw.g_w0_base = h->g_w0_base; dw.g_w0_stride = h->g_w0_end - h->g_w0_begin;
     dw.w_off = h->off_w0; dw.P = h->L.head_stride;
@@ -1043,6 +1066,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, dw);               \
     } while (0)
     if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
     else if (nq == 2) D0W_LAUNCH(false, 2);
@@ -1277,6 +1301,7 @@ extern "C" int idqn_destroy(idqn_handle_t h) {
         if (g.second.second) (void)hipGraphExecDestroy(g.second.second);
     if (h->act_stream) (void)hipStreamDestroy(h->act_stream);
     if (h->act_mail) (void)hipHostFree(h->act_mail);
+    if (h->fact_planes) (void)hipFree(h->fact_planes);
     delete h;
     return IDQN_OK;
 }
