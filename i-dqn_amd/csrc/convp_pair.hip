@@ -5,6 +5,7 @@
 // chip each they take only 5-25 % longer (dgrad Conv_2 19.7 -> 20 us on 125 workgroups, wgrad Conv_2 16.6 -> 19.0 on 120),
 // so side by side the pair costs about what the slower one costs alone.  One workgroup per CU, all co-resident.
 #include <algorithm>
+#include <cstdlib>
 
 #include "convp_fwd_body.h"
 #include "convp_wgrad_body.h"
@@ -13,13 +14,28 @@ namespace {
 
 template <int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG>
 __global__ __launch_bounds__(512) void k_cpair(CFwdArgs f, unsigned f_stage, int ring, unsigned mask_off, int n_f, long long* prof,
-                                               CWgradArgs w, unsigned w_stage, int MT) {
+                                               CWgradArgs w, unsigned w_stage, int MT, int split_xcd) {
     constexpr int KA = (int)(sizeof(CFwdArgs) + sizeof(CWgradArgs)) + 64;
     warm_kernargs<(KA < 1024 ? KA : 1024)>();
-    // XCD-contiguous over the whole grid: the data gradient's items land on the first XCDs, the weight gradient's on the rest
-    const int v = xcd_contiguous_id();
-    if (v < n_f) cfwd_body<NPA, CT, NQ, NT>(f, f_stage, ring, mask_off, prof, v, n_f);
-    else cwgrad_body<WNPX, WCT, WNTW, WPG>(w, w_stage, MT, v - n_f);
+    // Both roles on EVERY XCD (blocks go to XCDs round-robin: XCD x = blockIdx % 8 holds slots blockIdx / 8): the first
+    // f(x) slots of XCD x run the data gradient, the rest the weight gradient, each role numbered XCD-contiguously
+    // (neighbouring items share inputs through that XCD's L2).  With the roles on separate XCDs the longer one had only
+    // half of the chip's L2 / fabric ports for its staging traffic.
+    const int n = (int)gridDim.x, b = (int)blockIdx.x, x = b & 7, slot = b >> 3;
+    const int qf = n_f >> 3, rf = n_f & 7, fx = qf + (x < rf ? 1 : 0);
+    if (!split_xcd) {
+        const int v = xcd_contiguous_id();
+        if (v < n_f) cfwd_body<NPA, CT, NQ, NT>(f, f_stage, ring, mask_off, prof, v, n_f);
+        else cwgrad_body<WNPX, WCT, WNTW, WPG>(w, w_stage, MT, v - n_f);
+    } else if (slot < fx) {
+        cfwd_body<NPA, CT, NQ, NT>(f, f_stage, ring, mask_off, prof, x * qf + min(x, rf) + slot, n_f);
+    } else {
+        const int n_w = n - n_f, qn = n >> 3, rn = n & 7;
+        // weight-gradient blocks of the XCDs before x: their block counts minus their data-gradient blocks
+        const int before = (x * qn + min(x, rn)) - (x * qf + min(x, rf));
+        (void)n_w;
+        cwgrad_body<WNPX, WCT, WNTW, WPG>(w, w_stage, MT, before + (slot - fx));
+    }
 }
 
 template <int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG>
@@ -27,6 +43,9 @@ int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_l
                 hipStream_t q, long long* prof) {
     const unsigned mask_off = (unsigned)convp_fwd_mask_off(f_stage, NT, ring, f.out3 != nullptr, f.out_f32 != nullptr);
     const size_t lds = std::max(f_lds, w_lds + 2048);
+    // every XCD needs at least as many blocks as data-gradient blocks: true whenever the weight gradient has >= 8 items
+    static const bool role_xcds = getenv("IDQN_PAIR_ROLE_XCDS") != nullptr;  // A/B switch: roles on separate XCDs
+    const int split_xcd = (!role_xcds && n_w >= 8) ? 1 : 0;
     static size_t attr = 0;  // per instantiation
     if (lds > attr) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cpair<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>,
@@ -34,7 +53,7 @@ int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_l
         attr = lds;
     }
     hipLaunchKernelGGL((k_cpair<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>), dim3((unsigned)(n_f + n_w)), dim3(512), lds, q, f,
-                       (unsigned)f_stage, ring, mask_off, n_f, prof, w, (unsigned)(w_lds / 2), MT);
+                       (unsigned)f_stage, ring, mask_off, n_f, prof, w, (unsigned)(w_lds / 2), MT, split_xcd);
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }

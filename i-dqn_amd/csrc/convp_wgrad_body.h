@@ -56,31 +56,64 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
     const unsigned long xb = (unsigned long)a.x, dyb = (unsigned long)a.dy;
 
     auto cnt_of = [&](int pos) { return min(PG, min((pos / OW + 1) * OW, p_end) - pos); };
-    auto stage = [&](int bb, int pos, unsigned buf) {
+    // NPX == 3: the x region of the two stages is ONE ring of 2 strips of pixels.  Consecutive stages of an output row slide
+    // along the same input row, so a stage copies only the pixels its predecessor did not (PG * S of (PG - 1) * S + KW) and
+    // appends them behind the window; a stage that starts a row (or a batch block) appends its whole strip.  The window of
+    // the stage being read and the pixels appended meanwhile are each at most one strip: they never overlap in two strips.
+    const unsigned ring_bytes = 2 * XB;
+    // window state of a stage, kept in step by loader and compute waves: start of its window and end of the data, in ring bytes
+    auto advance = [&](int pos, unsigned& wstart, unsigned& wend, int& first_col, int& n_new) {
+        const int oh = pos / OW, ow0 = pos - oh * OW, cnt = cnt_of(pos);
+        const bool cont = pos != p0 && ow0 != 0;  // same input row as the stage before
+        const int lo = ow0 * a.S, hi = (ow0 + cnt - 1) * a.S + a.KW;
+        first_col = cont ? lo - a.S + a.KW : lo;  // the previous stage ended with position ow0 - 1
+        n_new = hi - first_col;
+        if (cont) {
+            wstart += (unsigned)(PG * a.S * a.x_pix);  // the previous stage of a row always holds PG positions
+            if (wstart >= ring_bytes) wstart -= ring_bytes;
+        } else {
+            wstart = wend;
+        }
+        wend += (unsigned)(n_new * a.x_pix);
+        if (wend >= ring_bytes) wend -= ring_bytes;
+    };
+    unsigned l_wstart = 0, l_wend = 0;  // the loader's copy of the window state
+    auto stage = [&](int bb, int pos, unsigned par) {
         const int oh = pos / OW, ow0 = pos - oh * OW, cnt = cnt_of(pos);
         const unsigned long xs = xb + (unsigned long)(a.x_shared ? bb : k * a.nb + bb) * (unsigned long)a.x_slot;
+        const unsigned buf = lds0 + par * stage_bytes;
+        unsigned dy_dst;
         if (NPX == 3) {
+            const unsigned at = l_wend;  // append here
+            int first_col, n_new;
+            advance(pos, l_wstart, l_wend, first_col, n_new);
             const unsigned long src = xs + (unsigned long)(oh * a.S + it.kh) * (unsigned long)a.x_row +
-                                      (unsigned long)(ow0 * a.S) * (unsigned long)a.x_pix;
-            const int npiece = (((cnt - 1) * a.S + a.KW) * a.x_pix) >> 10;
-            for (int i = wave; i < npiece; i += 4) dma16(voff, src + (unsigned long)i * 1024, buf + i * 1024);
+                                      (unsigned long)first_col * (unsigned long)a.x_pix;
+            const int npiece = (n_new * a.x_pix) >> 10;
+            for (int i = wave; i < npiece; i += 4) {
+                unsigned d = at + i * 1024;
+                if (d >= ring_bytes) d -= ring_bytes;
+                dma16(voff, src + (unsigned long)i * 1024, lds0 + d);
+            }
+            dy_dst = lds0 + ring_bytes + par * (unsigned)(PG * dy_pix);
         } else {
             const int npiece = cnt + 1;
             for (int kh = 0; kh < a.KH; ++kh) {
                 const unsigned long src = xs + (unsigned long)(oh * a.S + kh) * (unsigned long)a.x_row + (unsigned long)ow0 * 1024;
                 for (int i = wave; i < npiece; i += 4) dma16(voff, src + (unsigned long)i * 1024, buf + kh * strip_bytes + i * 1024);
             }
+            dy_dst = buf + XB;
         }
         const unsigned long dsrc = dyb + (unsigned long)(k * a.nb + bb) * (unsigned long)a.dy_slot +
                                    ((unsigned long)(oh + a.dy_lo_h) * a.dy_Wp + (ow0 + a.dy_lo_w)) * (unsigned long)dy_pix;
         const int ndp = (cnt * dy_pix) >> 10;
-        for (int i = wave; i < ndp; i += 4) dma16(voff, dsrc + (unsigned long)i * 1024, buf + XB + i * 1024);
+        for (int i = wave; i < ndp; i += 4) dma16(voff, dsrc + (unsigned long)i * 1024, dy_dst + i * 1024);
     };
 
     if (loader) {
         // ---- loader waves: copy stage s + 1 while the compute waves work on stage s -----------------------------------
         int ibb = 0, ipos = p0, par = 0;
-        stage(ibb, ipos, lds0);
+        stage(ibb, ipos, 0u);
         ipos += cnt_of(ipos);
         if (ipos >= p_end) { ipos = p0; ++ibb; }
         int cbb = 0, cpos = p0;  // mirrors the compute waves' progress (same barrier count)
@@ -88,7 +121,7 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (ibb < a.nb) {
-                stage(ibb, ipos, lds0 + (par ^ 1) * stage_bytes);
+                stage(ibb, ipos, (unsigned)(par ^ 1));
                 ipos += cnt_of(ipos);
                 if (ipos >= p_end) { ipos = p0; ++ibb; }
             }
@@ -134,13 +167,23 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
     const unsigned char* zero_blk = lds + 2 * stage_bytes;  // 2 KB of zeros behind the two stages
     *LDS_PTR(u32x4, lds + 2 * stage_bytes + wave * 512 + cl * 16) = (u32x4){0u, 0u, 0u, 0u};  // published by the first barrier
     int cbb = 0, cpos = p0, par = 0;
+    unsigned c_wstart = 0, c_wend = 0;  // window state (NPX == 3), advanced exactly like the loader's
     while (cbb < a.nb) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned char* cur = lds + par * stage_bytes;
         const int cnt = cnt_of(cpos);
+        if (NPX == 3) {
+            int fc, nn;
+            advance(cpos, c_wstart, c_wend, fc, nn);
+        }
         auto xaddr = [&](int u) {  // LDS address of the x fragment rows of tile-step u (plane 0)
             const int i = u % NTW, g = u / NTW, ks = g & 1, pp = g >> 1;
+            if (NPX == 3) {  // pixel (position pp, tap of tile i) of this stage's window in the ring (all wave-uniform)
+                unsigned off = c_wstart + pp * pos_stride + tbase[i];
+                if (off >= ring_bytes) off -= ring_bytes;
+                return (pp < cnt ? lds + off : zero_blk) + (ks ? rd1 : rd0);
+            }
             return (pp < cnt ? cur + pp * pos_stride + tbase[i] : zero_blk) + (ks ? rd1 : rd0);
         };
         auto xplane = [&](int u) { return (u / NTW >> 1) < cnt ? a.x_plane : 0; };
@@ -148,7 +191,8 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
         // the MFMAs -- a conditional accumulator update made hipcc shuffle whole accumulators through v_accvgpr moves
         auto daddr = [&](int g) {
             const int ks = g & 1, pp = g >> 1;
-            return (pp < cnt ? cur + XB + pp * dy_pix + ct * 2048 : zero_blk) + (ks ? rd1 : rd0);
+            const unsigned char* dyb_ = NPX == 3 ? lds + ring_bytes + par * (PG * dy_pix) : cur + XB;
+            return (pp < cnt ? dyb_ + pp * dy_pix + ct * 2048 : zero_blk) + (ks ? rd1 : rd0);
         };
         auto dplane = [&](int g) { return (g >> 1) < cnt ? a.CO * 64 : 0; };
         bf16x8 xf[3][NPX], df[2][3];
