@@ -17,6 +17,7 @@
 // LDS; weight gradient + Adam: MFMA tile parked in LDS, then whole-row streaming of theta / m / v).
 // f32 MFMA is 64 FLOP/clk/SIMD: one dword of each operand per 64-cycle instruction.
 #pragma once
+#include <type_traits>
 #include "convp.h"
 
 struct ActGeom {
@@ -509,6 +510,7 @@ struct TdArgs {
     int bcinv_done;          // 1: the staging launch of this step already wrote bcinv (plane path)
     const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr = plain mean
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
+    long long* prof;         // debug (IDQN_CONV_PROF=9): 8 stamps per workgroup, or nullptr
 };
 
 __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
@@ -524,6 +526,8 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     const float* w1 = po + a.w1_off;
     float* G = a.grad + (long)k * a.gP;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f, loss_acc = 0.f;
+    long long ts[8];
+    ts[0] = clock64();
     for (int bb = 0; bb < a.nb; ++bb) {
         const long so = (long)k * a.nb + bb, st = (long)(a.K + k) * a.nb + bb;
         // this block's hidden rows do not depend on the q reduction below: have them in flight meanwhile
@@ -542,34 +546,57 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             s_term = a.terminal[bg0];
             if (a.is_weight) s_wgt = a.is_weight[bg0];
         }
-        if (bb == 0)
-            for (int e = t; e < 32 * a.A; e += 256) w1s[e] = w1[(long)jc * 32 * a.A + e];
-        for (int e = t; e < a.A * 32; e += 256) {
-            const int ac = e >> 5;
-            float vo = 0.f, vt = 0.f;
-            const float* qo_ = a.qpart + so * NJC * 1024 + e;
-            const float* qt_ = a.qpart + st * NJC * 1024 + e;
-            for (int c = 0; c < NJC; c += 16) {  // NJC = J / 32 <= 16: all chunk partials of both nets in one round
-                float x[16], y[16];
+        if (bb == 0) {  // A <= 32: at most four elements per thread, all requested before the first LDS store
+            float wv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = t + 256 * r < 32 * a.A ? w1[(long)jc * 32 * a.A + t + 256 * r] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t + 256 * r < 32 * a.A) w1s[t + 256 * r] = wv[r];
+        }
+        // (action, sample) elements in rounds of 256: every partial of every round of this thread (NJC = J / 32 <= 16 chunks x
+        // 2 nets x up to 4 rounds) is requested before the first add -- one load latency whatever A is
+        auto q_reduce = [&](auto NR_) {
+            constexpr int NR = decltype(NR_)::value;
+            float x[NR][16], y[NR][16];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int e = min(t + 256 * r, a.A * 32 - 1);
+                const float* qo_ = a.qpart + so * NJC * 1024 + e;
+                const float* qt_ = a.qpart + st * NJC * 1024 + e;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    x[u] = c + u < NJC ? qo_[(c + u) * 1024] : 0.f;
-                    y[u] = c + u < NJC ? qt_[(c + u) * 1024] : 0.f;
+                    x[r][u] = u < NJC ? qo_[u * 1024] : 0.f;
+                    y[r][u] = u < NJC ? qt_[u * 1024] : 0.f;
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int e = t + 256 * r;
+                if (e >= a.A * 32) break;
+                const int ac = e >> 5;
+                float vo = 0.f, vt = 0.f;
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    if (c + u < NJC) { vo += x[u]; vt += y[u]; }
+                    if (u < NJC) { vo += x[r][u]; vt += y[r][u]; }
+                vo += po[a.b1_off + ac];
+                vt += pt[a.b1_off + ac];
+                qo[e] = vo;
+                qt[e] = vt;
+                if (jc == 0) {
+                    a.q_dbg[so * 1024 + e] = vo;
+                    a.q_dbg[st * 1024 + e] = vt;
+                }
             }
-            vo += po[a.b1_off + ac];
-            vt += pt[a.b1_off + ac];
-            qo[e] = vo;
-            qt[e] = vt;
-            if (jc == 0) {
-                a.q_dbg[so * 1024 + e] = vo;
-                a.q_dbg[st * 1024 + e] = vt;
-            }
+        };
+        switch ((a.A * 32 + 255) / 256) {  // A <= 32 (idqn_create)
+            case 1: q_reduce(std::integral_constant<int, 1>{}); break;
+            case 2: q_reduce(std::integral_constant<int, 2>{}); break;
+            case 3: q_reduce(std::integral_constant<int, 3>{}); break;
+            default: q_reduce(std::integral_constant<int, 4>{}); break;
         }
         __syncthreads();
+        ts[1] = clock64();
         if (t < 64) {  // wave 0: max over actions -- each half-wave folds every other action, one cross-lane step
             float m = -INFINITY;
             for (int ac = h; ac < a.A; ac += 2) m = fmaxf(m, qt[ac * 32 + bl]);
@@ -597,6 +624,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) hs[jj + 8 * i][b] = hreg[i];
         __syncthreads();
+        ts[2] = clock64();
         loss_acc += red[0];
         float* dh = a.dh + so * a.J * 32 + (long)jc * 32 * 32;
 #pragma unroll
@@ -608,19 +636,36 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
             gb0[i] += d;
         }
+        ts[3] = clock64();
+        // Dense_1 weight gradient: gw[jl][ac] = sum over the samples x with action ac of h[jl][x] * cs[x] (sample order).
+        // Every LDS operand is read into registers first -- written as `cond ? hs[..] * cs[..] : 0` hipcc guarded the two
+        // reads with a branch per sample: 170 cycles per sample, 2.6 us of the kernel at A = 6, 7.7 us at A = 18.
+        int av[32];
+        float cv[32];
+#pragma unroll
+        for (int x = 0; x < 32; ++x) { av[x] = acts[x]; cv[x] = cs[x]; }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int o = t + 256 * m;
             if (o < 32 * a.A) {
                 const int jl = o / a.A, ac = o - jl * a.A;
+                float hv[32];
+#pragma unroll
+                for (int x = 0; x < 32; ++x) hv[x] = hs[jl][x];
                 float s = 0.f;
-                for (int x = 0; x < 32; ++x) s += (acts[x] == ac) ? hs[jl][x] * cs[x] : 0.f;
+#pragma unroll
+                for (int x = 0; x < 32; ++x) {
+                    const float pr = hv[x] * cv[x];
+                    s += av[x] == ac ? pr : 0.f;
+                }
                 gw[m] += s;
             }
         }
+        ts[4] = clock64();
         if (jc == 0 && t < a.A) {
             float s = 0.f;
-            for (int x = 0; x < 32; ++x) s += (acts[x] == t) ? cs[x] : 0.f;
+#pragma unroll
+            for (int x = 0; x < 32; ++x) s += av[x] == t ? cv[x] : 0.f;
             gb1 += s;
         }
         __syncthreads();
@@ -632,6 +677,11 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     for (int m = 0; m < 4; ++m) {
         const int o = t + 256 * m;
         if (o < 32 * a.A) G[a.g_w1_off + (long)jc * 32 * a.A + o] = gw[m];
+    }
+    if (a.prof && t == 0) {
+        ts[5] = clock64();
+        long long* pr = a.prof + ((long)k * NJC + jc) * 8;
+        for (int i = 0; i < 6; ++i) pr[i] = ts[i];
     }
     if (jc == 0) {
         if (t < a.A) G[a.g_b1_off + t] = gb1;

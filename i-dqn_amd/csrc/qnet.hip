@@ -1097,6 +1097,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         ta.gP = h->gP; ta.g_b0_off = h->off_b0 - w0n; ta.g_w1_off = h->off_w1 - w0n; ta.g_b1_off = h->off_b1 - w0n;
     } ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
     ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
+    ta.prof = (h->cprof && h->cprof_role == 9) ? (long long*)h->cprof : nullptr;
     ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
