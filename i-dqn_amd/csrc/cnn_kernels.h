@@ -438,44 +438,50 @@ struct HiddenArgs {
 
 __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a) {
     __shared__ float hs[32][33];
-    const int t = threadIdx.x, b = t & 31, jj = t >> 5;
+    __shared__ float w1s[32 * 32];  // this chunk's rows of W1 ([32 hidden units][A]), requested before the partials
+    const int t = threadIdx.x;
     const int jc = blockIdx.x, slot = blockIdx.y;
     const float* p = a.wbase[slot / a.nb];
     const float* part = a.part + (long)slot * a.NS * a.J * 32;
     float* hb = a.hbuf + (long)slot * a.J * 32;
-    // 4 rows per thread; the split partials are loaded 8 x 4 at a time (independent loads in flight) and
-    // added in fixed split order, so the sum is reproducible
-    float sv[4];
-    const float* pr = part + (long)(jc * 32 + jj) * 32 + b;
+    {
+        const float* w1 = p + a.w1_off + (long)jc * 32 * a.A;
+        float wv[4];  // A <= 32: at most four elements per thread
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = t + 256 * r < 32 * a.A ? w1[t + 256 * r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (t + 256 * r < 32 * a.A) w1s[t + 256 * r] = wv[r];
+    }
+    // split-K reduce: thread = (row jl = t / 8, samples 4 (t % 8) .. + 3): a wave-instruction moves 8 whole rows (1 KB); the
+    // partials are added in split order (reproducible), 16 splits per round in flight
+    const int jl = t >> 3, l8 = t & 7, j = jc * 32 + jl;
+    const float* pr = part + (long)j * 32 + 4 * l8;
     const long sstride = (long)a.J * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sv[i] = p[a.b0_off + jc * 32 + jj + 8 * i];
-    for (int sp = 0; sp < a.NS; sp += 16) {  // 16 splits per round, every load of a round in flight (none past the last split)
-        float v[16][4];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = sp + u < a.NS ? pr[(sp + u) * sstride + i * 256] : 0.f;
+    const float bias = p[a.b0_off + j];
+    float4 sv = make_float4(bias, bias, bias, bias);
+    for (int sp = 0; sp < a.NS; sp += 16) {
+        float4 v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (sp + u < a.NS) {
+            v[u] = sp + u < a.NS ? *reinterpret_cast<const float4*>(pr + (sp + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sv[i] += v[u][i];
-            }
+        for (int u = 0; u < 16; ++u)
+            if (sp + u < a.NS) { sv.x += v[u].x; sv.y += v[u].y; sv.z += v[u].z; sv.w += v[u].w; }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int jl = jj + 8 * i, j = jc * 32 + jl;
-        const float s = fmaxf(sv[i], 0.f);
-        hs[jl][b] = s;
-        hb[j * 32 + b] = s;
-    }
+    sv.x = fmaxf(sv.x, 0.f); sv.y = fmaxf(sv.y, 0.f); sv.z = fmaxf(sv.z, 0.f); sv.w = fmaxf(sv.w, 0.f);
+    hs[jl][4 * l8 + 0] = sv.x; hs[jl][4 * l8 + 1] = sv.y; hs[jl][4 * l8 + 2] = sv.z; hs[jl][4 * l8 + 3] = sv.w;
+    *reinterpret_cast<float4*>(hb + (long)j * 32 + 4 * l8) = sv;
     __syncthreads();
-    const float* w1 = p + a.w1_off + (long)jc * 32 * a.A;
+    // Dense_1 partial of this chunk: q[ac][b] = sum over its 32 hidden units (in order) of h[jl][b] * W1[jl][ac]
+    const int b = t & 31, jj = t >> 5;
     for (int ac = jj; ac < a.A; ac += 8) {
+        float hv[32], wv[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { hv[r] = hs[r][b]; wv[r] = w1s[r * a.A + ac]; }
         float s = 0.f;
-#pragma unroll 8
-        for (int jl = 0; jl < 32; ++jl) s = fmaf(hs[jl][b], w1[jl * a.A + ac], s);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s = fmaf(hv[r], wv[r], s);
         a.qpart[(((long)slot * (a.J / 32) + jc) * 32 + ac) * 32 + b] = s;
     }
 }
