@@ -1339,7 +1339,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             }
             return IDQN_OK;
         };
-        // A whole plain step is 15 launches whose arguments are pointers and sizes only: for a given set of batch buffers it
+        // A whole plain step is 13 launches whose arguments are pointers and sizes only: for a given set of batch buffers it
         // can be replayed as ONE hipGraph (opt-in).  The first call of a key runs eagerly (it builds the launch plans, which
         // allocate), the second is captured on the handle's private stream, every call from then on is one graph launch.
         static const bool step_graph = getenv("IDQN_STEP_GRAPH") && atoi(getenv("IDQN_STEP_GRAPH")) != 0;
