@@ -1,0 +1,76 @@
+"""Launch-structure switches of the HIP path must not change results: the same seeded steps are run in child processes
+(the switches are read once per process) and compared with the default build of the step.
+
+  IDQN_STEP_GRAPH=1   the plain step replayed as a hipGraph          -> bit-identical to the eager launches
+  IDQN_NO_PAIR=1      conv data / weight gradients as two launches   -> same losses, parameters within fp32 round-off
+                      (the weight gradient is cut into a different number of position chunks, i.e. summed in another order)
+  IDQN_ACT_POLL=0     acting result by copy + synchronisation        -> same greedy actions as the polled mailbox
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys, os
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn.networks.idqn import iDQN
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+rng = np.random.default_rng(7)
+agent = iDQN(3, (84, 84, 4), 6, 5, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+def batch():
+    return Batch(torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy(rng.integers(0, 6, 32).astype(np.int32)).cuda(),
+                 torch.from_numpy(rng.standard_normal(32).astype(np.float32)).cuda(),
+                 torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy((rng.random(32) < 0.1).astype(np.uint8)).cuda())
+bs = [batch(), batch()]  # two buffer sets, used in turn like the replay buffer's staging sets
+losses = [agent._learn(bs[i % 2]).cpu().numpy().astype(np.float64).tolist() for i in range(6)]
+state = rng.integers(0, 256, (84, 84, 4), dtype=np.uint8)
+acts = [int(agent._best_action(0, k, state)) for k in range(5)]
+flat = agent._flat(agent._online)
+probe = {name: v.reshape(5, -1)[:, :: max(1, v[0].size // 97)].astype(np.float64).tolist() for name, v in flat.items()}
+print("RESULT" + json.dumps({"losses": losses, "acts": acts, "probe": probe}))
+"""
+
+
+def _run(**env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):])
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    return _run()
+
+
+def test_step_graph_replay_is_bit_identical(default_run):
+    got = _run(IDQN_STEP_GRAPH="1")
+    assert got["losses"] == default_run["losses"]
+    assert got["probe"] == default_run["probe"]
+
+
+def test_unpaired_conv_backward_matches(default_run):
+    got = _run(IDQN_NO_PAIR="1")
+    np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
+    for name, want in default_run["probe"].items():
+        # six Adam steps at lr 6.25e-5 on gradients that differ in their last bits
+        np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_acting_by_copy_and_sync_matches(default_run):
+    got = _run(IDQN_ACT_POLL="0")
+    assert got["acts"] == default_run["acts"]
+    assert got["losses"] == default_run["losses"]
