@@ -1,6 +1,8 @@
 """One launcher for the four entry points (``experiments/{atari,lunar_lander}/{dqn,idqn}.py`` of the reference wire
 the same four objects -- flags, environment, replay buffer, agent -- with per-environment constants; here that wiring
 is a table and a function instead of four near-identical scripts)."""
+import os
+
 import numpy as np
 
 from experiments.base.dqn import train
@@ -44,6 +46,9 @@ def make_agent(algo, key, obs_dim, n_actions, p, adam_eps):
 
 def launch(env_name, algo, argvs, env=None, save_root=None):
     """Parses the flags, builds environment / replay buffer / agent and trains; returns ``(p, agent)``."""
+    # the trainer steps the same two batch-buffer sets over and over: let the library replay the step's launches as one
+    # hipGraph per set (read once, at the first step; results are bit-identical, tests/test_gpu_switches.py)
+    os.environ.setdefault("IDQN_STEP_GRAPH", "1")
     consts = ENVIRONMENTS[env_name]
     p = prepare_logs(env_name, algo, argvs, save_root)
     agent_key, train_key = prng.split(prng.PRNGKey(p["seed"]))

@@ -204,8 +204,14 @@ class ReplayBuffer:
         # capacity elements; `_upload_frame` grows the ring in the rare case the slack runs out.
         self._n_frames = cap + self._update_horizon + self._stack_size + max(64, cap // 16)
         self._frames = torch.empty((self._n_frames, self._frame_bytes), dtype=torch.uint8, device="cuda")
-        self._meta = np.zeros((cap, 8), np.int32)  # host copy of the element rows (see replay_gather_stacked)
+        # host copy of the element rows (see replay_gather_stacked), in PINNED memory: new rows go to the device by
+        # asynchronous copies.  A row is rewritten only `capacity` adds after it was written; `_write` waits for the last
+        # upload first in the (tiny-buffer) case that it could still be in flight.
+        self._meta_pin = torch.zeros((cap, 8), dtype=torch.int32).pin_memory()
+        self._meta = self._meta_pin.numpy()
         self._meta_dev = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
+        self._meta_ev, self._meta_ev_lo = None, 0  # event behind the last upload, oldest key it may still be reading
+        self._meta_ev_obj = None
         self._first_frame = np.zeros(cap, np.int64)  # oldest frame (transition index) an element refers to
         # host mirrors of the scalars (cheap; `_memory[key]` and logging read them)
         self._action = np.zeros(cap, np.int64)
@@ -221,6 +227,9 @@ class ReplayBuffer:
 
         from slimdqn import _hip
 
+        if self._meta_ev is not None:  # the rows are rewritten below: no upload may still be reading them
+            self._meta_ev.synchronize()
+            self._meta_ev = None
         old_n, new_n = self._n_frames, 2 * self._n_frames
         new = torch.empty((new_n, self._frame_bytes), dtype=torch.uint8, device="cuda")
         _hip.check(_hip.lib().replay_ring_regrow(_hip.ptr(self._frames), old_n, _hip.ptr(new), new_n, oldest_needed,
@@ -272,6 +281,9 @@ class ReplayBuffer:
 
     def _write(self, key: int, plan: ElementPlan, window_size: int, t_now: int) -> None:
         slot = key % self._max_capacity
+        if self._meta_ev is not None and key >= self._meta_ev_lo + self._max_capacity:  # (buffers of a few elements only)
+            self._meta_ev.synchronize()
+            self._meta_ev = None
         to_t = lambda pos: t_now - (window_size - 1 - pos)  # window position -> transition index
         valid_s, valid_n = min(self._stack_size, plan.last_s + 1), min(self._stack_size, plan.last_n + 1)
         row = self._meta[slot]
@@ -287,17 +299,32 @@ class ReplayBuffer:
         """Element rows written since the last sample go to the device: FIFO slots are contiguous modulo capacity."""
         import torch
 
+        from slimdqn import _hip
+
         lo, hi, cap = self._flushed, self.add_count, self._max_capacity
+        if hi == lo:
+            return
+        lib, q, src, dst = _hip.lib(), _hip.current_stream(), self._meta_pin.data_ptr(), self._meta_dev.data_ptr()
+
+        def rows(a, b):  # one asynchronous copy from the pinned mirror (the byte-range form of replay_add_frame)
+            _hip.check(lib.replay_add_frame(dst + 32 * a, 0, 32 * (b - a), src + 32 * a, q), "replay_add_frame")
+
         if hi - lo >= cap:
-            self._meta_dev.copy_(torch.from_numpy(self._meta))
-        elif hi > lo:
+            rows(0, cap)
+        else:
             a, b = lo % cap, hi % cap
             if a < b:
-                self._meta_dev[a:b].copy_(torch.from_numpy(self._meta[a:b]))
+                rows(a, b)
             else:
-                self._meta_dev[a:].copy_(torch.from_numpy(self._meta[a:]))
+                rows(a, cap)
                 if b:
-                    self._meta_dev[:b].copy_(torch.from_numpy(self._meta[:b]))
+                    rows(0, b)
+        if self._meta_ev is None:
+            self._meta_ev_lo = lo
+            if self._meta_ev_obj is None:
+                self._meta_ev_obj = torch.cuda.Event()
+            self._meta_ev = self._meta_ev_obj
+        self._meta_ev.record()  # (re-recorded: the event now stands behind every upload issued so far)
         self._flushed = hi
 
     # ---- reference API -----------------------------------------------------------------------------
@@ -319,14 +346,29 @@ class ReplayBuffer:
         # valid until the SECOND-next sample of the same size (the reference returns fresh arrays every time; a caller that
         # keeps more than two batches alive has to copy them).
         if size not in self._stage:
-            self._stage[size] = [dict(
-                slots=torch.empty(size, dtype=torch.int32, device="cuda"),
-                state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
-                next_state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
-                action=torch.empty(size, dtype=torch.int32, device="cuda"),
-                reward=torch.empty(size, dtype=torch.float32, device="cuda"),
-                terminal=torch.empty(size, dtype=torch.uint8, device="cuda"),
-            ) for _ in range(2)] + [0]
+            tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
+                   np.dtype(np.float64): torch.float64, np.dtype(np.int64): torch.int64,
+                   np.dtype(np.int32): torch.int32}[np.dtype(self._obs_dtype)]
+            shape = (size,) + tuple(self._obs_shape)
+            sets = []
+            for _ in range(2):
+                st = dict(
+                    slots=torch.empty(size, dtype=torch.int32, device="cuda"),
+                    slots_pin=torch.empty(size, dtype=torch.int32).pin_memory(), slots_ev=None,
+                    state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
+                    next_state=torch.empty((size, self._frame_bytes * self._stack_size), dtype=torch.uint8, device="cuda"),
+                    action=torch.empty(size, dtype=torch.int32, device="cuda"),
+                    reward=torch.empty(size, dtype=torch.float32, device="cuda"),
+                    terminal=torch.empty(size, dtype=torch.uint8, device="cuda"),
+                )
+                st["slots_np"] = st["slots_pin"].numpy()
+                # the element handed out and the output pointers of the gather are the same every time the set is used
+                st["element"] = ReplayElement(
+                    state=DevArray(st["state"].view(tdt).view(shape)), action=DevArray(st["action"]),
+                    reward=DevArray(st["reward"]), next_state=DevArray(st["next_state"].view(tdt).view(shape)),
+                    is_terminal=DevArray(st["terminal"]), episode_end=DevArray(st["terminal"]))
+                sets.append(st)
+            self._stage[size] = sets + [0]
         sets = self._stage[size]
         sets[2] ^= 1
         return sets[sets[2]]
@@ -335,13 +377,20 @@ class ReplayBuffer:
         import torch
 
         st = self._staging(int(slots.size))
-        st["slots"].copy_(torch.from_numpy(np.ascontiguousarray(slots, np.int32)))
+        from slimdqn import _hip
+
+        if st["slots_ev"] is None:
+            st["slots_ev"] = torch.cuda.Event()
+        else:  # the set's previous upload (two samples ago) has long passed; make sure
+            st["slots_ev"].synchronize()
+        st["slots_np"][:] = slots
+        _hip.check(_hip.lib().replay_add_frame(st["slots"].data_ptr(), 0, 4 * int(slots.size), st["slots_pin"].data_ptr(),
+                                               _hip.current_stream()), "replay_add_frame")
+        st["slots_ev"].record()
         return self._gather_device(st["slots"], st)
 
     def _gather_device(self, slots_dev, st=None) -> ReplayElement:
         """Stacked gather for slots that are already on the device (int32 tensor): no host round trip."""
-        import torch
-
         from slimdqn import _hip
 
         size = int(slots_dev.numel())
@@ -349,23 +398,13 @@ class ReplayBuffer:
         st = st if st is not None else self._staging(size)
         if slots_dev.data_ptr() != st["slots"].data_ptr():
             st["slots"].copy_(slots_dev)
+        if "gargs" not in st:
+            st["gargs"] = (_hip.ptr(self._meta_dev), _hip.ptr(st["slots"]), size, _hip.ptr(st["state"]), _hip.ptr(st["next_state"]),
+                           _hip.ptr(st["action"]), _hip.ptr(st["reward"]), _hip.ptr(st["terminal"]))
         _hip.check(_hip.lib().replay_gather_stacked(
-            _hip.ptr(self._frames), self._n_frames, self._frame_elems, self._itemsize, self._stack_size,
-            _hip.ptr(self._meta_dev), _hip.ptr(st["slots"]), size, _hip.ptr(st["state"]), _hip.ptr(st["next_state"]),
-            _hip.ptr(st["action"]), _hip.ptr(st["reward"]), _hip.ptr(st["terminal"]), _hip.current_stream()),
-            "replay_gather_stacked")
-        tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
-               np.dtype(np.float64): torch.float64, np.dtype(np.int64): torch.int64,
-               np.dtype(np.int32): torch.int32}[np.dtype(self._obs_dtype)]
-        shape = (size,) + tuple(self._obs_shape)
-        return ReplayElement(
-            state=DevArray(st["state"].view(tdt).view(shape)),
-            action=DevArray(st["action"]),
-            reward=DevArray(st["reward"]),
-            next_state=DevArray(st["next_state"].view(tdt).view(shape)),
-            is_terminal=DevArray(st["terminal"]),
-            episode_end=DevArray(st["terminal"]),
-        )
+            _hip.ptr(self._frames), self._n_frames, self._frame_elems, self._itemsize, self._stack_size, *st["gargs"],
+            _hip.current_stream()), "replay_gather_stacked")
+        return st["element"]
 
     def sample(self, size=None) -> ReplayElement:
         assert self.add_count, ValueError("No samples in replay buffer!")

@@ -229,7 +229,8 @@ int replay_gather_scalars(const int32_t* action_store_dev, const float* reward_s
                           void* stream);
 /* ReplayBuffer.add, device half (replay_buffer.py:206-213 keeps transitions on the host): the newest frame, staged in
  * PINNED host memory, is copied asynchronously into slot `slot` of the frame ring in HBM.  The staging slot may be
- * reused once the stream has passed this copy.                                                                        */
+ * reused once the stream has passed this copy.  The host mirror also sends the new element rows and the sampled slot
+ * indices this way (slot 0 of a byte range: frame_ring_dev = destination, frame_bytes = length).                      */
 int replay_add_frame(void* frame_ring_dev, int64_t slot, int64_t frame_bytes, const void* frame_host_pinned, void* stream);
 /* Growth of the frame ring (no reference counterpart: the reference's host dict grows by itself,
  * replay_buffer.py:206-213): the live frames, transition indices [first_t, first_t + count), are copied from slot
