@@ -1390,9 +1390,18 @@ struct AdamArgs {
     long gP, w0_begin, w0_end, g_w0_base;  // gradient arena layout (GradLayout in qnet.hip)
     int K, n_seg;               // n_seg > 0: the conv leaves' gradients are still per-chunk slabs (fused path):
     SlabSeg seg[3];             // sum them here (fixed chunk order) instead of a separate reduce launch
+    // step epilogue of the two-phase (data-parallel) step, or nullptr: count += 1 (optax count, idqn.py:53) and
+    // cum_losses += losses in f64 (idqn.py:72), by one thread per head -- this launch reads bcinv, not count
+    int32_t* ep_count;
+    const float* ep_losses;
+    double* ep_cum;
 };
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int k = blockIdx.y;
+    if (a.ep_count && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.ep_count[k] += 1;
+        a.ep_cum[k] = a.ep_cum[k] + (double)a.ep_losses[k];
+    }
     // FOUR lanes per float4 of parameters: where the gradient is still per-chunk slabs (the conv leaves on the fused path),
     // each lane sums every fourth chunk, up to 8 loads in flight, and the four partial sums are combined in a
     // fixed order, ((l0 + l1) + (l2 + l3)) -- one latency round instead of npc / 8 (Conv_0 has 51 chunks).  Lane 0 of the

@@ -168,7 +168,7 @@ struct idqn_handle_s {
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
     float* dpart = nullptr;  // partial Dense_0 data gradients of the fused weight-gradient kernel [n_jt][K * nb][F][32]
-    float *dh = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
+    float *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
     float *act_a[3] = {nullptr, nullptr, nullptr}, *act_part = nullptr;  // single-state acting path (act_kernels.h)
     hipStream_t act_stream = nullptr;  // capture stream of the acting graphs
@@ -190,6 +190,7 @@ struct idqn_handle_s {
     // plane conv path (convp.h; the default): packed weight planes per net, plane dout buffers, per-position dy sums
     bool planes = true;
     unsigned short *da3p = nullptr, *da2p = nullptr, *da1p = nullptr;
+    int dh_nb = 0;  // batch blocks of the step that last wrote dL/dh (debug buffer "dh")
     unsigned short* fact_planes = nullptr;  // bf16 planes of the gathered Dense_0 factors (factored data-parallel step)
     long fact_planes_cap = 0;               // in sample blocks
     float* pbuf[3] = {nullptr, nullptr, nullptr};  // [K * nb][OH * OW][CO] of conv layer i
@@ -247,6 +248,12 @@ int alloc_zero16(unsigned short** p, long n, idqn_handle_s* h, const char* name)
     return IDQN_OK;
 }
 
+// dL/dh [K][nb][J][32] of a batch of nb blocks: ends where the training set's a3 begins (netset_alloc)
+float* dh_of(idqn_handle_s* h, int nb) {
+    h->dh_nb = nb;
+    return h->train.a3 - (long)h->cfg.n_heads * nb * h->J * 32;
+}
+
 // step timeline: an event on the stream after the launch just made (name = nullptr: start of a step)
 void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
     if (!h->tl_on || h->tl_used >= (int)h->tl_ev.size()) return;
@@ -280,7 +287,17 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
         if ((rc = alloc_zero(&s.a1, (long)n_nets * nb * h->ga1.block, h, (t + "a1").c_str()))) return rc;
         if ((rc = alloc_zero(&s.a2, (long)n_nets * nb * h->ga2.block, h, (t + "a2").c_str()))) return rc;
     }
-    if ((rc = alloc_zero(&s.a3, (long)n_nets * nb * h->ga3.block, h, (t + "a3").c_str()))) return rc;
+    {
+        // The training set's a3 (online nets first) sits directly behind the dL/dh area: for a batch of nb blocks dL/dh is
+        // placed so that it ENDS where a3 begins, and [dL/dh | a3 of the K online nets] is one contiguous run -- the two
+        // factors of the Dense_0 gradient a data-parallel rank sends (idqn_dense0_factors) without copying them anywhere.
+        const long front = (&s == &h->train) ? (long)h->cfg.n_heads * nb * h->J * 32 : 0;
+        const long n_a3 = (long)n_nets * nb * h->ga3.block;
+        float* base = nullptr;
+        if ((rc = alloc_zero(&base, front + n_a3, h, (t + "a3_block").c_str()))) return rc;
+        s.a3 = base + front;
+        h->dbg.push_back({t + "a3", {(void*)s.a3, n_a3 * 4}});
+    }
     if ((rc = alloc_zero(&s.part, (long)n_nets * nb * s.NS * h->J * 32, h, (t + "part").c_str()))) return rc;
     return IDQN_OK;
 }
@@ -378,7 +395,6 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&p, 16, h, "act_action"))) return rc;
         h->act_action = (int32_t*)p;
     }
-    if ((rc = alloc_zero(&h->dh, (long)K * nb * h->J * 32, h, "dh"))) return rc;
     if (h->J % 256 == 0 && (rc = alloc_zero(&h->dpart, (long)(h->J / 256) * K * nb * h->F * 32, h, "dpart"))) return rc;
     if (!h->planes) {
         if ((rc = alloc_zero(&h->da3, (long)K * nb * h->gda3.block, h, "da3"))) return rc;
@@ -935,8 +951,9 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     return IDQN_OK;
 }
 
-int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, hipStream_t q) {
+int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, hipStream_t q, bool epilogue = false) {
     AdamArgs a;
+    a.ep_count = epilogue ? h->count : nullptr; a.ep_losses = h->losses; a.ep_cum = h->cum;
     a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
     a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
     a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
@@ -1098,7 +1115,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     } ta.nb = nb; ta.J = h->J; ta.A = h->cfg.n_actions;
     ta.B = B; ta.Bdiv = Bdiv; ta.action = action; ta.reward = reward; ta.terminal = terminal; ta.gamma_n = h->gamma_n;
     ta.prof = (h->cprof && h->cprof_role == 9) ? (long long*)h->cprof : nullptr;
-    ta.dh = h->dh; ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
+    ta.dh = dh_of(h, nb); ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
@@ -1120,7 +1137,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg;
     if (!fuse_dg) {
         DenseDgradArgs dd;
-        dd.dh = h->dh; dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
+        dd.dh = dh_of(h, nb); dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
         dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
         // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
         const long wg4 = (long)K * nb * cdiv(dd.n_ft, 4), wg3 = (long)K * nb * cdiv(dd.n_ft, 3);
@@ -1140,7 +1157,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         return IDQN_OK;
     }
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
-    int rcw = launch_dense0_wgrad(h, s.a3, h->dh, nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
+    int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
     if (fuse_dg) {
@@ -1403,7 +1420,17 @@ extern "C" int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, fl
     const long nb = cdiv(h->pend_B, 32), K = h->cfg.n_heads;
     // the online nets are the first K * nb slots of the activation buffer
     IDQN_HIP_CHECK(hipMemcpyAsync(a3_out_dev, h->train.a3, (size_t)K * nb * h->F * 32 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    IDQN_HIP_CHECK(hipMemcpyAsync(dh_out_dev, h->dh, (size_t)K * nb * h->J * 32 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    IDQN_HIP_CHECK(hipMemcpyAsync(dh_out_dev, dh_of(h, (int)nb), (size_t)K * nb * h->J * 32 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return IDQN_OK;
+}
+
+extern "C" int idqn_dense0_factors(idqn_handle_t h, float** factors_dev, int64_t* n_dh, int64_t* n_a3) {
+    IDQN_REQUIRE(h && factors_dev && n_dh && n_a3, "idqn_dense0_factors: null pointer");
+    IDQN_REQUIRE(h->pend_stage == 1 && h->pend_B > 0, "idqn_dense0_factors: needs IDQN_F_STOP_BEFORE_DENSE0_WGRAD first");
+    const int nb = cdiv(h->pend_B, 32);
+    *factors_dev = dh_of(h, nb);
+    *n_dh = (int64_t)h->cfg.n_heads * nb * h->J * 32;
+    *n_a3 = (int64_t)h->cfg.n_heads * nb * h->F * 32;
     return IDQN_OK;
 }
 
@@ -1426,8 +1453,8 @@ extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_de
     if (phases & IDQN_FACTORED_REST) {
         IDQN_REQUIRE(h->pend_stage == 3, "idqn_finish_step_factored: the Dense_0 phase has to come first");
         h->pend_stage = 0;
-        if ((rc = launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q))) return rc;  // every other leaf, from grad_dev
-        return step_epilogue(h, true, q);
+        // every other leaf, from grad_dev; count += 1 and cum_losses += losses ride in the same launch
+        return launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q, h->cfg.arch == IDQN_ARCH_CNN);
     }
     return IDQN_OK;
 }
@@ -1647,6 +1674,12 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
 
 extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {
     IDQN_REQUIRE(h && name && ptr_dev && nbytes, "idqn_debug_buffer: null pointer");
+    if (!strcmp(name, "dh") && h->cfg.arch == IDQN_ARCH_CNN && h->dh_nb > 0) {  // placed per batch size (dh_of)
+        const int nb = h->dh_nb;
+        *ptr_dev = (void*)dh_of(h, nb);
+        *nbytes = (int64_t)h->cfg.n_heads * nb * h->J * 32 * 4;
+        return IDQN_OK;
+    }
     for (auto& e : h->dbg)
         if (e.first == name) {
             *ptr_dev = e.second.first;

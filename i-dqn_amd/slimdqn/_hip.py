@@ -47,6 +47,7 @@ SYMBOLS = {
     "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
     "idqn_backward_rest": (C.c_int, [_P, _P]),
     "idqn_export_dense0_factors": (C.c_int, [_P, _P, _P, _P]),
+    "idqn_dense0_factors": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [C.c_uint32, _P]),
     "idqn_apply_adam": (C.c_int, [_P, _P]),
     "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
@@ -111,6 +112,21 @@ def check(rc, what=""):
 def ptr(t):
     """Device address of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _RawDeviceArray:
+    """Device memory owned by the library, presented through the CUDA array interface so that torch can alias it."""
+
+    def __init__(self, address, n_floats):
+        self.__cuda_array_interface__ = {"shape": (int(n_floats),), "typestr": "<f4", "data": (int(address), False),
+                                         "version": 2, "strides": None}
+
+
+def device_view(address, n_floats):
+    """float32 torch tensor over `n_floats` floats of library-owned device memory at `address` (no copy)."""
+    import torch
+
+    return torch.as_tensor(_RawDeviceArray(address, n_floats), device="cuda")
 
 
 def current_stream():

@@ -17,13 +17,15 @@ small ones.  ``IDQN_DP_OVERLAP=0`` falls back to one all-reduce of the whole are
 
 Factored mode (GPU, cnn path, the default): the Dense_0/kernel gradient is the outer product ``a3^T . dh`` over the
 samples, i.e. of rank <= global batch, far below its 7744 x 512 shape.  Ranks therefore ALL-GATHER the two factors
-(``a3``: K x 7744 x 32 floats, ``dh``: K x 512 x 32 floats -- 5.3 MB per rank at K=5) instead of all-reducing the
+(``a3``: K x 7744 x 32 floats, ``dh``: K x 512 x 32 floats -- 5.3 MB per rank at K=5, one contiguous run inside the
+library: nothing is copied before the collective) instead of all-reducing the
 79.3 MB product, and every rank runs the fused weight-gradient + Adam kernel over the gathered global batch: 4x
 (8 ranks) to 15x (2 ranks) fewer bytes over xGMI, the gradient is never materialised, and Adam stays fused.  The
 gather runs while ``idqn_backward_rest`` computes the conv backward; the 1.6 MB of small leaves (and the K losses)
 are all-reduced under the fused Dense_0 update, which needs only the gathered factors.  Every rank sums the same blocks in the same order, so replicas stay bit-identical.
 ``IDQN_DP_MODE=allreduce`` selects the all-reduce variants above.
 """
+import ctypes as C
 import os
 
 import torch.distributed as dist
@@ -42,15 +44,18 @@ def _factored_step(agent, shard, global_batch, group, extra_flags, serial=False)
     X, Y = F * 32, J * 32
     n_a3, n_dh = K * nb * X, K * nb * Y
     key = (world, nb)
-    if getattr(agent, "_factor_key", None) != key:  # exchange buffers, allocated once per (world, shard blocks)
-        dev = agent._grad.device
-        agent._fact_send = torch.empty(n_a3 + n_dh, dtype=torch.float32, device=dev)  # [a3 | dh] of this rank
-        agent._fact_all = torch.empty(world * (n_a3 + n_dh), dtype=torch.float32, device=dev)  # [rank][a3 | dh]
-        agent._factor_key = key
-    send, gathered = agent._fact_send, agent._fact_all
+    if getattr(agent, "_factor_key", None) != key:  # gathered factors, allocated once per (world, shard blocks)
+        agent._fact_all = torch.empty(world * (n_a3 + n_dh), dtype=torch.float32, device=agent._grad.device)  # [rank][dh | a3]
+        agent._factor_key, agent._fact_send = key, None
+    gathered = agent._fact_all
     agent._learn(shard, flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD | extra_flags, mean_divisor=global_batch)
-    _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()),
-               "idqn_export_dense0_factors")
+    # this rank's factors: dL/dh directly in front of the online nets' a3 inside the library -- one contiguous run, no copy
+    p, c_dh, c_a3 = C.c_void_p(), C.c_int64(), C.c_int64()
+    _hip.check(lib.idqn_dense0_factors(agent._handle, C.byref(p), C.byref(c_dh), C.byref(c_a3)), "idqn_dense0_factors")
+    assert (c_dh.value, c_a3.value) == (n_dh, n_a3)
+    if agent._fact_send is None or agent._fact_send.data_ptr() != p.value:
+        agent._fact_send = _hip.device_view(p.value, n_dh + n_a3)
+    send = agent._fact_send
     work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)  # ONE collective for both factors
     if serial:  # test mode: no collective overlaps any kernel (the stream-race stress compares the two bit for bit)
         work.wait()
@@ -63,7 +68,7 @@ def _factored_step(agent, shard, global_batch, group, extra_flags, serial=False)
         small.wait()
         torch.cuda.synchronize()
     work.wait()
-    args = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), world * nb, nb, n_a3 + n_dh, nb * X, X,
+    args = (agent._handle, _hip.ptr(gathered[n_dh:]), _hip.ptr(gathered), world * nb, nb, n_a3 + n_dh, nb * X, X,
             n_a3 + n_dh, nb * Y, Y)
     # the 80 us Dense_0 update needs only the gather: it runs while the small all-reduce is still in flight
     _hip.check(lib.idqn_finish_step_factored(*args, _hip.FACTORED_DENSE0, q()), "idqn_finish_step_factored")

@@ -117,6 +117,11 @@ int idqn_backward_rest(idqn_handle_t h, void* stream);
  * Block bb of the gathered buffers lives at (bb / nb_inner) * outer + head * head_stride + (bb % nb_inner) * inner
  * (strides in floats); a plain all_gather of the exported buffers gives outer = K*nb*X, head = nb*X, inner = X.   */
 int idqn_export_dense0_factors(idqn_handle_t h, float* a3_out_dev, float* dh_out_dev, void* stream);
+/* The same two factors WITHOUT a copy: the library keeps dL/dh [K][nb][J*32] directly in front of the online nets' a3
+ * [K][nb][F*32], so one contiguous run of n_dh + n_a3 floats at *factors_dev is what a rank contributes to the
+ * all-gather (valid from the IDQN_F_STOP_BEFORE_DENSE0_WGRAD call until the next step; ordered behind that call's
+ * stream).  In the gathered buffer dh_all = gathered, a3_all = gathered + n_dh, outer stride = n_dh + n_a3.          */
+int idqn_dense0_factors(idqn_handle_t h, float** factors_dev, int64_t* n_dh, int64_t* n_a3);
 #define IDQN_FACTORED_DENSE0 1u
 #define IDQN_FACTORED_REST 2u
 int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const float* dh_all_dev, int32_t nb_total,
