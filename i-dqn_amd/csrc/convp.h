@@ -77,7 +77,9 @@ struct CWgradArgs {
     const unsigned short* x;    // forward input planes of the conv
     const unsigned short* dy;   // gradient w.r.t. the conv's output, planes [K][nb][...] zero-bordered
     const float* pb;            // [K * nb][OH * OW][CO] sums of dy over the samples (bias gradient) or nullptr
-    const CWItem* items;
+    // work items (no table: a workgroup derives its item from its index, like the forward kernels): n_chunks balanced
+    // chunks of the OH * OW positions; index order (head, chunk, kernel row) or, chunk_major, (chunk, head, kernel row)
+    int n_chunks, chunk_major, kh_per_item;  // kh_per_item: kernel rows with an item of their own (Conv_0: 1)
     float* slab;                // [n_chunks][K][slab_stride]: weights [(kh, kw, ci)][co], then bias [co]
     long x_slot, dy_slot, slab_stride;  // bytes, bytes, floats
     int x_shared;               // 1: every head reads slot bb (Conv_0 reads the staged `state`), 0: slot k * nb + bb

@@ -31,7 +31,17 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
     const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool loader = wave8 >= 4;
     const int wave = wave8 & 3;
-    const CWItem it = a.items[b];  // the kernel rows of one chunk share an XCD
+    CWItem it;  // derived from the workgroup index (the kernel rows of one chunk are neighbours: they share an XCD)
+    {
+        const int kh = b % a.kh_per_item, r = b / a.kh_per_item;
+        const int o = a.chunk_major ? r / a.K : r / a.n_chunks, i = a.chunk_major ? r - o * a.K : r - o * a.n_chunks;
+        it.net = a.chunk_major ? i : o;
+        it.chunk = a.chunk_major ? o : i;
+        it.kh = kh;
+        const int npos = a.OH * a.OW, base = npos / a.n_chunks, rem = npos - base * a.n_chunks;
+        it.p0 = it.chunk * base + min(it.chunk, rem);
+        it.np = base + (it.chunk < rem ? 1 : 0);
+    }
     const int OW = a.OW, p0 = it.p0, p_end = it.p0 + it.np, k = it.net;
     const int dy_pix = 3 * a.CO * 64;
     // LDS stage: [x region][PG dy pixels]
@@ -114,6 +124,25 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
         // ---- loader waves: copy stage s + 1 while the compute waves work on stage s -----------------------------------
         int ibb = 0, ipos = p0, par = 0;
         stage(ibb, ipos, 0u);
+        // bias gradient of this chunk: the per-position sums of dy, added in (batch block, position) order -- by the first
+        // loader wave while the first stage travels (on a compute wave these loads sat in front of its MFMA loop)
+        if (wave == 0 && a.pb && (NPX == 1 || it.kh == 0)) {
+            float bsum = 0.f;
+            const int bcol = min(lane, a.CO - 1);
+            const int npos = a.OH * a.OW, n = it.np * a.nb;
+            for (int e0 = 0; e0 < n; e0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u, n - 1), bb = e / it.np, p = p0 + (e - bb * it.np);
+                    v[u] = a.pb[((long)(k * a.nb + bb) * npos + p) * a.CO + bcol];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < n) bsum += v[u];
+            }
+            if (lane < a.CO) (a.slab + ((long)it.chunk * a.K + k) * a.slab_stride)[(long)a.KH * a.KW * a.CI * a.CO + lane] = bsum;
+        }
         ipos += cnt_of(ipos);
         if (ipos >= p_end) { ipos = p0; ++ibb; }
         int cbb = 0, cpos = p0;  // mirrors the compute waves' progress (same barrier count)
@@ -138,26 +167,6 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    // bias gradient of this chunk: the per-position sums of dy, added in (batch block, position) order
-    // (wave-uniform branch; lanes past CO read a clamped column)
-    float bsum = 0.f;
-    const bool bias_wave = a.pb && (NPX == 1 || it.kh == 0) && wave == 0;
-    const int bcol = min(lane, a.CO - 1);
-    if (bias_wave) {
-        const int npos = a.OH * a.OW, n = it.np * a.nb;
-        for (int e0 = 0; e0 < n; e0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + u, n - 1), bb = e / it.np, p = p0 + (e - bb * it.np);
-                v[u] = a.pb[((long)(k * a.nb + bb) * npos + p) * a.CO + bcol];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (e0 + u < n) bsum += v[u];
-        }
-    }
 
     // Tile-steps of a stage, flattened: u = (position pp, k-step ks, tile i); the x fragments of tile-step u + 2 and the dy
     // fragments of the next (pp, ks) are requested in the gaps between the MFMAs of tile-step u (sched_barrier pins that);
@@ -257,7 +266,6 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
         for (int r = 0; r < 16; ++r)
             S[(row_base + tm[i] * 32 + mfma_row(r, h)) * a.CO + ct * 32 + cl] = acc[i][r] / a.out_div;
     }
-    if (bias_wave && lane < a.CO) S[(long)a.KH * a.KW * a.CI * a.CO + lane] = bsum;
 }
 
 

@@ -148,7 +148,7 @@ struct NetSet {
 // host-side plans of the plane conv launches: the work items of a launch depend only on geometry, net count and batch
 // blocks, so they are built once and kept on the device
 struct FwdPlan { int n_items = 0, NT = 0, ring = 2, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
-struct WgradPlan { CWItem* dev = nullptr; int n_items = 0, n_chunks = 0, MT = 0, PG = 0; size_t lds = 0; };
+struct WgradPlan { int n_items = 0, n_chunks = 0, chunk_major = 0, MT = 0, PG = 0; size_t lds = 0; };
 
 }  // namespace
 
@@ -689,26 +689,12 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunk
     IDQN_REQUIRE(pl.lds + 2048 <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
     // item order = workgroup order (the XCD-contiguous remap gives an XCD consecutive items): head-major, so that the kernel
     // rows of one chunk share its x / dy strips through L2; Conv_0 chunk-major, because its K heads read the SAME staged
-    // minibatch and a pixel strip then crosses the fabric once per XCD instead of once per head
-    std::vector<CWItem> items;
+    // minibatch and a pixel strip then crosses the fabric once per XCD instead of once per head.  The kernel derives its
+    // item (head, chunk, kernel row, balanced position range) from the workgroup index.
     static const bool net_major = getenv("IDQN_NET_MAJOR") != nullptr;  // A/B switch
-    const bool chunk_major = layer == 0 && !net_major;
-    std::vector<int> p0s(nch + 1, 0);
-    for (int c = 0; c < nch; ++c) p0s[c + 1] = p0s[c] + npos / nch + (c < npos % nch ? 1 : 0);
-    for (int o = 0; o < (chunk_major ? nch : K); ++o)
-        for (int i = 0; i < (chunk_major ? K : nch); ++i) {
-            const int k = chunk_major ? i : o, c = chunk_major ? o : i;
-            for (int kh = 0; kh < (layer == 0 ? 1 : l.K); ++kh) {
-                CWItem it;
-                memset(&it, 0, sizeof(it));
-                it.net = k; it.kh = kh; it.chunk = c; it.p0 = p0s[c]; it.np = p0s[c + 1] - p0s[c];
-                items.push_back(it);
-            }
-        }
-    pl.n_items = (int)items.size();
-    IDQN_HIP_CHECK(hipMalloc((void**)&pl.dev, sizeof(CWItem) * items.size()));
-    h->owned.push_back((void*)pl.dev);
-    IDQN_HIP_CHECK(hipMemcpy(pl.dev, items.data(), sizeof(CWItem) * items.size(), hipMemcpyHostToDevice));
+    pl.chunk_major = (layer == 0 && !net_major) ? 1 : 0;
+    pl.n_chunks = nch;
+    pl.n_items = K * nch * (layer == 0 ? 1 : l.K);
     (void)nb;
     if (getenv("IDQN_PLAN_PRINT"))
         fprintf(stderr, "[plan] wgrad layer %d: %d workgroups, %d chunks of ~%d positions, PG %d, MT %d, lds %zu B\n", layer,
@@ -841,7 +827,8 @@ int wgrad_args(idqn_handle_s* h, int layer, int nb, int n_chunks, CWgradArgs& a,
     const ActGeom* gx[3] = {&h->gx, &h->ga1, &h->ga2};
     const ActGeom* gd[3] = {&h->gda1, &h->gda2, &h->gda3};
     memset(&a, 0, sizeof(a));
-    a.x = xs[layer]; a.dy = dys[layer]; a.pb = h->pbuf[layer]; a.items = pl->dev; a.slab = h->slab + h->slab_off[layer];
+    a.x = xs[layer]; a.dy = dys[layer]; a.pb = h->pbuf[layer]; a.slab = h->slab + h->slab_off[layer];
+    a.n_chunks = pl->n_chunks; a.chunk_major = pl->chunk_major; a.kh_per_item = layer == 0 ? 1 : l.K;
     const int npx = layer == 0 ? 1 : 3;
     a.x_slot = gx[layer]->block * 2 * npx; a.dy_slot = gd[layer]->block * 6; a.slab_stride = h->slab_stride[layer];
     a.x_shared = layer == 0 ? 1 : 0;
