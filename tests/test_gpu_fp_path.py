@@ -499,6 +499,37 @@ def test_factored_step_sums_blocks_of_several_ranks():
     assert agent._count.cpu().numpy().tolist() == [1] * K
 
 
+def test_factor_view_is_the_exported_factors():
+    """idqn_dense0_factors (zero-copy: dL/dh directly in front of the online nets' a3 inside the library) shows exactly the
+    floats idqn_export_dense0_factors copies out, for one and for two sample blocks per rank."""
+    import ctypes as C
+
+    import torch
+
+    from slimdqn import _hip
+
+    lib = _hip.lib()
+    for name in ("cnn_atari_k5", "cnn_atari_a18_b64"):
+        agent, bs, _, _ = _agent(name)
+        K = agent._K
+        F, J = next(shape for n, _, shape in agent._leaves if n == "Dense_0/kernel")
+        nb = -(-len(np.asarray(bs[0].action)) // 32)
+        n_a3, n_dh = K * nb * F * 32, K * nb * J * 32
+        agent._learn(bs[0], flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD)
+        a3 = torch.empty(n_a3, dtype=torch.float32, device="cuda")
+        dh = torch.empty(n_dh, dtype=torch.float32, device="cuda")
+        _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(a3), _hip.ptr(dh), _hip.current_stream()), "export")
+        p, c_dh, c_a3 = C.c_void_p(), C.c_int64(), C.c_int64()
+        _hip.check(lib.idqn_dense0_factors(agent._handle, C.byref(p), C.byref(c_dh), C.byref(c_a3)), "idqn_dense0_factors")
+        assert (c_dh.value, c_a3.value) == (n_dh, n_a3)
+        view = _hip.device_view(p.value, n_dh + n_a3)
+        torch.cuda.synchronize()
+        assert torch.equal(view[:n_dh], dh) and torch.equal(view[n_dh:], a3)
+        assert float(dh.abs().sum()) > 0 and float(a3.abs().sum()) > 0
+        _hip.check(lib.idqn_backward_rest(agent._handle, _hip.current_stream()), "rest")  # leave no step half done
+        torch.cuda.synchronize()
+
+
 def test_head_window_agent_equals_rows_of_the_full_agent():
     """Head-parallel mode: an agent holding heads [first, first + count) of a K-head i-DQN
     starts from the same parameters as those rows of the single-device agent and, fed the same minibatches, follows
