@@ -1486,7 +1486,8 @@ extern "C" int idqn_target_sync(idqn_handle_t h, void* stream) {
 }
 
 // argmax over the actions of each row, first maximum on ties (jnp.argmax, idqn.py:131)
-__global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t* __restrict__ out) {
+__global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t* __restrict__ out, volatile int32_t* mail,
+                              unsigned* seq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int best = 0;
@@ -1496,6 +1497,13 @@ __global__ void k_argmax_rows(const float* __restrict__ q, int n, int A, int32_t
         if (v > bv) { bv = v; best = ac; }
     }
     out[i] = best;
+    if (mail && i == 0) {  // host mailbox of idqn_act_host (see k_act_head): the action, then the number that announces it
+        const unsigned nn = seq[0] + 1u;
+        seq[0] = nn;
+        mail[0] = best;
+        __threadfence_system();
+        mail[1] = (int32_t)nn;
+    }
 }
 
 static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
@@ -1560,7 +1568,8 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
         hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
         if (action_out_dev)
-            hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev);
+            hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev,
+                               (volatile int32_t*)(h->act_use_mail ? h->act_mail_dev : nullptr), h->act_seq);
     }
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
@@ -1584,15 +1593,22 @@ extern "C" int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, co
 extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
                              int32_t* action_host_pinned, void* stream) {
     IDQN_REQUIRE(h && state_host_pinned && q_out_dev && action_host_pinned, "idqn_act_host: null pointer");
-    IDQN_REQUIRE(h->cfg.arch == IDQN_ARCH_CNN, "idqn_act_host: the cnn path only (fc states are a few floats: idqn_best_action)");
     IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_act_host: bad head / which");
     hipStream_t q = (hipStream_t)stream;
-    const size_t E = (size_t)h->cfg.obs_h * h->cfg.obs_w * h->cfg.obs_c;
+    const bool cnn = h->cfg.arch == IDQN_ARCH_CNN;
+    // bytes of one state: uint8 pixels (cnn) or float32 features (fc)
+    const size_t E = cnn ? (size_t)h->cfg.obs_h * h->cfg.obs_w * h->cfg.obs_c : (size_t)h->fc.d[0] * 4;
+    if (!h->act_state) {  // (fc handles: a few floats)
+        IDQN_HIP_CHECK(hipMalloc((void**)&h->act_state, E + 64));
+        h->owned.push_back((void*)h->act_state);
+        IDQN_HIP_CHECK(hipMalloc((void**)&h->act_action, 64));
+        h->owned.push_back((void*)h->act_action);
+    }
     // The single-state path ends in a kernel that can write the action straight into mapped host memory, followed by a
     // sequence number the host polls (IDQN_ACT_POLL=0: a device-to-host copy and a stream synchronisation instead).
     static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
     static const bool no_poll = getenv("IDQN_ACT_POLL") && atoi(getenv("IDQN_ACT_POLL")) == 0;
-    const bool poll = !no_poll && !act_generic && h->J <= 512 && h->cfg.n_actions <= 32;
+    const bool poll = !no_poll && (cnn ? (!act_generic && h->J <= 512 && h->cfg.n_actions <= 32) : true);
     if (poll && !h->act_mail) {
         IDQN_HIP_CHECK(hipHostMalloc((void**)&h->act_mail, 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(h->act_mail, 0, 64);

@@ -192,14 +192,15 @@ class DeviceAgent:
         """Greedy action (device int32 scalar, first maximum on ties) of one head for one state: one C call.
         A host state goes through a pinned staging buffer (a pageable 28 KB upload costs ~100 us, this ~10)."""
         dt = torch.uint8 if self._arch == "cnn" else torch.float32
-        if isinstance(state, torch.Tensor) and state.is_cuda:
-            s = self._dev(state, dt)
-        elif self._arch == "cnn":
+        st = getattr(state, "tensor", state)
+        if isinstance(st, torch.Tensor) and st.is_cuda:
+            s = self._dev(st, dt)
+        else:
             # a host state: ONE C call uploads it from pinned memory, runs the single-state path, brings the action back
             # and synchronises (what the reference's select_action does with its blocking `.item()`)
             if not hasattr(self, "_act_pin"):
                 n = int(np.prod(self._obs))
-                self._act_pin = torch.empty(n, dtype=torch.uint8).pin_memory()
+                self._act_pin = torch.empty(n, dtype=dt).pin_memory()
                 self._act_pin_np = self._act_pin.numpy()
                 self._act_out = torch.zeros(4, dtype=torch.int32).pin_memory()
                 self._act_out_np = self._act_out.numpy()
@@ -211,8 +212,6 @@ class DeviceAgent:
                                                 _hip.ptr(self._q_out), C.c_void_p(self._act_out.data_ptr()),
                                                 _hip.current_stream()), "idqn_act_host")
             return _HostAction(int(self._act_out_np[0]))
-        else:
-            s = self._dev(state, dt)  # fc: a handful of floats
         assert s.numel() == int(np.prod(self._obs)), "best_action takes a single state"
         self._ensure_handle(32)
         self._keep_q = s
