@@ -387,6 +387,220 @@ __global__ __launch_bounds__(FC_T) void k_fc_step_lds(FcArgs a, int tw, int wfl)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same step on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered sums), for nets whose
+// largest weight matrix fits LDS whole (the LunarLander sizes: 131 KB).  The LDS kernel above spends its time in LDS
+// reads -- one weight and eight broadcast activations per eight FMAs: 92 us for an 11 k-parameter head.  Here every layer
+// is a handful of 32 x 32 tiles:
+//   activations and deltas are kept TRANSPOSED, [feature][32 samples] with a 33-float pitch, the staged weight matrix
+//   [in][out] with an odd pitch: every MFMA operand is one conflict-free ds_read_b32 per lane, whichever of the three
+//   contractions (forward: k = in; weight gradient: k = sample; data gradient: k = out) it serves;
+//   tiles past a matrix edge read finite junk or staged zeros and their results are not written (the buffers are zeroed
+//   once: nothing that is not finite ever gets into LDS, so 0 x junk stays 0).
+// One 512-thread workgroup per head, tiles dealt round-robin to its 8 waves.
+// ---------------------------------------------------------------------------------------------------
+#define FCM_T 512
+#define FCM_BSP 33  // sample pitch of the transposed activations
+struct FcMfmaPlan {
+    int ldw, drows;   // weight pitch (odd), rows of a delta / ping-pong buffer
+    long w_floats, floats;  // floats of the weight buffer; total LDS floats (0: the net does not fit)
+};
+static inline FcMfmaPlan fc_mfma_plan(const FcNet& n) {
+    FcMfmaPlan p;
+    int dinmax = 0, doutmax = 0;
+    for (int l = 0; l < n.L; ++l) { dinmax = std::max(dinmax, n.d[l]); doutmax = std::max(doutmax, n.d[l + 1]); }
+    const int c32 = (doutmax + 31) / 32 * 32;
+    p.ldw = c32 + 1;
+    p.w_floats = (long)(dinmax + 1) * p.ldw;
+    p.drows = (n.dmax + 31) / 32 * 32;
+    // [weights][L + 1 activation buffers of dmax rows][2 delta buffers of drows rows][32 rows of slack for edge tiles][qmax, sq, misc]
+    p.floats = p.w_floats + (long)(n.L + 1) * n.dmax * FCM_BSP + 2L * p.drows * FCM_BSP + 32L * FCM_BSP + 96;
+    if (p.floats * 4 > FC_LDS_BUDGET) p.floats = 0;
+    return p;
+}
+
+// W [din][dout] (global) -> Wl [din + 1][ldw]: valid elements, zeros in the columns up to the next multiple of 32 and in
+// row din (the k padding of an odd din / the n padding of the last column tile)
+__device__ __forceinline__ void fcm_stage_w(const float* W, float* Wl, int din, int dout, int ldw) {
+    const int c32 = (dout + 31) / 32 * 32;
+    for (int e = threadIdx.x; e < (din + 1) * c32; e += FCM_T) {
+        const int i = e / c32, o = e - i * c32;
+        Wl[i * ldw + o] = (i < din && o < dout) ? W[(long)i * dout + o] : 0.f;
+    }
+    __syncthreads();
+}
+
+// outT[o][b] = (relu?)(bias[o] + sum_i inT[i][b] * W[i][o]): tiles of 32 columns o, k = i in pairs
+__device__ __forceinline__ void fcm_forward(const float* inT, const float* Wl, const float* bias, float* outT, int din,
+                                            int dout, int ldw, bool relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    const int ks = (din + 1) / 2;
+    for (int ct = wave; ct * 32 < dout; ct += FCM_T / 64) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* A = inT + h * FCM_BSP + bl;          // A[b = bl][k = 2 s + h]
+        const float* Bp = Wl + h * ldw + ct * 32 + bl;    // B[k = 2 s + h][col = ct * 32 + bl]
+        for (int s0 = 0; s0 < ks; ++s0) acc = mfma32(A[2 * s0 * FCM_BSP], Bp[2 * s0 * ldw], acc);
+        const int col = ct * 32 + bl;
+        if (col < dout) {
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r] + bv;
+                outT[col * FCM_BSP + mfma_row(r, h)] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int drows, long w_floats) {
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    const FcNet& n = a.net;
+    const int B = a.B, A = n.d[n.L], dm = n.dmax;
+    float* Wl = fl;
+    float* acts = Wl + w_floats;                         // [L + 1][dm][BSP]
+    float* dA = acts + (long)(n.L + 1) * dm * FCM_BSP;   // [drows][BSP]
+    float* dB = dA + (long)drows * FCM_BSP;
+    float* qmax = dB + (long)(drows + 32) * FCM_BSP;     // behind the slack rows
+    float* sq = qmax + 32;
+    float* lsum = sq + 32;
+    const float* po = a.online + (long)k * a.P;
+    const float* pt = a.target + (long)k * a.P;
+    float* G = a.grad + (long)k * a.P;
+    for (long e = t; e < (qmax - fl) + 96; e += FCM_T) fl[e] = 0.f;  // nothing but finite numbers ever lives in this LDS
+    __syncthreads();
+    const int nb = (B + 31) / 32;
+    for (int bb = 0; bb < nb; ++bb) {
+        const int b0 = bb * 32, nbk = min(32, B - b0);
+        // ---- inputs of the block, transposed (rows past the batch end are zero inputs; they carry no loss weight)
+        for (int e = t; e < 32 * n.d[0]; e += FCM_T) {
+            const int b = e / n.d[0], i = e - b * n.d[0];
+            dA[i * FCM_BSP + b] = b < nbk ? a.s2[(long)(b0 + b) * n.d[0] + i] : 0.f;
+            acts[i * FCM_BSP + b] = b < nbk ? a.s[(long)(b0 + b) * n.d[0] + i] : 0.f;
+        }
+        __syncthreads();
+        // ---- target net on s'
+        float *cur = dA, *nxt = dB;
+        for (int l = 0; l < n.L; ++l) {
+            fcm_stage_w(pt + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
+            fcm_forward(cur, Wl, pt + n.b_off[l], nxt, n.d[l], n.d[l + 1], ldw, l != n.L - 1);
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (t < 32) {  // max over actions, in action order
+            float m = -INFINITY;
+            for (int ac = 0; ac < A; ++ac) m = fmaxf(m, cur[ac * FCM_BSP + t]);
+            qmax[t] = m;
+        }
+        for (int e = t; e < nbk * A; e += FCM_T) a.q_dbg[((long)(a.K + k) * B + b0) * A + e] = cur[(e % A) * FCM_BSP + e / A];
+        __syncthreads();
+        // ---- online net on s, activations kept
+        for (int l = 0; l < n.L; ++l) {
+            fcm_stage_w(po + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
+            fcm_forward(acts + (long)l * dm * FCM_BSP, Wl, po + n.b_off[l], acts + (long)(l + 1) * dm * FCM_BSP, n.d[l], n.d[l + 1],
+                        ldw, l != n.L - 1);
+        }
+        const float* q = acts + (long)n.L * dm * FCM_BSP;  // [A][BSP]
+        for (int e = t; e < nbk * A; e += FCM_T) a.q_dbg[((long)k * B + b0) * A + e] = q[(e % A) * FCM_BSP + e / A];
+        // ---- TD error, loss, dL/dq  (idqn.py:111-124)
+        float* delta = dA;
+        if (t < 32) {
+            const int b = t;
+            float sqv = 0.f, g = 0.f;
+            int ac = 0;
+            if (b < nbk) {
+                const int bg = b0 + b;
+                const float tgt = a.reward[bg] + (float)(1 - (int)a.terminal[bg]) * a.gamma_n * qmax[b];
+                ac = a.action[bg];
+                const float td = q[ac * FCM_BSP + b] - tgt;
+                const float wgt = a.is_weight ? a.is_weight[bg] : 1.0f;
+                if (a.td_abs) a.td_abs[(long)k * B + bg] = fabsf(td);
+                sqv = wgt * td * td;
+                g = 2.0f * wgt * td / (float)a.Bdiv;
+            }
+            for (int o = 0; o < A; ++o) delta[o * FCM_BSP + b] = (o == ac) ? g : 0.f;
+            sq[b] = sqv;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float s = lsum[0];
+            for (int b = 0; b < 32; ++b) s += sq[b];
+            lsum[0] = s;
+        }
+        // ---- backward of the block; the gradient arena accumulates over blocks.  Wl holds the online matrix of layer L - 1.
+        float* dprev = dB;
+        for (int l = n.L - 1; l >= 0; --l) {
+            const int din = n.d[l], dout = n.d[l + 1];
+            const float* inT = acts + (long)l * dm * FCM_BSP;
+            if (l != n.L - 1) fcm_stage_w(po + n.w_off[l], Wl, din, dout, ldw);
+            // gW[i][o] = sum_b inT[i][b] * delta[o][b]: tiles of 32 rows i x 32 columns o, k = the 32 samples
+            const int nti = (din + 31) / 32, nto = (dout + 31) / 32;
+            for (int tile = wave; tile < nti * nto; tile += FCM_T / 64) {
+                const int ti = tile / nto, to = tile - ti * nto;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* Ap = inT + (long)(ti * 32 + bl) * FCM_BSP + h;    // A[i = bl][k = b = 2 s + h]
+                const float* Bp = delta + (long)(to * 32 + bl) * FCM_BSP + h;  // B[k = b][o = bl]
+#pragma unroll
+                for (int s0 = 0; s0 < 16; ++s0) acc = mfma32(Ap[2 * s0], Bp[2 * s0], acc);
+                const int o = to * 32 + bl;
+                if (o < dout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = ti * 32 + mfma_row(r, h);
+                        if (i < din) {
+                            float* g = G + n.w_off[l] + (long)i * dout + o;
+                            *g = bb == 0 ? acc[r] : *g + acc[r];
+                        }
+                    }
+                }
+            }
+            for (int o = t; o < dout; o += FCM_T) {  // bias gradient, in sample order
+                float s = 0.f;
+                for (int b = 0; b < 32; ++b) s += delta[o * FCM_BSP + b];
+                float* g = G + n.b_off[l] + o;
+                *g = bb == 0 ? s : *g + s;
+            }
+            if (l > 0) {
+                // dprev[i][b] = relu'(in[i][b]) * sum_o delta[o][b] * W[i][o]: tiles of 32 columns i, k = o in pairs
+                const int ks = (dout + 1) / 2;
+                for (int ti = wave; ti * 32 < din; ti += FCM_T / 64) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    const float* Ap = delta + h * FCM_BSP + bl;                  // A[b = bl][k = o = 2 s + h]
+                    const float* Bp = Wl + (long)(ti * 32 + bl) * ldw + h;       // B[k = o][i = bl]   (rows past din: junk, not written)
+                    for (int s0 = 0; s0 < ks; ++s0) acc = mfma32(Ap[2 * s0 * FCM_BSP], Bp[2 * s0], acc);
+                    const int i = ti * 32 + bl;
+                    if (i < din) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int b = mfma_row(r, h);
+                            dprev[i * FCM_BSP + b] = inT[i * FCM_BSP + b] > 0.f ? acc[r] : 0.f;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            float* tmp = delta; delta = dprev; dprev = tmp;
+        }
+    }
+    if (t == 0) {
+        const float s = lsum[0];
+        a.losses[k] = s / (float)a.Bdiv;
+        const double tt = (double)(a.count[k] + 1);
+        a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.adam_b1, tt));
+        a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.adam_b2, tt));
+        if (a.finish_step) {
+            a.count[k] += 1;
+            a.cum[k] = a.cum[k] + (double)(s / (float)a.Bdiv);
+        }
+    }
+}
+
 // Q-values of one net for n states (inference)
 struct FcQArgs {
     FcNet net;

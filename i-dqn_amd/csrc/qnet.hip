@@ -207,6 +207,7 @@ struct idqn_handle_s {
     FcNet fc;
     float* fc_ws = nullptr;
     FcPlan fc_plan_;  // LDS plan of k_fc_step_lds (BS = 0: the net does not fit and the generic kernel runs)
+    FcMfmaPlan fcm_plan_;  // LDS plan of k_fc_step_mfma (floats = 0: the largest weight matrix does not fit LDS whole)
     // timeline of a whole step (IDQN_F_PROFILE_ALL): one event after every launch; idqn_profile_table averages per name
     std::vector<hipEvent_t> tl_ev;
     std::vector<const char*> tl_name;
@@ -482,6 +483,11 @@ int fc_setup(idqn_handle_s* h) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
+    h->fcm_plan_ = fc_mfma_plan(n);
+    if (getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA")) h->fcm_plan_.floats = 0;  // A/B switches
+    if (h->fcm_plan_.floats)
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(h->fcm_plan_.floats * 4)));
     h->dominant = "k_fc_step";
     return IDQN_OK;
 }
@@ -1380,7 +1386,9 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
         const FcPlan& fp = h->fc_plan_;
         const size_t lds = (size_t)fp.floats * 4;
-        if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
+        const FcMfmaPlan& fm = h->fcm_plan_;
+        if (fm.floats) hipLaunchKernelGGL(k_fc_step_mfma, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
+        else if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else if (fp.BS == 16) hipLaunchKernelGGL(k_fc_step_lds<16>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else if (fp.BS == 8) hipLaunchKernelGGL(k_fc_step_lds<8>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else hipLaunchKernelGGL(k_fc_step, dim3(h->cfg.n_heads), dim3(256), 0, q, a);
