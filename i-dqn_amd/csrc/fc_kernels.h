@@ -623,3 +623,42 @@ __global__ __launch_bounds__(256) void k_fc_q(FcQArgs a) {
     const int A = n.d[n.L];
     for (int e = t; e < a.n * A; e += 256) a.q_out[e] = cur[(long)(e / A) * dm + e % A];
 }
+
+// One state (acting): the same forward with the k index of every layer cut into 8 slices, one per wave -- a lane's loads of
+// a slice (<= 64 rows) are all in flight at once and coalesced along the output row; the slices are added in order.
+// (k_fc_q walks each dot product as one chain of dependent fmas over global loads: 19 us for the LunarLander net.)
+__global__ __launch_bounds__(512) void k_fc_q1(FcQArgs a) {
+    __shared__ float x[2][FC_MAX_WIDTH];
+    __shared__ float part[8][FC_MAX_WIDTH];
+    const FcNet& n = a.net;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int e = t; e < n.d[0]; e += 512) x[0][e] = a.s[e];
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < n.L; ++l) {
+        const int din = n.d[l], dout = n.d[l + 1];
+        const float* W = a.params + n.w_off[l];
+        const int per = (din + 7) / 8, i0 = wave * per, i1 = min(din, i0 + per);  // per <= 64 (widths <= 512)
+        for (int o = lane; o < dout; o += 64) {
+            float s = 0.f;
+            for (int ib = i0; ib < i1; ib += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = ib + u < i1 ? W[(long)(ib + u) * dout + o] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = fmaf(ib + u < i1 ? x[cur][ib + u] : 0.f, w[u], s);
+            }
+            part[wave][o] = s;
+        }
+        __syncthreads();
+        for (int o = t; o < dout; o += 512) {
+            float s = a.params[n.b_off[l] + o];
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += part[w8][o];
+            x[cur ^ 1][o] = l != n.L - 1 ? fmaxf(s, 0.f) : s;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int e = t; e < n.d[n.L]; e += 512) a.q_out[e] = x[cur][e];
+}

@@ -1574,7 +1574,8 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         FcQArgs a;
         a.net = h->fc; a.params = params; a.s = (const float*)states_dev; a.n = n; a.q_out = q_out_dev;
         a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
-        hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
+        if (n == 1) hipLaunchKernelGGL(k_fc_q1, dim3(1), dim3(512), 0, q, a);  // acting: one state
+        else hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
         if (action_out_dev)
             hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev,
                                (volatile int32_t*)(h->act_use_mail ? h->act_mail_dev : nullptr), h->act_seq);
