@@ -20,6 +20,32 @@
 #include <type_traits>
 #include "convp.h"
 
+// Cache policy of the Dense_0 streams (tools/probes/mall_policy_probe.hip, profiles/r3_mall_policy_probe.txt): a
+// default-policy read that comes behind dirty lines in the memory-side cache pays for their write-back (2.8 instead of
+// 6.3 TB/s); a non-temporal read does not allocate, evicts nothing and runs at 5.6-7.0 TB/s in either state.
+//   D0_FWD_NT  1: the forward pass streams W (read once per step and net) non-temporally
+//   D0_WG_NT   bit 0: theta / m / v loads of the fused update non-temporal; bit 1: its stores
+#ifndef D0_FWD_NT
+#define D0_FWD_NT 1
+#endif
+#ifndef D0_WG_NT
+#define D0_WG_NT 3
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float* p) {
+    if (NT) {
+        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, const float4& v) {
+    if (NT) __builtin_nontemporal_store((f32x4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v*>(p));
+    else *reinterpret_cast<float4*>(p) = v;
+}
+
 struct ActGeom {
     int H, W, C;        // logical extent
     int lo_h, lo_w;     // zero border before the first row / column
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
     float xv[4][8];
 #define D3_LOAD(c, s)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
-        wv[s][jj] = *reinterpret_cast<const float4*>(W + ((long)(c) * step_rows + jj) * a.J);         \
+        wv[s][jj] = ld4<D0_FWD_NT != 0>(W + ((long)(c) * step_rows + jj) * a.J);                      \
         xv[s][jj] = X[((long)(c) * step_rows + jj) * 32];                                             \
     }
 #define D3_TILE(s, q, comp)                                                                    \
@@ -990,9 +1016,9 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const long on = o0 + (long)(RPI * d) * a.J;
-            th[d] = *reinterpret_cast<const float4*>(a.theta + on);
-            mm[d] = *reinterpret_cast<const float4*>(a.mu + on);
-            vv[d] = *reinterpret_cast<const float4*>(a.nu + on);
+            th[d] = ld4<(D0_WG_NT & 1) != 0>(a.theta + on);
+            mm[d] = ld4<(D0_WG_NT & 1) != 0>(a.mu + on);
+            vv[d] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
         }
     }
     f32x16 acc[NQ];
@@ -1064,18 +1090,18 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             if (FUSE_DG) *reinterpret_cast<float4*>(gp) = t4;  // theta BEFORE the update takes the consumed gradient's place
             if (i + DEPTH < NIT) {  // the slot just read is re-filled DEPTH row groups ahead, before the (may-alias) stores
                 const long on = o0 + (long)(RPI * (i + DEPTH)) * a.J;
-                th[s] = *reinterpret_cast<const float4*>(a.theta + on);
-                mm[s] = *reinterpret_cast<const float4*>(a.mu + on);
-                vv[s] = *reinterpret_cast<const float4*>(a.nu + on);
+                th[s] = ld4<(D0_WG_NT & 1) != 0>(a.theta + on);
+                mm[s] = ld4<(D0_WG_NT & 1) != 0>(a.mu + on);
+                vv[s] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
             }
             adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
             adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
             adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
             adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
             const long o = o0 + (long)(RPI * i) * a.J;
-            *reinterpret_cast<float4*>(a.theta + o) = t4;
-            *reinterpret_cast<float4*>(a.mu + o) = m4;
-            *reinterpret_cast<float4*>(a.nu + o) = v4;
+            st4<(D0_WG_NT & 2) != 0>(a.theta + o, t4);
+            st4<(D0_WG_NT & 2) != 0>(a.mu + o, m4);
+            st4<(D0_WG_NT & 2) != 0>(a.nu + o, v4);
         }
     } else {
         const long g0 = a.g_w0_base + (long)k * a.g_w0_stride + (long)(f0 + prow) * a.J + j0 + pcol;

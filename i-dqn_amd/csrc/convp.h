@@ -193,3 +193,18 @@ int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_
                       const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
 int convp_fwd_max_nt(int CT);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: the launchers keep one high-water mark per device and
+// kernel instantiation (a process that creates handles on a second GPU must set it there too).
+struct LdsAttrMark {
+    size_t bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // true: the attribute has to be raised to `want` on the current device
+    bool needs(size_t want) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;  // (unknown device: always set)
+        if (want <= bytes[dev]) return false;
+        bytes[dev] = want;
+        return true;
+    }
+};
+

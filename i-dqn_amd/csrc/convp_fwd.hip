@@ -15,10 +15,9 @@ __global__ __launch_bounds__(512) void k_cfwd(CFwdArgs a, unsigned stage_bytes, 
 template <int NPA, int CT, int NQ, int NT>
 int launch_one(const CFwdArgs& a, int n_items, size_t stage_bytes, int ring, size_t lds_bytes, hipStream_t q, long long* prof) {
     const unsigned mask_off = (unsigned)convp_fwd_mask_off(stage_bytes, NT, ring, a.out3 != nullptr, a.out_f32 != nullptr);
-    static size_t attr = 0;  // per instantiation
-    if (lds_bytes > attr) {
+    static LdsAttrMark attr;  // per instantiation
+    if (attr.needs(lds_bytes)) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cfwd<NPA, CT, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = lds_bytes;
     }
     hipLaunchKernelGGL((k_cfwd<NPA, CT, NQ, NT>), dim3((unsigned)n_items), dim3(512), lds_bytes, q, a, (unsigned)stage_bytes, ring, mask_off, prof);
     IDQN_HIP_CHECK(hipGetLastError());

@@ -46,11 +46,10 @@ int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_l
     // every XCD needs at least as many blocks as data-gradient blocks: true whenever the weight gradient has >= 8 items
     static const bool role_xcds = getenv("IDQN_PAIR_ROLE_XCDS") != nullptr;  // A/B switch: roles on separate XCDs
     const int split_xcd = (!role_xcds && n_w >= 8) ? 1 : 0;
-    static size_t attr = 0;  // per instantiation
-    if (lds > attr) {
+    static LdsAttrMark attr;  // per instantiation
+    if (attr.needs(lds)) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cpair<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
     }
     hipLaunchKernelGGL((k_cpair<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>), dim3((unsigned)(n_f + n_w)), dim3(512), lds, q, f,
                        (unsigned)f_stage, ring, mask_off, n_f, prof, w, (unsigned)(w_lds / 2), MT, split_xcd);

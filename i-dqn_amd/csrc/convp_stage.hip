@@ -51,10 +51,12 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
         return;
     }
     const long pb = (long)blockIdx.x - a.n_prep_blocks;
-    if (pb == 0 && a.bcinv && t < a.K) {
-        const double tt = (double)(a.count[t] + 1);
-        a.bcinv[2 * t] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
-        a.bcinv[2 * t + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+    if (pb == 0 && a.bcinv) {
+        for (int k = t; k < a.K; k += 256) {  // (any number of heads)
+            const double tt = (double)(a.count[k] + 1);
+            a.bcinv[2 * k] = 1.0f / (1.0f - (float)pow((double)a.b1, tt));
+            a.bcinv[2 * k + 1] = 1.0f / (1.0f - (float)pow((double)a.b2, tt));
+        }
     }
     int ji = 0;
 #pragma unroll

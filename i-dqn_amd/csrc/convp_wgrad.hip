@@ -11,10 +11,9 @@ __global__ __launch_bounds__(512) void k_cwgrad(CWgradArgs a, unsigned stage_byt
 
 template <int NPX, int CT, int NTW, int PG>
 int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipStream_t q) {
-    static size_t attr = 0;
-    if (lds_bytes > attr) {
+    static LdsAttrMark attr;  // per instantiation
+    if (attr.needs(lds_bytes)) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cwgrad<NPX, CT, NTW, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 2048));
-        attr = lds_bytes;
     }
     hipLaunchKernelGGL((k_cwgrad<NPX, CT, NTW, PG>), dim3((unsigned)n_items), dim3(512), lds_bytes + 2048, q, a, (unsigned)(lds_bytes / 2), MT);
     IDQN_HIP_CHECK(hipGetLastError());

@@ -29,6 +29,13 @@ struct ConvL {
     long w_off, b_off;
 };
 
+// CUs the conv launches of the step are planned for (one 512-thread workgroup per CU, all co-resident).  IDQN_CUS < 256
+// leaves the rest of the chip to a concurrent stream (the overlapped Dense_0 update, tools/probes/overlap_cumask.py).
+int cu_budget() {
+    static const int n = getenv("IDQN_CUS") ? std::max(16, std::min(256, atoi(getenv("IDQN_CUS")))) : 256;
+    return n;
+}
+
 void same_pad(int i, int k, int s, int* out, int* lo, int* hi) {
     *out = (i + s - 1) / s;
     int p = (*out - 1) * s + k - i;
@@ -223,6 +230,7 @@ struct idqn_handle_s {
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
+    hipEvent_t d0_wait = nullptr;  // experiment hook: the training forward waits for this event in front of its Dense_0 launch
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
@@ -338,9 +346,8 @@ int cnn_setup(idqn_handle_s* h) {
     // what matters is that EVERY CU streams and that they all stream the same amount: as many 4-wave workgroups as CUs,
     // never more (a 257th would stream alone after the others), with balanced splits of the F / 32 row units
     {
-        const int units = h->F / 32, wgs_per_split = 2 * c.n_heads * (c.features[3] / 128) / 4 > 0 ? 2 * c.n_heads * (c.features[3] / 128) : 1;
+        const int units = h->F / 32;
         int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
-        (void)wgs_per_split;
         if (const char* e = getenv("IDQN_D0_SPLITS")) ns = atoi(e);
         h->NS = std::max(1, std::min(std::min(ns, 64), units));
     }
@@ -442,7 +449,7 @@ int cnn_setup(idqn_handle_s* h) {
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
             const int per_chunk = K * (i == 0 ? 1 : cl.K);
-            int nch = 256 / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
+            int nch = cu_budget() / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
             if (const char* e = getenv("IDQN_WCHUNKS")) nch = atoi(e);
             if (const char* e = getenv("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
             h->npc[i] = std::max(1, std::min(nch, npos));
@@ -654,18 +661,18 @@ int plan_fwd_target(int role, int n_nets, int nb, const RoleGeom& g, int target,
 // workgroups per CU instead (80 KB of LDS each), so that one's prologue / first fill / epilogue overlaps the other's main
 // loop -- measured: Conv_0 forward 18.8 -> 18.5 us, Conv_1 data gradient 16.9 -> 21.7 us (more weight re-staging per
 // MFMA, a two-deep ring); not the default.
-int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out, int target = 256) {
+int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out, int target) {
     auto key = std::make_tuple(role, n_nets, nb, target);
     auto itp = h->fwd_plans.find(key);
     if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
     static const int forced = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 0;
     FwdPlan pl;
     int rc = IDQN_E_INVALID;
-    if (forced > 256 && target == 256) {
+    if (forced > 256 && target == cu_budget()) {
         rc = plan_fwd_target(role & 7, n_nets, nb, g, forced ? forced : 512, 80 * 1024, pl);
         if (!rc && pl.NT < 2 && !forced) rc = IDQN_E_INVALID;  // items too small to be worth two per CU
     }
-    if (rc) rc = plan_fwd_target(role & 7, n_nets, nb, g, target != 256 ? target : (forced && forced <= 256 ? forced : 256), 160 * 1024, pl);
+    if (rc) rc = plan_fwd_target(role & 7, n_nets, nb, g, target != cu_budget() ? target : (forced && forced <= 256 ? forced : target), 160 * 1024, pl);
     if (rc) return rc;
     if (getenv("IDQN_PLAN_PRINT"))
         fprintf(stderr, "[plan] fwd role %d nets %d nb %d target %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
@@ -690,7 +697,7 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunk
         const long XB = layer == 0 ? (long)l.K * (pl.PG + 1) * 1024 : ((pl.PG - 1) * l.S + l.K) * x_pix;
         pl.lds = (size_t)(2 * (XB + pl.PG * dy_pix));
         if (pl.lds + 2048 <= 160 * 1024 || pl.PG == 1) break;
-        if (layer == 0) --pl.PG;  // Conv_0: 4 or 2 positions
+        if (layer == 0 && pl.PG > 2) --pl.PG;  // Conv_0: 4, 2 or 1 positions (never 0)
     }
     IDQN_REQUIRE(pl.lds + 2048 <= 160 * 1024, "plane wgrad: layer %d needs %zu bytes of LDS", layer, pl.lds);
     // item order = workgroup order (the XCD-contiguous remap gives an XCD consecutive items): head-major, so that the kernel
@@ -817,7 +824,7 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     CFwdArgs a;
     RoleGeom g;
     FwdPlan* pl;
-    int rc = conv_args(h, s, role, nb, 256, a, g, pl);
+    int rc = conv_args(h, s, role, nb, cu_budget(), a, g, pl);
     if (rc) return rc;
     return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->ring, pl->lds, q, conv_prof(h, s, role, pl));
 }
@@ -868,7 +875,7 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) 
         const char* e = getenv(nm);
         return e ? atoi(e) : dflt;
     };
-    const int d_target = knob("IDQN_PAIR_D", 128);
+    const int d_target = knob("IDQN_PAIR_D", cu_budget() / 2);
     NetSet& s = h->train;
     const int role = layer == 2 ? 3 : 4, K = h->cfg.n_heads;
     const ConvL& l = h->conv[layer];
@@ -877,13 +884,13 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) 
     FwdPlan* pf;
     int rc = conv_args(h, s, role, nb, d_target, f, g, pf);
     if (rc) return rc;
-    const int n_chunks = std::min(knob("IDQN_PAIR_C", 1 << 20), (256 - pf->n_items) / (K * l.K));  // what is left of the chip, in whole position chunks
+    const int n_chunks = std::min(knob("IDQN_PAIR_C", 1 << 20), (cu_budget() - pf->n_items) / (K * l.K));  // what is left of the chip, in whole position chunks
     if (n_chunks < 1) return IDQN_OK;
     CWgradArgs w;
     WgradPlan* pw;
     if ((rc = wgrad_args(h, layer, nb, n_chunks, w, pw))) return rc;
     const int WCT = l.CO / 32, ntw = (pw->MT * WCT + 3) / 4;
-    if (pf->n_items + pw->n_items > 256 || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
+    if (pf->n_items + pw->n_items > cu_budget() || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
     h->npc_used[layer] = pw->n_chunks;
     *done = true;
     return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT, pw->n_items,
@@ -932,6 +939,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
                 hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
         }
     }
+    if (&s == &h->train && h->d0_wait) IDQN_HIP_CHECK(hipStreamWaitEvent(q, h->d0_wait, 0));
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
@@ -1112,7 +1120,8 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
-    ta.bcinv_done = h->planes ? 1 : 0;
+    static const bool stage_part = getenv("IDQN_STAGE_PART") && atoi(getenv("IDQN_STAGE_PART")) == 1;  // (timing experiment: no packing blocks)
+    ta.bcinv_done = (h->planes && !stage_part) ? 1 : 0;
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
         WtBuildArgs wb;
@@ -1357,6 +1366,13 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             auto key = std::make_tuple(state_dev, next_state_dev, (const void*)action_dev, (const void*)reward_dev,
                                        (const void*)terminal_dev, (int)batch, (int)batch_mean_divisor,
                                        (const void*)h->is_weight, (const void*)h->td_abs);
+            // bounded: a caller that hands over allocator-recycled buffers would otherwise instantiate a graph per pointer
+            // tuple that ever recurs; past 32 keys everything is dropped and the cache starts again
+            if (h->step_graphs.size() >= 32 && !h->step_graphs.count(key)) {
+                for (auto& g : h->step_graphs)
+                    if (g.second.second) (void)hipGraphExecDestroy(g.second.second);
+                h->step_graphs.clear();
+            }
             auto& ent = h->step_graphs[key];
             if (ent.first++ == 0) return issue(q);
             if (!ent.second) {
@@ -1365,10 +1381,15 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
                 IDQN_HIP_CHECK(hipStreamBeginCapture(h->act_stream, hipStreamCaptureModeRelaxed));
                 rc = issue(h->act_stream);
                 const hipError_t e = hipStreamEndCapture(h->act_stream, &graph);
-                if (rc) return rc;
-                IDQN_HIP_CHECK(e);
-                IDQN_HIP_CHECK(hipGraphInstantiate(&ent.second, graph, nullptr, nullptr, 0));
-                IDQN_HIP_CHECK(hipGraphDestroy(graph));
+                if (rc || e != hipSuccess) {  // nothing of a failed capture is kept
+                    if (graph) (void)hipGraphDestroy(graph);
+                    h->step_graphs.erase(key);
+                    if (rc) return rc;
+                    IDQN_HIP_CHECK(e);
+                }
+                const hipError_t ei = hipGraphInstantiate(&ent.second, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ei != hipSuccess) { h->step_graphs.erase(key); IDQN_HIP_CHECK(ei); }
             }
             IDQN_HIP_CHECK(hipGraphLaunch(ent.second, q));
             return IDQN_OK;
@@ -1451,6 +1472,13 @@ extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_de
         // every other leaf, from grad_dev; count += 1 and cum_losses += losses ride in the same launch
         return launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q, h->cfg.arch == IDQN_ARCH_CNN);
     }
+    return IDQN_OK;
+}
+
+// experiment hook (not part of include/idqn_hip.h): see idqn_handle_s::d0_wait
+extern "C" int idqn_x_set_dense0_wait_event(idqn_handle_t h, void* event) {
+    IDQN_REQUIRE(h, "idqn_x_set_dense0_wait_event: null handle");
+    h->d0_wait = (hipEvent_t)event;
     return IDQN_OK;
 }
 

@@ -145,9 +145,12 @@ int idqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* stat
 int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
                      float* q_out_dev, int32_t* action_out_dev, void* stream);
 
-/* The greedy branch of select_action for ONE uint8 state in PINNED host memory (slimdqn/sample_collection/utils.py:8-21:
- * upload, `best_action`, blocking `.item()`): the action of head `head` lands in action_host_pinned[0] and the stream has
- * been synchronised when the call returns; q_out_dev receives the A Q-values.  cnn only.  After the first call per (net,
+/* The greedy branch of select_action for ONE state in PINNED host memory (slimdqn/sample_collection/utils.py:8-21:
+ * upload, `best_action`, blocking `.item()`): uint8 pixels for the cnn, float32 features for the fc arch.  The action of
+ * head `head` is in action_host_pinned[0] when the call returns; q_out_dev receives the A Q-values (device memory,
+ * ordered on `stream` like any other result).  By default the last kernel writes the action into a mapped host mailbox
+ * that the call polls, so it returns WITHOUT a stream synchronisation (work queued on `stream` behind it may still be
+ * running); IDQN_ACT_POLL=0 restores a device-to-host copy plus hipStreamSynchronize.  After the first call per (net,
  * buffers) the whole sequence is replayed as one hipGraph (IDQN_ACT_GRAPH=0: eager).                                   */
 int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
                   int32_t* action_host_pinned, void* stream);
@@ -206,9 +209,10 @@ int per_priorities_from_td(const float* td_abs_dev, int32_t n_heads, int32_t n, 
                            double alpha, double* priorities_out_dev, double* max_priority_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Replay store in HBM (slimdqn/sample_collection/replay_buffer.py:202-230).  One slot holds one
- * ReplayElement's state and next_state back to back: [2][obs_bytes]; slot = key % capacity (keys
- * are the monotonically increasing add_count and eviction is FIFO, :206-213).
+ * Replay store in HBM (slimdqn/sample_collection/replay_buffer.py:202-230).  The store the product uses is the
+ * frame ring described next (frames written once, elements are 8-int32 rows, slot = key % capacity: keys are the
+ * monotonically increasing add_count and eviction is FIFO, :206-213); replay_gather further down serves stores that
+ * keep whole (state, next_state) pairs per slot.
  * ---------------------------------------------------------------------------------------- */
 /* Frame-ring replay store (the layout ReplayBuffer uses): every environment frame is written to HBM once, at ring
  * slot (transition index % n_frames) of frames_dev [n_frames][frame_elems * itemsize]; a replay element is one row

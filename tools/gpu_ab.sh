@@ -1,5 +1,5 @@
 # A/B of two builds of the library: bash tools/gpu_ab.sh <libA.so> <libB.so>   (paths relative to the repo root)
-mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for lib in "$@"; do
   tag=$(basename $lib .so)
   IDQN_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 300 --warmup 50 --no-cpu-baseline > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err && python -c "

@@ -1,5 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rm -rf gpurun_out/trace_dp1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_dp1 -- python bench.py --gpus 1 --force-dp --no-cpu-baseline --repeats 1 --steps 60 --warmup 20 > gpurun_out/trace_dp1.log 2>&1
 python - <<'PY'

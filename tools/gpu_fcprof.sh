@@ -1,5 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 rm -rf gpurun_out/prof_fc; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_fc -- python tools/bench_fc.py > gpurun_out/prof_fc.log 2>&1
 python - <<'PY'
 import csv,glob

@@ -1,6 +1,6 @@
 # End-of-round measurement set (one GPU call): default bench line, A=18 repeat, rocprofv3 kernel stats, PMC passes,
 # one-rank RCCL rehearsal of both data-parallel modes, head-parallel line, trainer loop.  Outputs under gpurun_out/final/.
-mkdir -p gpurun_out/final && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/final && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/final
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --actions 18 --no-cpu-baseline > $O/bench_a18.json 2> $O/bench_a18.err; echo "bench a18 rc=$?"
