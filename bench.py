@@ -108,6 +108,9 @@ def main():
                     help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
     ap.add_argument("--actions", type=int, default=N_ACTIONS, help="action count A (SURVEY 8d: 6, repeat with 18)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
+                    help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
+                         "has no quantile code), one GPU, its own JSON line")
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.heads_per_gpu) and "WORLD_SIZE" not in os.environ:
@@ -173,6 +176,8 @@ def main():
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
     if args.heads_per_gpu:
         return head_parallel_bench(args, rank, world, json_fd, Batch)
+    if args.algo == "iiqn":
+        return iiqn_bench(args, json_fd, Batch)
     A = args.actions
     agent = iDQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
@@ -306,6 +311,117 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()
+
+
+def iiqn_cpu_baseline(n_actions, n_quantiles, budget_s=12.0):
+    """The oracle's torch-CPU fp32 restatement of the i-IQN step (K heads one after the other: loss, autograd, Adam)."""
+    import torch
+
+    from oracle import iqn_ref as I
+    from oracle import qnet_ref as Q
+    from oracle import torch_ref as T
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    p = I.init_params(0, OBS, n_actions, FEATURES, K_HEADS)
+    pt = I.init_params(1, OBS, n_actions, FEATURES, K_HEADS)
+    mu = {n: np.zeros_like(a) for n, a in p.items()}
+    nu = {n: np.zeros_like(a) for n, a in p.items()}
+    s, a, r, s2, t = synthetic(0, n_actions)
+    batch = (s, a, r, s2, t.astype(bool))
+    taus = I.synthetic_taus(1, K_HEADS, n_quantiles, BATCH)
+
+    def step(count):
+        for k in range(K_HEADS):
+            _, g = T.iqn_loss_and_grads(Q.head(p, k), Q.head(pt, k), batch, tuple(taus[k]), 0.99, dtype=torch.float32)
+            for n in p:
+                p[n][k], mu[n][k], nu[n][k] = Q.adam_update(p[n][k], g[n], mu[n][k], nu[n][k], count, 6.25e-5, 1.5e-4, np.float32)
+
+    step(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(n + 1)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same K=5 B=32 N={n_quantiles} i-IQN step in {dt:.1f} s (oracle/torch_ref.iqn_loss_and_grads, "
+                      f"torch-CPU fp32 autograd + numpy Adam, {cores} threads; no reference implementation exists)"}
+
+
+def iiqn_bench(args, json_fd, Batch):
+    """BASELINE config 3: K=5 i-IQN heads, 32 quantile fractions (online / action selection / target), batch 32, one GPU."""
+    import ctypes as C
+
+    import torch
+
+    from slimdqn import _hip
+    from slimdqn.networks.iiqn import iIQN
+
+    A, N = args.actions, 32
+    agent = iIQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4, n_quantiles=N)
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i, A))) for i in range(8)]
+    it = [0]
+
+    def step(flags=0):
+        agent._learn(batches[it[0] % 8], flags=flags)  # draws the step's fractions on the host and uploads them (60 KB)
+        it[0] += 1
+
+    steps = min(args.steps, 100)
+    for _ in range(min(args.warmup, 10)):
+        step()
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    elapsed = float(np.median(regions))
+    for _ in range(10):
+        step(_hip.F_PROFILE_ALL)
+    torch.cuda.synchronize()
+    buf = C.create_string_buffer(8192)
+    _hip.check(_hip.lib().idqn_profile_table(agent._handle, buf, 8192), "idqn_profile_table")
+    kernels = []
+    for ln in buf.value.decode().splitlines():
+        nm, us, cnt = ln.split("\t")
+        kernels.append({"launch": nm, "us": float(us), "n": int(cnt)})
+    losses = agent._losses.cpu().numpy()
+    assert np.isfinite(losses).all(), losses
+    F, J = 7744, 512
+    rows = N * BATCH  # (sample, fraction) rows per virtual net
+    work = {  # f32-equivalent FLOPs of the contraction-bound launches (DESIGN.md, i-IQN section)
+        "iqn dense0 fwd": 2.0 * 3 * K_HEADS * rows * F * J,
+        "iqn dense0 dgrad": 2.0 * K_HEADS * rows * F * J,
+        "dense0 wgrad + adam": 2.0 * K_HEADS * rows * F * J,
+        "iqn embedding x features": 2.0 * 3 * K_HEADS * rows * 64 * F,
+        "iqn embedding backward": 2.0 * 3 * K_HEADS * rows * 64 * F,
+    }
+    dom = max(kernels, key=lambda k: k["us"]) if kernels else None
+    roof = None
+    if dom and dom["launch"] in work:
+        ach = work[dom["launch"]] / (dom["us"] * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": dom["launch"], "achieved": ach, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": ach / (MFMA_F32_PEAK / 1e12), "traffic": None, "launch_ms": dom["us"] * 1e-3,
+                "algorithmic_flops": work[dom["launch"]],
+                "note": "f32-equivalent FLOPs against the f32-rate MFMA peak; the contraction runs as exact bf16x3 products"}
+    out = {"metric": "i-IQN grad-steps/sec, Nature-CNN K=5 batch=32, 32 quantile samples", "value": steps / elapsed,
+           "unit": "grad-steps/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 10), "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Atari synthetic 84x84x4 uint8, i-IQN K=5 Nature-CNN [32,64,64,512] A={A}, batch 32, "
+                                  f"{N} online / {N} action-selection / {N} target fractions per sample (extension: the reference "
+                                  "has no quantile code; parity pinned to oracle/iqn_ref.py only)",
+                      "heads": K_HEADS, "batch_per_gpu": BATCH, "quantiles": N, "actions": A},
+           "timing": {"regions": args.repeats, "steps_per_region": steps, "reported": "median region",
+                      "ms_per_step_all": [r / steps * 1e3 for r in regions]},
+           "roofline": roof, "kernels": kernels, "final_losses": [float(x) for x in losses]}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = iiqn_cpu_baseline(A, N)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def head_parallel_bench(args, rank, world, json_fd, Batch):

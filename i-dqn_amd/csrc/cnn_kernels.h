@@ -20,31 +20,7 @@
 #include <type_traits>
 #include "convp.h"
 
-// Cache policy of the Dense_0 streams (tools/probes/mall_policy_probe.hip, profiles/r3_mall_policy_probe.txt): a
-// default-policy read that comes behind dirty lines in the memory-side cache pays for their write-back (2.8 instead of
-// 6.3 TB/s); a non-temporal read does not allocate, evicts nothing and runs at 5.6-7.0 TB/s in either state.
-//   D0_FWD_NT  1: the forward pass streams W (read once per step and net) non-temporally
-//   D0_WG_NT   bit 0: theta / m / v loads of the fused update non-temporal; bit 1: its stores
-#ifndef D0_FWD_NT
-#define D0_FWD_NT 1
-#endif
-#ifndef D0_WG_NT
-#define D0_WG_NT 3
-#endif
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ float4 ld4(const float* p) {
-    if (NT) {
-        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const float4*>(p);
-}
-template <bool NT>
-__device__ __forceinline__ void st4(float* p, const float4& v) {
-    if (NT) __builtin_nontemporal_store((f32x4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v*>(p));
-    else *reinterpret_cast<float4*>(p) = v;
-}
+#include "dense0_update.h"
 
 struct ActGeom {
     int H, W, C;        // logical extent
@@ -797,6 +773,7 @@ struct DenseDgradArgs {
     long w_off, n_items;
     int K, nb, n_ft, F, J, C;  // C = channels of a3 (f = pos*C + c)
     ActGeom g;                 // geometry of da3
+    float* raw;                // i-IQN: plain rows [K][nb][F][32] of W0 . dh, no mask, none of the outputs above (or nullptr)
 };
 
 template <int WAVES>  // f tiles (= waves) per workgroup: 4, or 3 when that fills the chip more evenly
@@ -854,6 +831,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
     if (!live) return;
     // this lane: row f = f0 + bl, samples (r & 3) + 8 (r >> 2) + 4 h
     const int f = f0 + bl;
+    if (a.raw) {
+        float* O = a.raw + (((long)k * a.nb + bb) * a.F + f) * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(O + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        return;
+    }
     const float* A3 = a.a3 + ((long)k * a.nb + bb) * a.F * 32 + (long)f * 32 + 4 * h;
     float4 mk[4];
 #pragma unroll
@@ -896,47 +880,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense0_dgrad(DenseDgradArgs a) {
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// Dense_0 weight gradient (+ optionally fused Adam): g[f][j] = sum_b a3[f][b] * dh[j][b]
-// HBM-bound: the output (and, fused, theta/m/v) is the 15.9 MB/head matrix; MFMA work is ~10 % of the time.
-// --------------------------------------------------------------------------------------------
-struct AdamConsts {
-    float lr_neg, b1, b2, omb1, omb2, eps;
-};
-// The reciprocal bias corrections 1 / (1 - b^t), t = count + 1, are computed ONCE per step and head
-// (k_td_dh / k_fc_step, one thread) into bcinv[k][2]; b^t is the correctly rounded f32 power of the
-// f32 base (double pow, then rounded).
-// optax.adam element update (idqn.py:106-107).  The bias corrections are multiplications by the
-// precomputed reciprocals and the final quotient uses the hardware sqrt / rcp (<= 2 ulp each): the
-// IEEE-exact division / sqrt expansions made the fused kernel VALU-bound (4.4 k instructions per
-// wave) while changing the update by < 1e-6 relative (~1e-11 absolute on a parameter).
-__device__ __forceinline__ void adam_elem(const AdamConsts& c, float rbc1, float rbc2, float g, float& th, float& m,
-                                          float& v) {
-    m = fmaf(c.omb1, g, c.b1 * m);
-    v = fmaf(c.omb2, g * g, c.b2 * v);
-    const float mh = m * rbc1, vh = v * rbc2;
-    const float d = __builtin_amdgcn_sqrtf(vh) + c.eps;
-    th = fmaf(c.lr_neg, mh * __builtin_amdgcn_rcpf(d), th);
-}
-
-struct DenseWgradArgs {
-    const float* a3;  // [2K][nb][F*32]
-    const float* dh;  // [K][nb][J][32]
-    float* grad;      // [K][P]
-    float *theta, *mu, *nu;
-    const float* bcinv;  // [K][2]
-    AdamConsts ad;
-    long w_off, P, n_items;
-    long g_w0_base, g_w0_stride;  // unfused output: grad + g_w0_base + k * g_w0_stride (contiguous over heads)
-    // sample block bb of head k: base + (bb / nb_inner) * outer + k * head + (bb % nb_inner) * inner   (floats)
-    long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
-    int K, nb, nb_inner, n_ft, n_jt, F, J;
-    float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
-    // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
-    // dhp[plane][bb][k][J * 32]
-    const unsigned short *a3p, *dhp;
-};
-
 // f32 factors of the Dense_0 gradient -> three exact bf16 planes (convp.h arithmetic), compact per (sample block, head).
 // The factored data-parallel step runs the fused update over the GLOBAL batch: its MFMA work grows with the number of
 // ranks while its HBM traffic does not (f32 MFMA: +16 us per extra sample block), so there the contraction runs on the
@@ -975,191 +918,10 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     *reinterpret_cast<uint2*>(dst + 2 * plane + e * 4) = make_uint2(q2a, q2b);
 }
 
-// Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
-// on the MFMA (2 accumulators, k = the 32 samples per batch block) and parks it in LDS.  Phase 2: all 256
-// threads stream the tile row by row -- every wave-instruction moves one whole 1 KB row segment of theta / m / v
-// (16 B per lane), the gradient comes from LDS -- exactly the access pattern of the plain Adam kernel, which
-// reaches 6.9 TB/s on MI355X.  The first version kept the tile in accumulators and ran Adam from the MFMA
-// layout at 2 waves/SIMD (5.3 TB/s); this one needs ~100 registers and 32 KB of LDS (4-5 workgroups per CU).
-#ifndef D0W_DEPTH
-#define D0W_DEPTH 4  // row groups of theta / m / v in flight per thread in the fused kernel's streaming phase
-#endif
-// FUSE_DG (with FUSE_ADAM): the workgroup also produces its column tile's share of the Dense_0 DATA gradient,
-//   dL/da3[f][b] += sum over its 256 columns j of theta_old[f][j] * dh[j][b],
-// from the theta rows that stream through its registers anyway -- the separate data-gradient kernel re-read all of
-// theta (79 MB per step at K = 5; a pure read stream runs at ~4 TB/s on this chip: 24 us).  Each thread parks the
-// pre-update theta float4 in the LDS slot whose gradient it has just consumed; after the streaming phase the four waves
-// run D'[b][f] over 64 columns each on the MFMA (B operand = theta from LDS, A operand = dh rows from L2), add their four
-// tiles in LDS and write the 4 KB partial.  k_da3_finalize sums the column tiles' partials and applies the ReLU mask.
-// The LDS tile's columns are rotated by 4 * row: the MFMA reads one column of 32 rows per instruction, which would hit a
-// single bank with a 256-float pitch (rotated: 4-way, 8 cycles per 64-cycle MFMA); float4 accesses stay aligned.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3>  // column tile JT = 128 * NQ (256 when the dense width allows it)
-__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats (+ 4096 FUSE_DG) */) {
-    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
-    static_assert(!FUSE_DG || (FUSE_ADAM && NQ == 2), "the fused data gradient rides on the fused 256-column kernel");
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    const int jt = item % a.n_jt;
-    item /= a.n_jt;
-    const int ft = item % a.n_ft;
-    const int k = item / a.n_ft;
-    const int f0 = ft * 32, j0 = jt * JT, jw = wave * (32 * NQ);
-    const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
-    // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
-    const int prow = wave * (64 / LPR) + lane / LPR, pcol = (lane % LPR) * 4;
-    const long o0 = base + (long)prow * a.J + pcol;
-    auto rot = [&](int row, int col) { return FUSE_DG ? row * JT + ((col + 4 * row) & (JT - 1)) : row * JT + col; };
-    // phase-2 state runs DEPTH row groups ahead (a ring of named-index registers): the rows of the first DEPTH
-    // iterations are requested before the MFMA phase, so the workgroup keeps streaming while it computes its tile
-    constexpr int DEPTH = D0W_DEPTH;
-    float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
-    if (FUSE_ADAM) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const long on = o0 + (long)(RPI * d) * a.J;
-            th[d] = ld4<(D0_WG_NT & 1) != 0>(a.theta + on);
-            mm[d] = ld4<(D0_WG_NT & 1) != 0>(a.mu + on);
-            vv[d] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
-        }
-    }
-    f32x16 acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    for (int bb = 0; bb < a.nb; ++bb) {
-        if (BF3) {
-            // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
-            const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
-            const unsigned short* Ap = a.a3p + slot * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
-            const unsigned short* Dp = a.dhp + slot * a.J * 32 + (long)(j0 + jw + bl) * 32 + 16 * h;
-            bf16x8 A[3][2];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) A[pl][s] = *reinterpret_cast<const bf16x8*>(Ap + pl * pa + 8 * s);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                bf16x8 B[3][2];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) B[pl][s] = *reinterpret_cast<const bf16x8*>(Dp + (long)q * 32 * 32 + pl * pd + 8 * s);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    acc[q] = mfma_bf16(A[2][s], B[0][s], acc[q]);
-                    acc[q] = mfma_bf16(A[0][s], B[2][s], acc[q]);
-                    acc[q] = mfma_bf16(A[1][s], B[1][s], acc[q]);
-                    acc[q] = mfma_bf16(A[1][s], B[0][s], acc[q]);
-                    acc[q] = mfma_bf16(A[0][s], B[1][s], acc[q]);
-                    acc[q] = mfma_bf16(A[0][s], B[0][s], acc[q]);
-                }
-            }
-            continue;
-        }
-        const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
-        const float* Ap = a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner + (long)(f0 + bl) * 32 + 16 * h;
-        float4 x0 = *reinterpret_cast<const float4*>(Ap), x1 = *reinterpret_cast<const float4*>(Ap + 4);
-        float4 x2 = *reinterpret_cast<const float4*>(Ap + 8), x3 = *reinterpret_cast<const float4*>(Ap + 12);
-        const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
-                              x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-        const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + bl) * 32 + 16 * h;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float* dq = Dp + (long)q * 32 * 32;  // columns jw + 32 q + bl
-            float4 y0 = *reinterpret_cast<const float4*>(dq), y1 = *reinterpret_cast<const float4*>(dq + 4);
-            float4 y2 = *reinterpret_cast<const float4*>(dq + 8), y3 = *reinterpret_cast<const float4*>(dq + 12);
-            const float bv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
-                                  y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[q] = mfma32(av[u], bv[u], acc[q]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gs[rot(mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
-    __syncthreads();
-    if (FUSE_ADAM) {
-        const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int s = i % DEPTH;
-            float* gp = &gs[rot(RPI * i + prow, pcol)];
-            const float4 g = *reinterpret_cast<const float4*>(gp);
-            float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
-            if (FUSE_DG) *reinterpret_cast<float4*>(gp) = t4;  // theta BEFORE the update takes the consumed gradient's place
-            if (i + DEPTH < NIT) {  // the slot just read is re-filled DEPTH row groups ahead, before the (may-alias) stores
-                const long on = o0 + (long)(RPI * (i + DEPTH)) * a.J;
-                th[s] = ld4<(D0_WG_NT & 1) != 0>(a.theta + on);
-                mm[s] = ld4<(D0_WG_NT & 1) != 0>(a.mu + on);
-                vv[s] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
-            }
-            adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
-            adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
-            adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
-            adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
-            const long o = o0 + (long)(RPI * i) * a.J;
-            st4<(D0_WG_NT & 2) != 0>(a.theta + o, t4);
-            st4<(D0_WG_NT & 2) != 0>(a.mu + o, m4);
-            st4<(D0_WG_NT & 2) != 0>(a.nu + o, v4);
-        }
-    } else {
-        const long g0 = a.g_w0_base + (long)k * a.g_w0_stride + (long)(f0 + prow) * a.J + j0 + pcol;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i)
-            *reinterpret_cast<float4*>(a.grad + g0 + (long)(RPI * i) * a.J) =
-                *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
-    }
-    if (FUSE_DG) {
-        __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
-        float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
-        for (int bb = 0; bb < a.nb; ++bb) {
-            const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
-            // A operand: dh^T, lane (b = bl, k = h) reads dh[j0 + jw + 2 t + h][b]; B operand: theta_old[f = bl][j = jw + 2 t + h]
-            const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + h) * 32 + bl;
-            f32x16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            float dv[2][8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dv[0][u] = Dp[(long)(2 * u) * 32];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 MFMA steps (16 columns each)
-                if (c + 1 < 4) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dv[(c + 1) & 1][u] = Dp[(long)(16 * (c + 1) + 2 * u) * 32];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int col = jw + 16 * c + 2 * u + h;
-                    d = mfma32(dv[c & 1][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
-                }
-            }
-            // this wave's tile -> LDS: lane = row f (bl), 4 x 4 consecutive samples per register quad
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(&red[wave * 1024 + bl * 32 + (((2 * g + h) ^ (bl & 7)) * 4)]) =
-                    make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
-            __syncthreads();
-            {   // all 256 threads: float4 t of the 32 x 32 tile = row t >> 3, slot t & 7; the four waves' tiles in wave order
-                const int row = t >> 3, slot = ((t & 7) ^ (row & 7)) * 4;
-                float4 s4 = *reinterpret_cast<const float4*>(&red[row * 32 + slot]);
-#pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const float4 y = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
-                    s4.x += y.x; s4.y += y.y; s4.z += y.z; s4.w += y.w;
-                }
-                float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
-                *reinterpret_cast<float4*>(O + t * 4) = s4;
-            }
-            __syncthreads();  // red is reused by the next batch block
-        }
-    }
-}
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 128 * NQ + (FUSE_DG ? 4096 : 0)];
-    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3>(a, blockIdx.x, gs);
+    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

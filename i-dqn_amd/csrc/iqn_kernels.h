@@ -1,0 +1,361 @@
+// gfx950 kernels of the i-IQN heads (BASELINE config 3) -- a LABELLED EXTENSION, parity unpinned: the reference snapshot
+// has no quantile code (/root/reference/README.md:3,10 only names i-IQN); oracle/iqn_ref.py states the algorithm
+// (implicit quantile network of Dabney et al. 2018 on the reference's conv trunk, the reference's chain of K heads) and its
+// sources.  Included by qnet.hip.
+//
+// Mapping onto the existing step: a (sample, quantile fraction) pair is one more "sample"; quantile index q of all 32
+// samples of the batch is one more 32-sample BLOCK, so the Dense_0 / hidden kernels of the plain step run unchanged over
+// V = 3K "virtual nets" (online k | target k for the action choice | target k for the values) x N blocks each:
+//   x[v][q][f][b] = psi[net(v)][f][b] * relu(sum_i cos(pi i tau[v][q][b]) * We[i][f] + be[f])       (k_iqn_cos, k_iqn_embed)
+//   k_dense0_fwd3 / k_hidden over (V, N) blocks  ->  Dense_1 partials
+//   k_iqn_loss   Z, a*, targets, the N' x N quantile Huber loss and dL/dZ                             (one workgroup per head)
+//   k_iqn_dh     dL/dh per block, Dense_1 / Dense_0-bias gradients
+//   k_dense0_dgrad (raw rows) -> k_iqn_embed_bwd: dL/dpsi (summed over the N fractions) and the embedding's gradients
+// then the plain step's conv backward, fused Dense_0 weight gradient + Adam (over the N blocks) and small-leaf Adam.
+#pragma once
+#include "cnn_kernels.h"
+
+constexpr int IQN_EMBED = 64;  // cos features per fraction (IQN paper, section 3; Dopamine quantile_embedding_dim)
+
+// cos(pi * i * tau), i = 1..64, evaluated in fp64 and rounded once: cosb[slot][i - 1][b].  tau: [K][3][N][B] (floats in
+// (0, 1)); slot = (type * K + k) * N + q.  Padded samples (b >= B) get tau = 0.5.
+struct IqnCosArgs {
+    const float* tau;
+    float* cosb;
+    int K, N, B;
+};
+__global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
+    const int slot = blockIdx.x, q = slot % a.N, v = slot / a.N, type = v / a.K, k = v - type * a.K;
+    const int b = threadIdx.x & 31;
+    const double tau = b < a.B ? (double)a.tau[(((long)k * 3 + type) * a.N + q) * a.B + b] : 0.5;
+    for (int i = threadIdx.x >> 5; i < IQN_EMBED; i += 8)
+        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = (float)cospi((double)(i + 1) * tau);
+}
+
+// x = psi * relu(We^T cos + be): one wave = one tile of 32 features x 32 samples of one (virtual net, fraction) block.
+struct IqnEmbedArgs {
+    const float* cosb;          // [V * N][64][32]
+    const float* const* wbase;  // [V] parameter base of the virtual net
+    const float* psi;           // trunk features [2K][F * 32] (training set: online nets first)
+    float* x;                   // [V * N][F][32]
+    long we_off, be_off;
+    int K, N, F;
+};
+__global__ __launch_bounds__(256) void k_iqn_embed(IqnEmbedArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int ft = blockIdx.x * 4 + wave;
+    if (ft >= a.F / 32) return;
+    const int slot = blockIdx.y, v = slot / a.N, type = v / a.K, k = v - type * a.K;
+    const int f0 = ft * 32;
+    const float* P = a.wbase[v];
+    const float* We = P + a.we_off + f0 + r;
+    const float* C = a.cosb + (long)slot * IQN_EMBED * 32 + r;
+    float wa[32], cb[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        wa[s] = We[(long)(2 * s + h) * a.F];
+        cb[s] = C[(2 * s + h) * 32];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[s], acc);
+    const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
+    float* X = a.x + (long)slot * a.F * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = f0 + mfma_row(i, h);
+        const float e = acc[i] + P[a.be_off + f];
+        X[(long)f * 32 + r] = fmaxf(e, 0.f) * psi[(long)f * 32 + r];
+    }
+}
+
+// Z of the three virtual nets of head k from the Dense_1 chunk partials, greedy target action, targets, quantile Huber
+// loss and its gradient.  One workgroup per head: thread = (sample b = t & 31, group g = t >> 5).
+struct IqnLossArgs {
+    const float* qpart;         // [V * N][J / 32][32 (action)][32]
+    const float* const* wbase;  // [V]
+    long b1_off;
+    int K, N, NJC, A, B, Bdiv;
+    const int32_t* action;
+    const float* reward;
+    const uint8_t* terminal;
+    const float* tau;  // [K][3][N][B]
+    float gamma_n;
+    float* dq;      // [K][N][A][32]  dL/dZ_online
+    float* losses;  // [K]
+    int32_t* count;
+    double* cum;
+    int finish_step;
+    float* dbg;  // [K][(2 N + 32 + 1)][32]: Z_online(a) rows, Z_target(a*) rows, q_select rows (32), a* row -- tests
+};
+__global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs a) {
+    extern __shared__ float sm[];
+    const int k = blockIdx.x, t = threadIdx.x, b = t & 31, g = t >> 5, N = a.N;
+    float* zon = sm;             // [N][32]
+    float* zval = zon + N * 32;  // [N][32]
+    float* qsel = zval + N * 32; // [32][32]
+    float* red = qsel + 32 * 32; // [8][32]
+    __shared__ int astar[32], act[32];
+    const float* Pt = a.wbase[a.K + k];
+    const float* Po = a.wbase[k];
+    auto zsum = [&](int v, int q, int ac) {  // b1 + chunk partials in chunk order
+        const float* p = a.qpart + (((long)(v * N + q) * a.NJC) * 32 + ac) * 32 + b;
+        float s = 0.f;
+        for (int c = 0; c < a.NJC; ++c) s += p[(long)c * 1024];
+        return s;
+    };
+    if (t < 32) act[t] = t < a.B ? a.action[t] : 0;
+    // mean over the selection fractions of the target net's Z, per action (fraction order)
+    for (int ac = g; ac < a.A; ac += 8) {
+        const float b1 = Pt[a.b1_off + ac];
+        float s = 0.f;
+        for (int q = 0; q < N; ++q) s += zsum(a.K + k, q, ac) + b1;
+        qsel[ac * 32 + b] = s / (float)N;
+    }
+    __syncthreads();
+    if (t < 32) {
+        int best = 0;
+        float bv = qsel[t];
+        for (int ac = 1; ac < a.A; ++ac) {
+            const float x = qsel[ac * 32 + t];
+            if (x > bv) { bv = x; best = ac; }
+        }
+        astar[t] = best;
+    }
+    __syncthreads();
+    for (int q = g; q < N; q += 8) {
+        zval[q * 32 + b] = zsum(2 * a.K + k, q, astar[b]) + Pt[a.b1_off + astar[b]];
+        zon[q * 32 + b] = zsum(k, q, act[b]) + Po[a.b1_off + act[b]];
+    }
+    __syncthreads();
+    const bool live = b < a.B;
+    const float rew = live ? a.reward[b] : 0.f;
+    const float cont = (live && a.terminal[b]) ? 0.f : a.gamma_n;  // (1 - terminal) * gamma^n
+    float lsum = 0.f;
+    for (int j = g; j < N; j += 8) {
+        const float z = zon[j * 32 + b];
+        const float tj = live ? a.tau[(((long)k * 3 + 0) * N + j) * a.B + b] : 0.5f;
+        float gsum = 0.f, ls = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const float d = (rew + cont * zval[i * 32 + b]) - z;
+            const float ad = fabsf(d);
+            const float w = fabsf(tj - (d < 0.f ? 1.f : 0.f));
+            ls += w * (ad <= 1.f ? 0.5f * d * d : ad - 0.5f);
+            gsum += w * (ad <= 1.f ? d : (d > 0.f ? 1.f : -1.f));
+        }
+        lsum += ls;
+        const float dz = live ? -gsum / ((float)a.Bdiv * (float)N) : 0.f;
+        for (int ac = 0; ac < a.A; ++ac)
+            a.dq[(((long)k * N + j) * a.A + ac) * 32 + b] = ac == act[b] ? dz : 0.f;
+    }
+    red[g * 32 + b] = live ? lsum / (float)N : 0.f;
+    __syncthreads();
+    if (a.dbg) {
+        float* D = a.dbg + (long)k * (2 * N + 33) * 32;
+        for (int e = t; e < N * 32; e += 256) { D[e] = zon[e]; D[N * 32 + e] = zval[e]; }
+        for (int e = t; e < 32 * 32; e += 256) D[2 * N * 32 + e] = e < a.A * 32 ? qsel[e] : 0.f;
+        if (t < 32) D[(2 * N + 32) * 32 + t] = (float)astar[t];
+    }
+    if (t == 0) {
+        float s = 0.f;
+        for (int x = 0; x < 32; ++x) {  // sample order, then group order
+            float sb = 0.f;
+            for (int gg = 0; gg < 8; ++gg) sb += red[gg * 32 + x];
+            s += sb;
+        }
+        const float loss = s / (float)a.Bdiv;
+        a.losses[k] = loss;
+        if (a.finish_step) {
+            a.count[k] += 1;
+            a.cum[k] = a.cum[k] + (double)loss;
+        }
+    }
+}
+
+// dL/dh of every fraction block + Dense_1 / Dense_0-bias gradients.  grid = (J / 32 chunks, head).
+struct IqnDhArgs {
+    const float* hbuf;  // [V * N][J][32]
+    const float* dq;    // [K][N][A][32]
+    const float* const* wbase;
+    long w1_off, gP, g_b0_off, g_w1_off, g_b1_off;
+    int K, N, J, A;
+    float* dh;    // [K][N][J][32]
+    float* grad;  // gradient arena
+};
+__global__ __launch_bounds__(256) void k_iqn_dh(IqnDhArgs a) {
+    __shared__ float hs[32][33], dqs[32 * 32], w1s[32 * 32];
+    const int jc = blockIdx.x, k = blockIdx.y, t = threadIdx.x, b = t & 31, jj = t >> 5;
+    const float* w1 = a.wbase[k] + a.w1_off + (long)jc * 32 * a.A;
+    for (int e = t; e < 32 * a.A; e += 256) w1s[e] = w1[e];
+    float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f;
+    for (int q = 0; q < a.N; ++q) {
+        const float* hb = a.hbuf + ((long)(k * a.N + q) * a.J + jc * 32) * 32;
+        const float* dq = a.dq + ((long)k * a.N + q) * a.A * 32;
+        __syncthreads();  // the previous block's tiles have been consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[jj + 8 * i][b] = hb[(jj + 8 * i) * 32 + b];
+        for (int e = t; e < a.A * 32; e += 256) dqs[e] = dq[e];
+        __syncthreads();
+        float* dh = a.dh + ((long)(k * a.N + q) * a.J + jc * 32) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int jl = jj + 8 * i;
+            float d = 0.f;
+            for (int ac = 0; ac < a.A; ++ac) d = fmaf(w1s[jl * a.A + ac], dqs[ac * 32 + b], d);
+            d = hs[jl][b] > 0.f ? d : 0.f;
+            dh[jl * 32 + b] = d;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+            gb0[i] += d;
+        }
+        // Dense_1 weight gradient: thread -> elements (jl, ac) = (o / A, o % A), o = t + 256 m; sum over the samples
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int o = t + 256 * m;
+            if (o < 32 * a.A) {
+                const int jl = o / a.A, ac = o - jl * a.A;
+                float s = 0.f;
+#pragma unroll
+                for (int x = 0; x < 32; ++x) s = fmaf(hs[jl][x], dqs[ac * 32 + x], s);
+                gw[m] += s;
+            }
+        }
+        if (jc == 0 && t < a.A) {
+            float s = 0.f;
+#pragma unroll
+            for (int x = 0; x < 32; ++x) s += dqs[t * 32 + x];
+            gb1 += s;
+        }
+    }
+    float* G = a.grad + (long)k * a.gP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (b == 0) G[a.g_b0_off + jc * 32 + jj + 8 * i] = gb0[i];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int o = t + 256 * m;
+        if (o < 32 * a.A) G[a.g_w1_off + (long)jc * 32 * a.A + o] = gw[m];
+    }
+    if (jc == 0 && t < a.A) G[a.g_b1_off + t] = gb1;
+}
+
+// Backward of the Hadamard product and of the embedding, one wave per (head, 32-feature tile), fractions in order:
+//   e, phi recomputed (the forward's MFMA);  dpsi[f][b] += dx * phi;  dphi = dx * psi * [e > 0];
+//   dWe[i][f] += sum_b cos[i][b] dphi[f][b]  (MFMA over the 32 samples, dphi through a per-wave LDS tile);  dbe[f] += sum_b dphi.
+struct IqnEmbedBwdArgs {
+    const float* cosb;  // [V * N][64][32] (online virtual nets = the first K * N slots)
+    const float* const* wbase;
+    const float* psi;   // [2K][F * 32]
+    const float* dx;    // [K][N][F][32]
+    float* dpsi;        // [K][F][32]  (not yet masked by psi > 0)
+    float* grad;
+    long we_off, be_off, gP, g_we_off, g_be_off;
+    int K, N, F;
+};
+__global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
+    __shared__ float tile[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int ft = blockIdx.x * 4 + wave, k = blockIdx.y;
+    const bool live = ft < a.F / 32;  // (idle waves still join no barrier: the LDS tile is per wave)
+    if (!live) return;
+    const int f0 = ft * 32;
+    const float* P = a.wbase[k];
+    const float* We = P + a.we_off + f0 + r;
+    float wa[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) wa[s] = We[(long)(2 * s + h) * a.F];
+    float be[16], ps[16], dps[16], dbe[16];
+    const float* psi = a.psi + (long)k * a.F * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = f0 + mfma_row(i, h);
+        be[i] = P[a.be_off + f];
+        ps[i] = psi[(long)f * 32 + r];
+        dps[i] = 0.f;
+        dbe[i] = 0.f;
+    }
+    f32x16 gw0, gw1;  // dWe rows i = 0..31 / 32..63 x the tile's 32 features
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { gw0[i] = 0.f; gw1[i] = 0.f; }
+    for (int q = 0; q < a.N; ++q) {
+        const int slot = k * a.N + q;
+        const float* C = a.cosb + (long)slot * IQN_EMBED * 32;
+        float cb[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) cb[s] = C[(2 * s + h) * 32 + r];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[s], acc);
+        const float* DX = a.dx + (long)slot * a.F * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int fl = mfma_row(i, h);
+            const float e = acc[i] + be[i];
+            const float dx = DX[(long)(f0 + fl) * 32 + r];
+            dps[i] = fmaf(dx, fmaxf(e, 0.f), dps[i]);
+            const float dphi = e > 0.f ? dx * ps[i] : 0.f;
+            dbe[i] += dphi;
+            tile[wave][fl][r] = dphi;  // [feature][sample]
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dWe[i][f] += sum_b cos[i][b] * dphi[f][b]: A = cos (row i = r (+32), k = sample 2 s + h), B = dphi (k = sample, col f = r)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bv = tile[wave][r][2 * s + h];
+            gw0 = mfma32(C[r * 32 + 2 * s + h], bv, gw0);
+            gw1 = mfma32(C[(32 + r) * 32 + 2 * s + h], bv, gw1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* DP = a.dpsi + (long)k * a.F * 32;
+    float* G = a.grad + (long)k * a.gP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int fl = mfma_row(i, h);
+        DP[(long)(f0 + fl) * 32 + r] = dps[i];
+        float d = dbe[i];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        if (r == 0) G[a.g_be_off + f0 + fl] = d;
+        G[a.g_we_off + (long)mfma_row(i, h) * a.F + f0 + r] = gw0[i];
+        G[a.g_we_off + (long)(32 + mfma_row(i, h)) * a.F + f0 + r] = gw1[i];
+    }
+}
+
+// mean over the N fractions of Z (acting): q[a] of ONE state = lane 0 of every block.  One wave per action.
+struct IqnQOutArgs {
+    const float* qpart;  // [N][J / 32][32][32]
+    const float* params;
+    long b1_off;
+    int N, NJC, A, n;
+    float* q_out;      // [n][A]
+    int32_t* action;   // [n] or nullptr
+};
+__global__ __launch_bounds__(256) void k_iqn_q_out(IqnQOutArgs a) {
+    __shared__ float qs[32 * 32];
+    for (int e = threadIdx.x; e < a.A * 32; e += 256) {
+        const int ac = e >> 5, b = e & 31;
+        float s = 0.f;
+        for (int q = 0; q < a.N; ++q) {
+            float z = 0.f;
+            for (int c = 0; c < a.NJC; ++c) z += a.qpart[(((long)q * a.NJC + c) * 32 + ac) * 32 + b];
+            s += z + a.params[a.b1_off + ac];
+        }
+        s /= (float)a.N;
+        qs[e] = s;
+        if (b < a.n) a.q_out[b * a.A + ac] = s;
+    }
+    __syncthreads();
+    if (a.action && (int)threadIdx.x < a.n) {
+        int best = 0;
+        float bv = qs[threadIdx.x];
+        for (int ac = 1; ac < a.A; ++ac)
+            if (qs[ac * 32 + threadIdx.x] > bv) { bv = qs[ac * 32 + threadIdx.x]; best = ac; }
+        a.action[threadIdx.x] = best;
+    }
+}

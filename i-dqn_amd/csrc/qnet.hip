@@ -21,6 +21,7 @@
 #include "act_kernels.h"
 #include "cnn_kernels.h"
 #include "fc_kernels.h"
+#include "iqn_kernels.h"
 
 namespace {
 
@@ -90,6 +91,9 @@ int build_layout(const idqn_config_t& c, Layout& L) {
     IDQN_REQUIRE(c.n_heads >= 1 && c.n_actions >= 1 && c.n_actions <= 32, "n_heads >= 1 and 1 <= n_actions <= 32 required");
     IDQN_REQUIRE(c.n_features >= 1 && c.n_features <= IDQN_MAX_FEATURES, "n_features out of range");
     IDQN_REQUIRE(c.max_batch >= 1, "max_batch must be positive");
+    IDQN_REQUIRE(c.n_quantiles >= 0 && c.n_quantiles <= 64, "n_quantiles must be in [0, 64]");
+    IDQN_REQUIRE(c.n_quantiles == 0 || (c.arch == IDQN_ARCH_CNN && c.max_batch <= 32),
+                 "i-IQN heads are built for the cnn arch and minibatches of at most 32 samples");
     long off = 0;
     char nm[32];
     if (c.arch == IDQN_ARCH_CNN) {
@@ -121,6 +125,12 @@ int build_layout(const idqn_config_t& c, Layout& L) {
         add_leaf(L, "Dense_1/kernel", 2, d1, &off);
         long b1[1] = {c.n_actions};
         add_leaf(L, "Dense_1/bias", 1, b1, &off);
+        if (c.n_quantiles > 0) {  // i-IQN heads (extension): the quantile embedding, phi(tau) = relu(Embed_0(cos(pi i tau)))
+            long es[2] = {IQN_EMBED, d0[0]};
+            add_leaf(L, "Embed_0/kernel", 2, es, &off);
+            long eb[1] = {d0[0]};
+            add_leaf(L, "Embed_0/bias", 1, eb, &off);
+        }
     } else if (c.arch == IDQN_ARCH_FC) {
         long fan = (long)c.obs_h * c.obs_w * c.obs_c;
         for (int i = 0; i <= c.n_features; ++i) {
@@ -157,6 +167,15 @@ struct NetSet {
 struct FwdPlan { int n_items = 0, NT = 0, ring = 2, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
 struct WgradPlan { int n_items = 0, n_chunks = 0, chunk_major = 0, MT = 0, PG = 0; size_t lds = 0; };
 
+// workspace of the i-IQN heads (iqn_kernels.h): V = 3K virtual nets x N fraction blocks
+struct IqnWs {
+    int N = 0, V = 0, NS = 2;
+    const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
+    float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
+          *dx = nullptr, *dpsi = nullptr, *dbg = nullptr;
+    long off_we = 0, off_be = 0;
+};
+
 }  // namespace
 
 struct idqn_handle_s {
@@ -174,6 +193,7 @@ struct idqn_handle_s {
     int F = 0, J = 0, NS = 0;
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
+    IqnWs iqn;
     float* dpart = nullptr;  // partial Dense_0 data gradients of the fused weight-gradient kernel [n_jt][K * nb][F][32]
     float *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
@@ -461,6 +481,33 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->slab, slab_total, h, "slab"))) return rc;
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
     IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_dgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, h->J * 32 * 4));
+    if (c.n_quantiles > 0) {  // i-IQN heads: V = 3K virtual nets x N fraction blocks (iqn_kernels.h)
+        IDQN_REQUIRE(h->planes, "i-IQN heads run on the plane conv path (IDQN_CONV=bf16x3)");
+        IDQN_REQUIRE(h->J % 256 == 0, "i-IQN heads: dense width %d must be a multiple of 256", h->J);
+        IqnWs& w = h->iqn;
+        w.N = c.n_quantiles; w.V = 3 * K;
+        if (const char* e = getenv("IDQN_IQN_SPLITS")) w.NS = std::max(1, std::min(64, atoi(e)));
+        w.off_we = h->L.leaves[10].offset; w.off_be = h->L.leaves[11].offset;
+        const long VN = (long)w.V * w.N, KN = (long)K * w.N;
+        IDQN_HIP_CHECK(hipMalloc((void**)&w.wbase_v, sizeof(float*) * w.V));
+        h->owned.push_back((void*)w.wbase_v);
+        std::vector<const float*> wv(w.V);
+        for (int k = 0; k < K; ++k) {
+            wv[k] = h->online + (long)k * h->L.head_stride;
+            wv[K + k] = wv[2 * K + k] = h->target + (long)k * h->L.head_stride;
+        }
+        IDQN_HIP_CHECK(hipMemcpy(w.wbase_v, wv.data(), sizeof(float*) * w.V, hipMemcpyHostToDevice));
+        if ((rc = alloc_zero(&w.cosb, VN * IQN_EMBED * 32, h, "iqn_cos"))) return rc;
+        if ((rc = alloc_zero(&w.xq, VN * h->F * 32, h, "iqn_x"))) return rc;
+        if ((rc = alloc_zero(&w.part, VN * w.NS * h->J * 32, h, "iqn_part"))) return rc;
+        if ((rc = alloc_zero(&w.hbuf, VN * h->J * 32, h, "iqn_h"))) return rc;
+        if ((rc = alloc_zero(&w.qpart, VN * (h->J / 32) * 32 * 32, h, "iqn_qpart"))) return rc;
+        if ((rc = alloc_zero(&w.dq, KN * c.n_actions * 32, h, "iqn_dq"))) return rc;
+        if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
+        if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
+        if ((rc = alloc_zero(&w.dpsi, (long)K * h->F * 32, h, "iqn_dpsi"))) return rc;
+        if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
+    }
     h->dominant = "k_dense0_wgrad";
     return IDQN_OK;
 }
@@ -898,7 +945,7 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) 
 }
 
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
-int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q) {
+int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q, bool with_dense0 = true) {
     const int nb = cdiv(B, 32);
     IDQN_REQUIRE(nb <= s.nb_cap, "batch %d exceeds the workspace (%d blocks of 32)", B, s.nb_cap);
     if (h->planes) {
@@ -938,6 +985,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
             else
                 hipLaunchKernelGGL((k_conv_fwd<2, 1>), dim3((unsigned)a.n_items), dim3(256), 0, q, a);
         }
+    }
+    if (!with_dense0) {  // (the i-IQN heads take the trunk features from here)
+        IDQN_HIP_CHECK(hipGetLastError());
+        return IDQN_OK;
     }
     if (&s == &h->train && h->d0_wait) IDQN_HIP_CHECK(hipStreamWaitEvent(q, h->d0_wait, 0));
     DenseFwdArgs d;
@@ -1067,7 +1118,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     dw.dh_outer = dh_outer; dw.dh_head = dh_head; dw.dh_inner = dh_inner;
     const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
-    dw.F = h->F; dw.J = h->J;
+    dw.F = h->F; dw.J = h->J; dw.item0 = 0;
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
     const dim3 wgrid((unsigned)dw.n_items);
     // profiling: the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so the
@@ -1078,10 +1129,17 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         h->ev_used += 2;
     }
     // (the extended launch only when there is something to time: it is not a capturable node of a step graph)
+    // IDQN_D0W_PAD: extra (unused) dynamic LDS per workgroup = fewer co-resident workgroups per CU (occupancy experiments)
+    static const int pad = getenv("IDQN_D0W_PAD") ? atoi(getenv("IDQN_D0W_PAD")) : 0;
 #define D0W_LAUNCH(...)                                                                                   \
     do {                                                                                                  \
-        if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, e0, e1, 0, dw); \
-        else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, dw);               \
+        static bool attr_set = false;                                                                     \
+        if (pad > 0 && !attr_set) {                                                                       \
+            IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, pad)); \
+            attr_set = true;                                                                              \
+        }                                                                                                 \
+        if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, e0, e1, 0, dw); \
+        else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, dw);             \
     } while (0)
     if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
@@ -1140,7 +1198,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     if (!fuse_dg) {
         DenseDgradArgs dd;
         dd.dh = dh_of(h, nb); dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
-        dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3;
+        dd.K = K; dd.nb = nb; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = c2->CO; dd.g = h->gda3; dd.raw = nullptr;
         // 4 or 3 f tiles per workgroup, whichever leaves the busiest CU fewer tiles (two workgroups fit a CU's LDS)
         const long wg4 = (long)K * nb * cdiv(dd.n_ft, 4), wg3 = (long)K * nb * cdiv(dd.n_ft, 3);
         const long busy4 = cdiv(wg4, 256) * 4, busy3 = wg3 <= 512 ? cdiv(wg3, 256) * 3 : 1 << 30;
@@ -1421,6 +1479,127 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
     }
     return IDQN_OK;  // count += 1 and cum_losses += losses already happened in k_td_dh / k_fc_step (fused path)
+}
+
+// ---- i-IQN heads (extension; iqn_kernels.h, oracle/iqn_ref.py) --------------------------------------------------------
+namespace {
+// fraction blocks -> Dense_0 -> hidden + Dense_1 partials, for `V` virtual nets whose trunk features are psi [.][F * 32]
+int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int K_for_index, const float* psi, const float* tau,
+                      int B, hipStream_t q) {
+    IqnWs& w = h->iqn;
+    IqnCosArgs ca;
+    ca.tau = tau; ca.cosb = w.cosb; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
+    tl_mark(h, q, "iqn cos features");
+    IqnEmbedArgs ea;
+    ea.cosb = w.cosb; ea.wbase = wbase_v; ea.psi = psi; ea.x = w.xq; ea.we_off = w.off_we; ea.be_off = w.off_be;
+    ea.K = K_for_index; ea.N = w.N; ea.F = h->F;
+    hipLaunchKernelGGL(k_iqn_embed, dim3((unsigned)cdiv(h->F / 32, 4), (unsigned)(V * w.N)), dim3(256), 0, q, ea);
+    tl_mark(h, q, "iqn embedding x features");
+    DenseFwdArgs d;
+    d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
+    d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
+    d.n_items = (long)V * w.N * d.NS * d.n_jt;
+    d.net_rot = 0;
+    hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    tl_mark(h, q, "iqn dense0 fwd");
+    HiddenArgs hi;
+    hi.part = w.part; hi.wbase = wbase_v; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = w.N; hi.NS = w.NS;
+    hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = w.hbuf; hi.qpart = w.qpart;
+    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, (unsigned)(V * w.N)), dim3(256), 0, q, hi);
+    tl_mark(h, q, "iqn hidden");
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+}  // namespace
+
+extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
+                                       const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
+                                       const float* tau_dev, int32_t batch, uint32_t flags, void* stream) {
+    IDQN_REQUIRE(h && state_dev && next_state_dev && action_dev && reward_dev && terminal_dev && tau_dev,
+                 "idqn_iqn_learn_on_batch: null pointer");
+    IDQN_REQUIRE(h->iqn.N > 0, "idqn_iqn_learn_on_batch: the handle was created without quantile heads (cfg.n_quantiles)");
+    IDQN_REQUIRE(batch >= 1 && batch <= 32 && batch <= h->cfg.max_batch, "idqn_iqn_learn_on_batch: batch %d not in [1, 32]", batch);
+    IDQN_REQUIRE(!(flags & ~(IDQN_F_PROFILE | IDQN_F_PROFILE_ALL)), "idqn_iqn_learn_on_batch: only the profile flags are supported");
+    hipStream_t q = (hipStream_t)stream;
+    IqnWs& w = h->iqn;
+    const int K = h->cfg.n_heads, A = h->cfg.n_actions;
+    h->pend_B = 0; h->pend_stage = 0;
+    h->tl_on = (flags & IDQN_F_PROFILE_ALL) != 0;
+    if (h->tl_on && h->tl_ev.empty()) {
+        h->tl_ev.resize(2048);
+        h->tl_name.resize(2048);
+        for (auto& e : h->tl_ev) IDQN_HIP_CHECK(hipEventCreate(&e));
+    }
+    tl_mark(h, q, nullptr);
+    int rc;
+    // trunk of the 2K nets (online on s, target on s'), then the fraction blocks of the 3K virtual nets
+    if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q, false))) return rc;
+    if ((rc = iqn_heads_forward(h, w.wbase_v, w.V, K, h->train.a3, tau_dev, batch, q))) return rc;
+    IqnLossArgs la;
+    la.qpart = w.qpart; la.wbase = w.wbase_v; la.b1_off = h->off_b1; la.K = K; la.N = w.N; la.NJC = h->J / 32; la.A = A;
+    la.B = batch; la.Bdiv = batch; la.action = action_dev; la.reward = reward_dev; la.terminal = terminal_dev; la.tau = tau_dev;
+    la.gamma_n = h->gamma_n; la.dq = w.dq; la.losses = h->losses; la.count = h->count; la.cum = h->cum; la.finish_step = 1;
+    la.dbg = w.dbg;
+    hipLaunchKernelGGL(k_iqn_loss, dim3(K), dim3(256), (size_t)(2 * w.N * 32 + 32 * 32 + 8 * 32) * 4, q, la);
+    tl_mark(h, q, "iqn quantile huber loss");
+    const long w0n = h->g_w0_end - h->g_w0_begin;
+    IqnDhArgs da;
+    da.hbuf = w.hbuf; da.dq = w.dq; da.wbase = w.wbase_v; da.w1_off = h->off_w1; da.gP = h->gP;
+    da.g_b0_off = h->off_b0 - w0n; da.g_w1_off = h->off_w1 - w0n; da.g_b1_off = h->off_b1 - w0n;
+    da.K = K; da.N = w.N; da.J = h->J; da.A = A; da.dh = w.dh; da.grad = h->grad;
+    hipLaunchKernelGGL(k_iqn_dh, dim3(h->J / 32, K), dim3(256), 0, q, da);
+    tl_mark(h, q, "iqn dh + dense1 grads");
+    {   // W0 . dh for every fraction block (plain rows)
+        DenseDgradArgs dd;
+        memset(&dd, 0, sizeof(dd));
+        dd.dh = w.dh; dd.raw = w.dx; dd.wbase = h->train.wbase; dd.w_off = h->off_w0;
+        dd.K = K; dd.nb = w.N; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = h->conv[2].CO; dd.g = h->gda3;
+        dd.n_items = (long)K * w.N * cdiv(dd.n_ft, 4);
+        hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+        tl_mark(h, q, "iqn dense0 dgrad");
+    }
+    IqnEmbedBwdArgs eb;
+    eb.cosb = w.cosb; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.grad = h->grad;
+    eb.we_off = w.off_we; eb.be_off = w.off_be; eb.gP = h->gP; eb.g_we_off = w.off_we - w0n; eb.g_be_off = w.off_be - w0n;
+    eb.K = K; eb.N = w.N; eb.F = h->F;
+    hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K), dim3(256), 0, q, eb);
+    tl_mark(h, q, "iqn embedding backward");
+    {   // dL/dpsi -> ReLU mask, bf16 planes, per-position sums: what the conv backward of the plain step reads
+        Da3FinalizeArgs fa;
+        fa.dpart = w.dpsi; fa.a3 = h->train.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
+        fa.n_rows = (long)K * h->F; fa.n_jt = 1; fa.F = h->F; fa.C = h->conv[2].CO; fa.K = K; fa.nb = 1; fa.g = h->gda3;
+        hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
+        tl_mark(h, q, "da3 finalize (sum, mask, planes)");
+    }
+    // Dense_0 weight gradient over the N fraction blocks of every head, fused with Adam (x of the online virtual nets, dh)
+    if ((rc = launch_dense0_wgrad(h, w.xq, w.dh, w.N, w.N, 0, (long)w.N * h->F * 32, (long)h->F * 32, 0, (long)w.N * h->J * 32,
+                                  (long)h->J * 32, true, (flags & IDQN_F_PROFILE) != 0, q, false)))
+        return rc;
+    if ((rc = cnn_backward_rest(h, batch, true, q))) return rc;
+    return launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, true, q);
+}
+
+extern "C" int idqn_iqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                                 const float* tau_dev, float* q_out_dev, int32_t* action_out_dev, void* stream) {
+    IDQN_REQUIRE(h && states_dev && tau_dev && q_out_dev, "idqn_iqn_q_values: null pointer");
+    IDQN_REQUIRE(h->iqn.N > 0, "idqn_iqn_q_values: the handle was created without quantile heads (cfg.n_quantiles)");
+    IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_iqn_q_values: bad head / which");
+    IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_iqn_q_values: n = %d, must be in [1, 32]", n);
+    hipStream_t q = (hipStream_t)stream;
+    IqnWs& w = h->iqn;
+    const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
+    h->infer.wbase = h->train.wbase + (which * h->cfg.n_heads + head);  // entry of the training table: no pointer upload
+    h->infer_pbase = params;
+    int rc;
+    if ((rc = cnn_forward(h, h->infer, (const uint8_t*)states_dev, nullptr, n, q, false))) return rc;
+    if ((rc = iqn_heads_forward(h, h->infer.wbase, 1, 1, h->infer.a3, tau_dev, n, q))) return rc;
+    IqnQOutArgs qo;
+    qo.qpart = w.qpart; qo.params = params; qo.b1_off = h->off_b1; qo.N = w.N; qo.NJC = h->J / 32; qo.A = h->cfg.n_actions;
+    qo.n = n; qo.q_out = q_out_dev; qo.action = action_out_dev;
+    hipLaunchKernelGGL(k_iqn_q_out, dim3(1), dim3(256), 0, q, qo);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
 }
 
 extern "C" int idqn_backward_rest(idqn_handle_t h, void* stream) {

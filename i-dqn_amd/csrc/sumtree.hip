@@ -22,7 +22,7 @@ void idqn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* idqn_last_error(void) { return g_err; }
-extern "C" int idqn_abi_version(void) { return 1; }
+extern "C" int idqn_abi_version(void) { return 2; }  // 2: idqn_config_t.n_quantiles, the i-IQN entry points
 
 #define ST_THREADS 1024
 #define ST_MAX_N 4096

@@ -29,6 +29,7 @@ class Config(C.Structure):
         ("max_batch", C.c_int32),
         ("learning_rate", C.c_double), ("adam_b1", C.c_double), ("adam_b2", C.c_double), ("adam_eps", C.c_double),
         ("gamma_n", C.c_double),
+        ("n_quantiles", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -45,6 +46,8 @@ SYMBOLS = {
     "idqn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "idqn_destroy": (C.c_int, [_P]),
     "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "idqn_iqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint32, _P]),
+    "idqn_iqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
     "idqn_backward_rest": (C.c_int, [_P, _P]),
     "idqn_export_dense0_factors": (C.c_int, [_P, _P, _P, _P]),
     "idqn_dense0_factors": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -138,7 +141,7 @@ def current_stream():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
-def make_config(arch, n_heads, n_actions, obs, features, max_batch, lr, eps, gamma_n, b1=0.9, b2=0.999):
+def make_config(arch, n_heads, n_actions, obs, features, max_batch, lr, eps, gamma_n, b1=0.9, b2=0.999, n_quantiles=0):
     cfg = Config()
     cfg.arch = {"cnn": IDQN_ARCH_CNN, "fc": IDQN_ARCH_FC}[arch]
     cfg.n_heads, cfg.n_actions = int(n_heads), int(n_actions)
@@ -148,6 +151,7 @@ def make_config(arch, n_heads, n_actions, obs, features, max_batch, lr, eps, gam
         cfg.features[i] = int(f)
     cfg.max_batch = int(max_batch)
     cfg.learning_rate, cfg.adam_b1, cfg.adam_b2, cfg.adam_eps, cfg.gamma_n = float(lr), b1, b2, float(eps), float(gamma_n)
+    cfg.n_quantiles = int(n_quantiles)
     return cfg
 
 

@@ -88,7 +88,8 @@ class DeviceAgent:
     # ---- plumbing ----------------------------------------------------------------------------------
     def _config(self, max_batch):
         return _hip.make_config(self._arch, self._K, self.network.n_actions, self._obs, self.network.features,
-                                max_batch, self._lr, self._eps, self._gamma_n)
+                                max_batch, self._lr, self._eps, self._gamma_n,
+                                n_quantiles=getattr(self, "_n_quantiles", 0))  # > 0: i-IQN heads (slimdqn/networks/iiqn.py)
 
     def _tree(self, arena):
         tree = {}

@@ -49,6 +49,10 @@ typedef struct idqn_config {
     double learning_rate;                 /* optax.adam(lr, eps=adam_eps), idqn.py:52            */
     double adam_b1, adam_b2, adam_eps;
     double gamma_n;                       /* gamma ** update_horizon (a Python double), idqn.py:122 */
+    int32_t n_quantiles;                  /* 0: i-DQN heads.  N > 0: i-IQN heads (extension, see idqn_iqn_learn_on_batch): N
+                                             quantile fractions per sample for the online, the action-selection and the
+                                             target pass; cnn only; adds the leaves Embed_0/kernel [64][F], Embed_0/bias [F] */
+    int32_t reserved;
 } idqn_config_t;
 
 typedef struct idqn_leaf {
@@ -87,6 +91,22 @@ int idqn_destroy(idqn_handle_t h);
 #define IDQN_F_PROFILE_ALL 16u /* one hipEvent after every launch of the step (see idqn_profile_table) */
 #define IDQN_F_STOP_AFTER_DENSE0 4u  /* two-call backward, see idqn_backward_rest */
 #define IDQN_F_STOP_BEFORE_DENSE0_WGRAD 8u  /* factored data-parallel step, see idqn_finish_step_factored */
+
+/* i-IQN heads -- BASELINE config 3, a LABELLED EXTENSION: the reference snapshot has no quantile code (its README.md:3,10
+ * names i-IQN and points at another repository), so nothing here replaces a reference function; oracle/iqn_ref.py states
+ * the algorithm (implicit quantile network, Dabney et al. 2018, on the reference's conv trunk; the reference's chain of K
+ * heads, idqn.py:13-24,96-109) and parity is pinned to that restatement only.
+ * One gradient step of K heads on a minibatch of batch <= 32 samples: per head N online fractions, N action-selection
+ * fractions and N target fractions per sample, tau_dev = float32 [K][3][N][batch] in (0, 1) (the host draws them);
+ * quantile Huber loss (kappa = 1), sum over the online and mean over the target fractions, mean over the batch; Adam on
+ * every leaf; count += 1, losses written, cum_losses accumulated -- as idqn_learn_on_batch.  flags: IDQN_F_PROFILE only. */
+int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
+                            const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
+                            const float* tau_dev, int32_t batch, uint32_t flags, void* stream);
+/* Acting rule of IQN for n <= 32 states: q[a] = mean over the N fractions tau_dev [N][n] of Z(s, tau)[a] of head `head`
+ * (which = 0 online / 1 target) -> q_out_dev [n][A]; action_out_dev [n] (may be NULL) = argmax, first maximum on ties. */
+int idqn_iqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* states_dev, int32_t n,
+                      const float* tau_dev, float* q_out_dev, int32_t* action_out_dev, void* stream);
 
 /* iDQN.learn_on_batch (idqn.py:96-109) == DQN.learn_on_batch (dqn.py:60-73) for K == 1:
  * 2K forwards, TD target (idqn.py:120-124), squared loss mean over the batch (idqn.py:111-118),

@@ -9,6 +9,8 @@
        records operation traces: inputs AND the reference's outputs (node arrays, roots, query
        results, sampled keys, index maps).  Only data is written; no reference source travels.
        -> tests/golden/int_path_sumtree.npz, int_path_samplers.npz
+--iqn  the same for the i-IQN extension (``oracle/iqn_ref.py``; the reference has no quantile code at all).
+       -> tests/golden/fp_path_iqn_*.json
 --fp   writes expected losses / gradient / post-Adam probes of the fp64 numpy restatement
        (``oracle/qnet_ref.py``) for seeded inputs.  NOT reference-captured (jax is not installed):
        "parity unpinned" for this part, see oracle/__init__.py.
@@ -226,10 +228,66 @@ def capture_fp(names=None):
         print("wrote", name, [s["losses"] for s in rec["steps"]])
 
 
+# ----------------------------------------------------------------------------------------------
+# i-IQN extension (oracle/iqn_ref.py; no reference code exists for it): fp64 restatement -> probes
+# ----------------------------------------------------------------------------------------------
+IQN_CASES = {  # name: (obs, A, features, K, B, N)
+    "iqn_small": ((20, 20, 4), 5, [32, 32, 32, 256], 2, 32, 4),
+    "iqn_small_ragged": ((20, 20, 4), 5, [32, 64, 32, 256], 2, 20, 5),
+    "iqn_atari_k5": ((84, 84, 4), 6, [32, 64, 64, 512], 5, 32, 32),
+}
+
+
+def iqn_case_inputs(name):
+    from . import iqn_ref as I
+    from . import qnet_ref as Q
+
+    obs, A, feats, K, B, N = IQN_CASES[name]
+    seed = sum(name.encode())
+    p = I.init_params(seed, obs, A, feats, K)
+    pt = I.init_params(seed + 1, obs, A, feats, K)
+    rng = np.random.default_rng(seed + 2)
+    for n in p:
+        if n.endswith("bias"):
+            p[n] = (0.05 * rng.standard_normal(p[n].shape)).astype(np.float32)
+            pt[n] = (0.05 * rng.standard_normal(p[n].shape)).astype(np.float32)
+    st, a, r, s2, term = Q.synthetic_batch(seed + 10, B, obs, A, "cnn")
+    term[0] = True
+    taus = I.synthetic_taus(seed + 20, K, N, B)
+    return p, pt, (st, a, r, s2, term), taus
+
+
+def capture_iqn(names=None):
+    from . import iqn_ref as I
+    from . import qnet_ref as Q
+
+    for name in names or IQN_CASES:
+        obs, A, feats, K, B, N = IQN_CASES[name]
+        p, pt, batch, taus = iqn_case_inputs(name)
+        gamma_n = FP_HYPER["gamma"] ** FP_HYPER["n"]
+        mu = {n: np.zeros_like(a, dtype=np.float64) for n, a in p.items()}
+        nu = {n: np.zeros_like(a, dtype=np.float64) for n, a in p.items()}
+        _, _, aux0 = I.loss_and_grads(Q.head(p, 0), Q.head(pt, 0), batch, tuple(taus[0]), gamma_n)
+        p64, mu, nu, count, losses, grads = I.learn_on_batch(p, pt, mu, nu, np.zeros(K, np.int64), batch, taus, gamma_n,
+                                                             FP_HYPER["lr"], FP_HYPER["eps"], np.float64, return_grads=True)
+        rec = {"case": name, "hyper": FP_HYPER, "losses": losses.tolist(), "z_online_head0": aux0["z_a"].tolist(),
+               "z_target_head0": aux0["z_t"].tolist(), "a_star_head0": aux0["a_star"].tolist(),
+               "q_select_head0": aux0["q_sel"].tolist(), "leaves": {}}
+        for leaf in p64:
+            flat_g, flat_p = grads[leaf].reshape(K, -1), p64[leaf].reshape(K, -1)
+            idx = probe_indices(name, leaf, flat_g.shape[1])
+            rec["leaves"][leaf] = {"idx": idx.tolist(), "grad": flat_g[:, idx].tolist(), "param": flat_p[:, idx].tolist(),
+                                   "grad_l2": np.sqrt((flat_g**2).sum(1)).tolist(), "grad_absmax": np.abs(flat_g).max(1).tolist()}
+        with open(os.path.join(GOLDEN, f"fp_path_{name}.json"), "w") as f:
+            json.dump(rec, f)
+        print("wrote", name, rec["losses"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--int", action="store_true")
     ap.add_argument("--fp", action="store_true")
+    ap.add_argument("--iqn", action="store_true")
     ap.add_argument("--cases", nargs="*")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -239,3 +297,5 @@ if __name__ == "__main__":
         capture_samplers()
     if args.fp:
         capture_fp(args.cases)
+    if args.iqn:
+        capture_iqn(args.cases)

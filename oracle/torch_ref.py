@@ -103,3 +103,37 @@ class BatchedStep:
                 self.v[n].mul_(B2).addcmul_(g, g, value=1 - B2)
                 t.add_((self.m[n] / bc1) / ((self.v[n] / bc2).sqrt() + self.eps), alpha=-self.lr)
         return losses.detach().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# i-IQN extension (oracle/iqn_ref.py states the algorithm and its sources): the same step through autograd
+# ----------------------------------------------------------------------------------------------
+def iqn_quantile_values(p, psi, tau, dtype=torch.float64):
+    i = torch.arange(1, 65, dtype=torch.float64)
+    c = torch.cos(np.pi * i * torch.as_tensor(tau).to(torch.float64)[..., None]).to(dtype)  # [N, B, 64]
+    phi = F.relu(c @ p["Embed_0/kernel"] + p["Embed_0/bias"])
+    h = F.relu((psi[None] * phi) @ p["Dense_0/kernel"] + p["Dense_0/bias"])
+    return h @ p["Dense_1/kernel"] + p["Dense_1/bias"]
+
+
+def iqn_loss_and_grads(p_online, p_target, batch, taus, gamma_n, dtype=torch.float64, kappa=1.0):
+    state, action, reward, next_state, terminal = batch
+    tau_on, tau_sel, tau_tg = taus
+    po = {n: _t(a, dtype).requires_grad_(True) for n, a in p_online.items()}
+    pt = {n: _t(a, dtype) for n, a in p_target.items()}
+    conv = lambda p: {n: a for n, a in p.items() if n.startswith("Conv_")}  # noqa: E731
+    bsz = state.shape[0]
+    ar = torch.arange(bsz)
+    z = iqn_quantile_values(po, forward_head(conv(po), torch.as_tensor(state), "cnn", dtype), tau_on, dtype)
+    with torch.no_grad():
+        psi_t = forward_head(conv(pt), torch.as_tensor(next_state), "cnn", dtype)
+        a_star = iqn_quantile_values(pt, psi_t, tau_sel, dtype).mean(0).argmax(1)
+        z_t = iqn_quantile_values(pt, psi_t, tau_tg, dtype)[:, ar, a_star]
+        tgt = _t(reward, dtype)[None] + (1 - _t(terminal.astype(np.int64), dtype))[None] * gamma_n * z_t
+    z_a = z[:, ar, torch.as_tensor(action.astype(np.int64))]
+    delta = tgt[:, None, :] - z_a[None, :, :]
+    hub = torch.where(delta.abs() <= kappa, 0.5 * delta**2, kappa * (delta.abs() - 0.5 * kappa))
+    wgt = (torch.as_tensor(tau_on).to(dtype)[None] - (delta.detach() < 0).to(dtype)).abs()
+    loss = (wgt * hub / kappa).sum(1).mean(0).mean()
+    loss.backward()
+    return float(loss.detach()), {n: t.grad.numpy() for n, t in po.items()}
