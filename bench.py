@@ -91,7 +91,165 @@ def cpu_baseline(budget_s=15.0, n_actions=N_ACTIONS):
             break
     return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of the same K=5 B=32 Nature-CNN step in {dt:.1f} s (oracle/torch_ref.BatchedStep, "
-                      f"torch-CPU fp32, {cores} threads; JAX is not installable here)"}
+                      f"torch-CPU fp32, {cores} threads; the JAX leg is probed separately: cpu_baseline.jax)"}
+
+
+def sampling_leg(reps=300):
+    """the integer / byte side of the path, reported separately (rank 0, N = 1): the stacked replay gather of a
+    32-sample minibatch out of the HBM frame ring (replay_buffer.py:223-229), SumTree.query and SumTree.set on a
+    2^20-leaf tree (sum_tree.py:20-102).  HIP events on the launch stream over `reps` back-to-back calls each."""
+    import torch
+
+    from slimdqn import _hip
+
+    lib, q = _hip.lib(), _hip.current_stream()
+    rng = np.random.default_rng(0)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    out = {}
+    n_frames, fe, stack, cap = 1 << 15, 84 * 84, 4, 1 << 14
+    frames = torch.randint(0, 256, (n_frames, fe), dtype=torch.uint8, device="cuda")
+    meta = np.zeros((cap, 8), np.int32)
+    meta[:, 0] = rng.integers(8, n_frames - 8, cap)
+    meta[:, 1] = 4
+    meta[:, 2] = meta[:, 0] + 1
+    meta[:, 3] = 4
+    meta_dev = torch.from_numpy(meta).cuda()
+    for B in (32, 256):
+        slots = torch.from_numpy(rng.integers(0, cap, B).astype(np.int32)).cuda()
+        so = torch.empty((B, fe, stack), dtype=torch.uint8, device="cuda")
+        s2o = torch.empty((B, fe, stack), dtype=torch.uint8, device="cuda")
+        ao = torch.empty(B, dtype=torch.int32, device="cuda")
+        ro = torch.empty(B, dtype=torch.float32, device="cuda")
+        to = torch.empty(B, dtype=torch.uint8, device="cuda")
+
+        def gather():
+            _hip.check(lib.replay_gather_stacked(_hip.ptr(frames), n_frames, fe, 1, stack, _hip.ptr(meta_dev), _hip.ptr(slots), B,
+                                                 _hip.ptr(so), _hip.ptr(s2o), _hip.ptr(ao), _hip.ptr(ro), _hip.ptr(to), q),
+                       "replay_gather_stacked")
+
+        dt = timed(gather)
+        moved = 2 * 2 * B * fe * stack  # frames read + stacks written, state and next_state
+        out[f"gather_B{B}"] = {"us": dt * 1e6, "GBps": moved / dt / 1e9, "bytes": moved}
+    depth = 21
+    nodes = torch.zeros(2**depth - 1, dtype=torch.float64, device="cuda")
+    scratch = torch.empty(16 * 4096, dtype=torch.uint8, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pri = rng.random(1 << 20) + 0.01
+    for lo in range(0, 1 << 20, 4096):
+        idx = torch.arange(lo, lo + 4096, dtype=torch.int32, device="cuda")
+        val = torch.from_numpy(pri[lo : lo + 4096]).cuda()
+        _hip.check(lib.sumtree_set(_hip.ptr(nodes), depth, _hip.ptr(idx), _hip.ptr(val), 4096, _hip.ptr(scratch), q), "sumtree_set")
+    root = float(nodes[0].item())
+    for B in (32, 256):
+        targets = torch.from_numpy(rng.uniform(0, root * (1 - 1e-9), B)).cuda()
+        leaves = torch.empty(B, dtype=torch.int32, device="cuda")
+        idx = torch.from_numpy(rng.integers(0, 1 << 20, B).astype(np.int32)).cuda()
+        val = torch.from_numpy(rng.random(B)).cuda()
+        dq = timed(lambda: _hip.check(lib.sumtree_query(_hip.ptr(nodes), depth, _hip.ptr(targets), B, _hip.ptr(leaves),
+                                                        _hip.ptr(status), q), "sumtree_query"))
+        ds = timed(lambda: _hip.check(lib.sumtree_set(_hip.ptr(nodes), depth, _hip.ptr(idx), _hip.ptr(val), B, _hip.ptr(scratch), q),
+                                      "sumtree_set"))
+        out[f"sumtree_B{B}"] = {"query_us": dq * 1e6, "set_us": ds * 1e6, "leaves": 1 << 20, "depth": depth,
+                                "query_GBps": B * (depth - 1) * 8 / dq / 1e9, "set_GBps": B * depth * 16 / ds / 1e9}
+    out["what"] = ("replay_gather_stacked out of a 2^15-frame ring (bytes = frames read + stacks written); sum tree of 2^20 "
+                   "leaves: query = B x 20 dependent 8-byte reads, set = B x 21 read-modify-writes; latency-bound, bytes for scale")
+    return out
+
+
+def jax_cpu_probe(budget_s=10.0, n_actions=N_ACTIONS):
+    """BASELINE.md 2.2 names a JAX-CPU leg.  jax is not installed in the build container; this probes for it on the box the
+    bench runs on (JAX_PLATFORMS=cpu) and, if it imports, times a from-scratch jit(vmap(value_and_grad) + Adam) of the same
+    step on the same synthetic inputs (slimdqn/networks/idqn.py:96-109 is the shape of it: no reference file is used) and
+    returns per-head losses + a few gradient probes of the small golden case -- vectors this build did not author.
+    Otherwise the reason is recorded ("ImportError: ...")."""
+    os.environ.setdefault("JAX_PLATFORMS", "cpu")
+    try:
+        import jax
+        import jax.numpy as jnp
+    except Exception as e:  # noqa: BLE001
+        return {"status": f"{type(e).__name__}: {e}"}
+    try:
+        from oracle import make_golden as G
+        from oracle import qnet_ref as Q
+
+        def net(p, x):
+            a = x.astype(jnp.float32) / 255.0
+            for li, (k, s) in enumerate(Q.CNN_GEOM):
+                a = jax.lax.conv_general_dilated(a, p[f"Conv_{li}/kernel"], (s, s), "SAME", dimension_numbers=("NHWC", "HWIO", "NHWC"))
+                a = jax.nn.relu(a + p[f"Conv_{li}/bias"])
+            a = a.reshape(a.shape[0], -1)
+            a = jax.nn.relu(a @ p["Dense_0/kernel"] + p["Dense_0/bias"])
+            return a @ p["Dense_1/kernel"] + p["Dense_1/bias"]
+
+        def loss(p, pt, batch, gamma_n):
+            s, a, r, s2, t = batch
+            tgt = r + (1.0 - t) * gamma_n * net(pt, s2).max(1)
+            q = jnp.take_along_axis(net(p, s), a[:, None], axis=1)[:, 0]
+            return jnp.mean((q - tgt) ** 2)
+
+        def step(p, pt, m, v, count, batch, lr, eps, gamma_n):
+            def one(pk, ptk, mk, vk, ck):
+                l, g = jax.value_and_grad(loss)(pk, ptk, batch, gamma_n)
+                t = ck + 1
+                mk = jax.tree_util.tree_map(lambda mm, gg: 0.1 * gg + 0.9 * mm, mk, g)
+                vk = jax.tree_util.tree_map(lambda vv, gg: 0.001 * gg * gg + 0.999 * vv, vk, g)
+                bc1, bc2 = 1 - 0.9 ** t, 1 - 0.999 ** t
+                pk = jax.tree_util.tree_map(lambda th, mm, vv: th - lr * (mm / bc1) / (jnp.sqrt(vv / bc2) + eps), pk, mk, vk)
+                return pk, mk, vk, t, l, g
+            return jax.vmap(one)(p, pt, m, v, count)
+
+        jstep = jax.jit(step, static_argnums=(6, 7, 8))
+
+        def run(p, pt, batch):
+            pj = {n: jnp.asarray(a) for n, a in p.items()}
+            ptj = {n: jnp.asarray(a) for n, a in pt.items()}
+            z = {n: jnp.zeros_like(a) for n, a in pj.items()}
+            K = next(iter(p.values())).shape[0]
+            s, a, r, s2, t = batch
+            b = (jnp.asarray(s), jnp.asarray(a.astype(np.int32)), jnp.asarray(r), jnp.asarray(s2), jnp.asarray(t.astype(np.float32)))
+            return pj, ptj, z, jnp.zeros(K, jnp.int32), b
+
+        out = {"status": "ok", "jax_version": jax.__version__, "devices": str(jax.devices())}
+        # (1) vectors: the small golden case, first step
+        p, pt, batches = G.fp_case_inputs("cnn_small")
+        pj, ptj, z, c, b = run(p, pt, batches[0])
+        _, _, _, _, l, g = jstep(pj, ptj, z, z, c, b, 6.25e-5, 1.5e-4, 0.99)
+        out["cnn_small_losses"] = [float(x) for x in l]
+        out["cnn_small_grad_probes"] = {n: [float(x) for x in np.asarray(gg).reshape(gg.shape[0], -1)[:, :8].reshape(-1)] for n, gg in g.items()}
+        # (2) timing: the headline config
+        cores = usable_cores()
+        p = Q.init_params(0, "cnn", OBS, n_actions, FEATURES, K_HEADS)
+        pt = Q.init_params(1, "cnn", OBS, n_actions, FEATURES, K_HEADS)
+        s, a, r, s2, t = synthetic(0, n_actions)
+        pj, ptj, m, c, b = run(p, pt, (s, a, r, s2, t))
+        v = m
+        pj, m, v, c, l, _ = jstep(pj, ptj, m, v, c, b, 6.25e-5, 1.5e-4, 0.99)
+        jax.block_until_ready(l)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            pj, m, v, c, l, _ = jstep(pj, ptj, m, v, c, b, 6.25e-5, 1.5e-4, 0.99)
+            jax.block_until_ready(l)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 200:
+                break
+        out.update({"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "jax",
+                    "sample": f"{n} jitted steps (vmap over K=5 heads, value_and_grad + Adam) in {dt:.1f} s on the host CPU"})
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"status": f"harness error: {type(e).__name__}: {e}"}
 
 
 def main():
@@ -305,9 +463,15 @@ def main():
             "kernels": kernels,
             "final_losses": [float(x) for x in losses],
         }
+        if not dp:
+            try:
+                out["sampling"] = sampling_leg()
+            except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg
+                out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
         if not dp and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_actions=A)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["jax"] = jax_cpu_probe(n_actions=A)  # "ImportError: ..." where jax is not installed
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
         dist.destroy_process_group()

@@ -47,7 +47,23 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
         }
     }
     __syncthreads();
-    // 2. bitonic sort by (leaf, position): ascending leaves, first occurrence first (np.unique)
+    // 2. sort by (leaf, position): ascending leaves, first occurrence first (np.unique).  Up to one key per thread: every
+    //    thread counts the keys below its own (keys are unique, LDS broadcast reads, no barrier per round) and drops its key
+    //    at that rank -- a minibatch-sized write-back spent most of its time in the bitonic network's 36-55 barriers.
+    if (n <= ST_THREADS) {
+        const unsigned long long mine = tid < n ? key[tid] : ~0ull;
+        int rank = 0;
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            unsigned long long kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = key[min(j0 + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (j0 + u < n && kk[u] < mine) ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < n) key[rank] = mine;
+        __syncthreads();
+    } else
     for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < m; i += ST_THREADS) {
@@ -96,12 +112,29 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
         const int s0 = pr / depth, level = pr - s0 * depth;  // the long runs near the root land on different lanes
         const unsigned int node = ((cur[s0] + 1u) >> level) - 1u;
         if (s0 == 0 || ((cur[s0 - 1] + 1u) >> level) - 1u != node) {
+            // The run's deltas are added strictly one after the other (that order IS the result), but its LDS operands do
+            // not depend on the running sum: eight (delta, leaf) pairs are fetched per round, so the chain costs one fp64
+            // add per element instead of an LDS round trip per element (the root's run is all n elements: 34 -> ~12 us
+            // for a 256-leaf write-back).
             double x = nodes[node];
             int e = s0;
-            do {
-                x = x + sdelta[e];
-                ++e;
-            } while (e < n && ((cur[e] + 1u) >> level) - 1u == node);
+            bool more = true;
+            while (more) {
+                double d[8];
+                unsigned int c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(e + u, n - 1);
+                    d[u] = sdelta[i];
+                    c[u] = cur[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    more = more && e + u < n && ((c[u] + 1u) >> level) - 1u == node;
+                    if (more) x = x + d[u];
+                }
+                e += 8;
+            }
             nodes[node] = x;
         }
     }

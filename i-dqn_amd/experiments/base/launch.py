@@ -47,7 +47,8 @@ def make_agent(algo, key, obs_dim, n_actions, p, adam_eps):
 def launch(env_name, algo, argvs, env=None, save_root=None):
     """Parses the flags, builds environment / replay buffer / agent and trains; returns ``(p, agent)``."""
     # the trainer steps the same two batch-buffer sets over and over: let the library replay the step's launches as one
-    # hipGraph per set (read once, at the first step; results are bit-identical, tests/test_gpu_switches.py)
+    # hipGraph per set (IDQN_STEP_GRAPH, default 0 everywhere else, is switched ON here; read once, at the first step;
+    # results are bit-identical: tests/test_gpu_switches.py runs this entry point both ways)
     os.environ.setdefault("IDQN_STEP_GRAPH", "1")
     consts = ENVIRONMENTS[env_name]
     p = prepare_logs(env_name, algo, argvs, save_root)
@@ -56,6 +57,7 @@ def launch(env_name, algo, argvs, env=None, save_root=None):
     rb = ReplayBuffer(UniformSamplingDistribution(p["seed"]), batch_size=p["batch_size"],
                       max_capacity=p["replay_buffer_capacity"], stack_size=consts["stack_size"],
                       update_horizon=p["update_horizon"], gamma=p["gamma"], clipping=consts["clipping"], compress=True)
+    rb.reuse_sample_buffers = True  # the loop below consumes every batch before it draws the next (two staging sets in turn)
     agent = make_agent(algo, agent_key, observation_dim(env_name, env), env.n_actions, p, consts["adam_eps"])
     train(train_key, p, agent, env, rb, save_fn=save_data)
     return p, agent

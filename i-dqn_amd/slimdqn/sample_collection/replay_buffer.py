@@ -184,6 +184,10 @@ class ReplayBuffer:
         self._frames = None  # device [n_frames][frame_bytes] uint8, allocated at the first add
         self._memory = _MemoryView(self)
         self._stage = {}
+        # sample() hands out FRESH device arrays by default, like the reference (replay_buffer.py:229 stacks new arrays).
+        # The trainer loop, which consumes a batch before it draws the next one, sets this to True: sample() then returns
+        # the same ReplayElement object per staging set (views that the second-next sample of that size overwrites).
+        self.reuse_sample_buffers = False
         self._t = 0  # transitions pushed so far == index of the next frame
         self._flushed = 0  # elements whose metadata row is already on the device
 
@@ -404,7 +408,12 @@ class ReplayBuffer:
         _hip.check(_hip.lib().replay_gather_stacked(
             _hip.ptr(self._frames), self._n_frames, self._frame_elems, self._itemsize, self._stack_size, *st["gargs"],
             _hip.current_stream()), "replay_gather_stacked")
-        return st["element"]
+        if self.reuse_sample_buffers:
+            return st["element"]
+        e = st["element"]  # detached copies (stream-ordered device copies behind the gather)
+        return ReplayElement(state=DevArray(e.state.tensor.clone()), action=DevArray(e.action.tensor.clone()),
+                             reward=DevArray(e.reward.tensor.clone()), next_state=DevArray(e.next_state.tensor.clone()),
+                             is_terminal=DevArray(e.is_terminal.tensor.clone()), episode_end=DevArray(e.episode_end.tensor.clone()))
 
     def sample(self, size=None) -> ReplayElement:
         assert self.add_count, ValueError("No samples in replay buffer!")

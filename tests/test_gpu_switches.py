@@ -74,3 +74,35 @@ def test_acting_by_copy_and_sync_matches(default_run):
     got = _run(IDQN_ACT_POLL="0")
     assert got["acts"] == default_run["acts"]
     assert got["losses"] == default_run["losses"]
+
+
+TRAINER_CHILD = r"""
+import json, sys, os, tempfile
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np
+from experiments.atari.idqn import run
+argv = ["-en", "g", "-s", "3", "-ne", "1", "-ntspe", "90", "-nis", "40", "-rbc", "120", "-nn", "2", "-at", "cnn",
+        "-tuf", "20", "-tsf", "5", "-f", "32", "64", "64", "128", "-horizon", "30", "-bs", "32"]
+p, agent = run(argv, save_root=tempfile.mkdtemp())
+flat = agent._flat(agent._online)
+tflat = agent._flat(agent._target)
+probe = {name: v.reshape(2, -1)[:, :: max(1, v[0].size // 61)].astype(np.float64).tolist() for name, v in flat.items()}
+tprobe = {name: v.reshape(2, -1)[:, :: max(1, v[0].size // 61)].astype(np.float64).tolist() for name, v in tflat.items()}
+print("RESULT" + json.dumps({"probe": probe, "target": tprobe, "count": int(agent._count[0].item())}))
+"""
+
+
+def test_trainer_loop_with_and_without_step_graph():
+    """The trainer's launcher switches IDQN_STEP_GRAPH on (experiments/base/launch.py).  The whole loop -- acting graphs,
+    replay staging sets, gradient steps, T-step copies and shifts, D-step syncs in between -- must end with bit-identical
+    online and target parameters whether the step is replayed as a graph or issued launch by launch."""
+    def run(flag):
+        e = dict(os.environ, IDQN_STEP_GRAPH=flag)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + TRAINER_CHILD], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+
+    a, b = run("1"), run("0")
+    assert a["count"] == b["count"] and a["count"] >= 40
+    assert a["probe"] == b["probe"]
+    assert a["target"] == b["target"]
