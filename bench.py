@@ -266,6 +266,10 @@ def main():
                     help="rehearse the data-parallel path (RCCL all-reduce + two-phase step) even with one rank")
     ap.add_argument("--actions", type=int, default=N_ACTIONS, help="action count A (SURVEY 8d: 6, repeat with 18)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="ONE GPU: the compute side of rank 0 of an N-rank factored data-parallel step (the fused Dense_0 update "
+                         "runs over N sample blocks: this rank's factors N times), no collective; a regression guard for the "
+                         "part of weak scaling that does not depend on xGMI")
     ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
                     help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
                          "has no quantile code), one GPU, its own JSON line")
@@ -324,6 +328,8 @@ def main():
         # choice (stderr only; the JSON line goes to stdout), IDQN_NCCL_DEBUG overrides
         os.environ["NCCL_DEBUG"] = os.environ.get("IDQN_NCCL_DEBUG", "INFO" if rank == 0 else "WARN")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        if rank == 0:  # rank 0's RCCL log also goes to a file that the JSON line quotes from (rccl.debug_excerpt)
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/idqn_rccl_rank0_{os.getpid()}.log")
         assert world == args.gpus, f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -336,6 +342,8 @@ def main():
         return head_parallel_bench(args, rank, world, json_fd, Batch)
     if args.algo == "iiqn":
         return iiqn_bench(args, json_fd, Batch)
+    if args.emulate_ranks:
+        return emulate_ranks_bench(args, json_fd, Batch)
     A = args.actions
     agent = iDQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
     # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
@@ -463,6 +471,8 @@ def main():
             "kernels": kernels,
             "final_losses": [float(x) for x in losses],
         }
+        if dp:
+            out["rccl"] = rccl_report(dp_mode, world, agent)
         if not dp:
             try:
                 out["sampling"] = sampling_leg()
@@ -586,6 +596,91 @@ def iiqn_bench(args, json_fd, Batch):
         out["cpu_baseline"] = iiqn_cpu_baseline(A, N)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def emulate_ranks_bench(args, json_fd, Batch):
+    """Rank 0's compute of an N-rank factored step on one GPU (slimdqn/networks/parallel.py issues exactly these calls; the
+    all-gather is replaced by N copies of this rank's own factors)."""
+    import ctypes as C  # noqa: F401
+
+    import torch
+
+    from slimdqn import _hip
+    from slimdqn.networks.idqn import iDQN
+
+    N, A = args.emulate_ranks, args.actions
+    agent = iDQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i, A))) for i in range(8)]
+    lib, q = _hip.lib(), _hip.current_stream
+    K = agent._K
+    F, J = next(shape for name, _, shape in agent._leaves if name == "Dense_0/kernel")
+    X, Y = F * 32, J * 32
+    n_a3, n_dh = K * X, K * Y
+    send = torch.zeros(n_a3 + n_dh, dtype=torch.float32, device="cuda")
+    gathered = torch.zeros(N * (n_a3 + n_dh), dtype=torch.float32, device="cuda")
+    it = [0]
+
+    def step():
+        agent._learn(batches[it[0] % 8], flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD, mean_divisor=32 * N)
+        it[0] += 1
+        _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()), "export")
+        for r in range(N):  # (stands for the all-gather: every slot holds this rank's factors)
+            gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
+        _hip.check(lib.idqn_backward_rest(agent._handle, q()), "rest")
+        fa = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), N, 1, n_a3 + n_dh, X, X, n_a3 + n_dh, Y, Y)
+        _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_DENSE0, q()), "finish")
+        _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_REST, q()), "finish")
+
+    for _ in range(args.warmup):
+        step()
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    elapsed = float(np.median(regions))
+    out = {"metric": "compute side of one rank of an N-rank factored i-DQN step (no collective), steps/s", "emulated_ranks": N,
+           "value": args.steps / elapsed, "unit": "rank-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "note": f"includes {N} device copies of the 5.3 MB factor block standing in for the all-gather; the Dense_0 update "
+                   f"contracts {N} sample blocks per head",
+           "final_losses": [float(x) for x in agent._losses.cpu().numpy()]}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def rccl_report(dp_mode, world, agent):
+    """What the first multi-GPU run should explain by itself: bytes handed to each collective per step, and RCCL's own
+    lines about topology / algorithm / channels (NCCL_DEBUG_FILE of rank 0, set before the communicator is created)."""
+    K, P = K_HEADS, None
+    rep = {"mode": dp_mode, "world": world, "collectives_per_step": []}
+    try:
+        F, J = next(shape for name, _, shape in agent._leaves if name == "Dense_0/kernel")
+        small = int(agent._grad_small.numel()) * 4
+        if dp_mode == "factored":
+            per_rank = K * (F + J) * 32 * 4
+            rep["collectives_per_step"] = [
+                {"op": "all_gather", "what": "Dense_0 gradient factors a3 | dh", "bytes_sent_per_rank": per_rank,
+                 "bytes_received_per_rank": per_rank * (world - 1)},
+                {"op": "all_reduce", "what": "small-leaf gradients + K losses", "bytes": small}]
+        else:
+            rep["collectives_per_step"] = [
+                {"op": "all_reduce", "what": "Dense_0/kernel gradients", "bytes": int(agent._grad_w0.numel()) * 4},
+                {"op": "all_reduce", "what": "small-leaf gradients + K losses", "bytes": small}]
+    except Exception as e:  # noqa: BLE001
+        rep["error"] = f"{type(e).__name__}: {e}"
+    try:
+        path = os.environ.get("NCCL_DEBUG_FILE", "")
+        if path and os.path.exists(path):
+            keep = ("Channel", "Ring", "Tree", "Using", "algo", "proto", "nChannels", "XGMI", "P2P", "NET/", "comm 0x")
+            lines = [ln.strip() for ln in open(path, errors="replace") if any(k in ln for k in keep)]
+            rep["debug_excerpt"] = lines[:40]
+            rep["debug_lines"] = len(lines)
+    except Exception as e:  # noqa: BLE001
+        rep["debug_error"] = f"{type(e).__name__}: {e}"
+    return rep
 
 
 def head_parallel_bench(args, rank, world, json_fd, Batch):

@@ -29,6 +29,11 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
 // CONTIGUOUS slice of [0, gridDim.x): neighbouring work items (the taps of one position chunk, adjacent output
 // positions of one net, the f tiles of one head) then re-read each other's operands from the same L2 instead of
 // every L2 fetching everything.  Bijective for any grid size (cdna_hip_programming.md, T1).
+__device__ __forceinline__ int xcd_contiguous_id_n(const int n) {  // the same over the FIRST n blocks of a larger grid
+    const int b = (int)blockIdx.x;
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 __device__ __forceinline__ int xcd_contiguous_id() {
     const int n = (int)gridDim.x, b = (int)blockIdx.x;
     const int q = n >> 3, r = n & 7, x = b & 7;

@@ -69,6 +69,7 @@ struct DenseWgradArgs {
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
+    int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
     float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
     // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
     // dhp[plane][bb][k][J * 32]
@@ -100,6 +101,10 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
     static_assert(!FUSE_DG || (FUSE_ADAM && NQ == 2), "the fused data gradient rides on the fused 256-column kernel");
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    // FUSE_DG with upd_end >= 0: items from upd_end on are DEFERRED -- their update runs later, in the stream role of a conv
+    // launch; here such a workgroup only produces its share of the data gradient (theta rows -> LDS -> phase 3), because
+    // the conv backward needs dL/da3 of every row before it can start.  Workgroup-uniform.
+    const bool upd = !FUSE_DG || a.upd_end < 0 || item < a.upd_end;
     const int jt = item % a.n_jt;
     item /= a.n_jt;
     const int ft = item % a.n_ft;
@@ -114,7 +119,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     // iterations are requested before the MFMA phase, so the workgroup keeps streaming while it computes its tile
     constexpr int DEPTH = D0W_DEPTH;
     float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
-    if (FUSE_ADAM) {
+    if (FUSE_ADAM && upd) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const long on = o0 + (long)(RPI * d) * a.J;
@@ -128,7 +133,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    for (int bb = 0; bb < a.nb; ++bb) {
+    for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
             const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
@@ -181,7 +186,18 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
         for (int r = 0; r < 16; ++r) gs[rot(mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
     __syncthreads();
-    if (FUSE_ADAM) {
+    if (FUSE_DG && !upd) {  // deferred item: the pre-update theta tile goes to LDS as phase 2 would leave it, nothing is stored
+#pragma unroll
+        for (int i0 = 0; i0 < NIT; i0 += 8) {
+            float4 tt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < NIT) tt[u] = ld4<(D0_WG_NT & 1) != 0>(a.theta + o0 + (long)(RPI * (i0 + u)) * a.J);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < NIT) *reinterpret_cast<float4*>(&gs[rot(RPI * (i0 + u) + prow, pcol)]) = tt[u];
+        }
+    } else if (FUSE_ADAM) {
         const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {

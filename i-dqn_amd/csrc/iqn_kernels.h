@@ -71,13 +71,33 @@ __global__ __launch_bounds__(256) void k_iqn_embed(IqnEmbedArgs a) {
     }
 }
 
-// Z of the three virtual nets of head k from the Dense_1 chunk partials, greedy target action, targets, quantile Huber
-// loss and its gradient.  One workgroup per head: thread = (sample b = t & 31, group g = t >> 5).
-struct IqnLossArgs {
+// Z[slot][action][b] = b1[action] + the Dense_1 chunk partials in chunk order: one workgroup per (virtual net, fraction).
+struct IqnZArgs {
     const float* qpart;         // [V * N][J / 32][32 (action)][32]
     const float* const* wbase;  // [V]
+    float* z;                   // [V * N][A][32]
     long b1_off;
-    int K, N, NJC, A, B, Bdiv;
+    int N, NJC, A;
+};
+__global__ __launch_bounds__(256) void k_iqn_z(IqnZArgs a) {
+    const int slot = blockIdx.x;
+    const float* P = a.wbase[slot / a.N];
+    for (int e = threadIdx.x; e < a.A * 32; e += 256) {
+        const float* p = a.qpart + (long)slot * a.NJC * 1024 + e;
+        float s = 0.f;
+        for (int c = 0; c < a.NJC; c += 4) {  // NJC is a multiple of 4 (J a multiple of 128); chunk order
+            const float x0 = p[(c + 0) * 1024], x1 = p[(c + 1) * 1024], x2 = p[(c + 2) * 1024], x3 = p[(c + 3) * 1024];
+            s = (((s + x0) + x1) + x2) + x3;
+        }
+        a.z[(long)slot * a.A * 32 + e] = s + P[a.b1_off + (e >> 5)];
+    }
+}
+
+// Greedy target action, targets, quantile Huber loss and its gradient from the Z of the three virtual nets of head k.
+// One workgroup per head: thread = (sample b = t & 31, group g = t >> 5).
+struct IqnLossArgs {
+    const float* z;  // [V * N][A][32]
+    int K, N, A, B, Bdiv;
     const int32_t* action;
     const float* reward;
     const uint8_t* terminal;
@@ -98,20 +118,18 @@ __global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs a) {
     float* qsel = zval + N * 32; // [32][32]
     float* red = qsel + 32 * 32; // [8][32]
     __shared__ int astar[32], act[32];
-    const float* Pt = a.wbase[a.K + k];
-    const float* Po = a.wbase[k];
-    auto zsum = [&](int v, int q, int ac) {  // b1 + chunk partials in chunk order
-        const float* p = a.qpart + (((long)(v * N + q) * a.NJC) * 32 + ac) * 32 + b;
-        float s = 0.f;
-        for (int c = 0; c < a.NJC; ++c) s += p[(long)c * 1024];
-        return s;
-    };
+    auto zat = [&](int v, int q, int ac) { return a.z[((long)(v * N + q) * a.A + ac) * 32 + b]; };
     if (t < 32) act[t] = t < a.B ? a.action[t] : 0;
     // mean over the selection fractions of the target net's Z, per action (fraction order)
     for (int ac = g; ac < a.A; ac += 8) {
-        const float b1 = Pt[a.b1_off + ac];
         float s = 0.f;
-        for (int q = 0; q < N; ++q) s += zsum(a.K + k, q, ac) + b1;
+        for (int q0 = 0; q0 < N; q0 += 8) {
+            float zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) zz[u] = q0 + u < N ? zat(a.K + k, q0 + u, ac) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += zz[u];
+        }
         qsel[ac * 32 + b] = s / (float)N;
     }
     __syncthreads();
@@ -126,8 +144,8 @@ __global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs a) {
     }
     __syncthreads();
     for (int q = g; q < N; q += 8) {
-        zval[q * 32 + b] = zsum(2 * a.K + k, q, astar[b]) + Pt[a.b1_off + astar[b]];
-        zon[q * 32 + b] = zsum(k, q, act[b]) + Po[a.b1_off + act[b]];
+        zval[q * 32 + b] = zat(2 * a.K + k, q, astar[b]);
+        zon[q * 32 + b] = zat(k, q, act[b]);
     }
     __syncthreads();
     const bool live = b < a.B;

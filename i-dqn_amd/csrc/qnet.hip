@@ -172,7 +172,7 @@ struct IqnWs {
     int N = 0, V = 0, NS = 2;
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
-          *dx = nullptr, *dpsi = nullptr, *dbg = nullptr;
+          *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
     long off_we = 0, off_be = 0;
 };
 
@@ -250,6 +250,10 @@ struct idqn_handle_s {
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
+    // Overlap of the fused Dense_0 update with the conv backward (cnn_backward): the last n_def update items are deferred
+    // to the stream roles of the Conv_2 pair launch (S2 workgroups x r2 rounds) and of the Conv_0 weight-gradient launch
+    // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
+    struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
     hipEvent_t d0_wait = nullptr;  // experiment hook: the training forward waits for this event in front of its Dense_0 launch
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
@@ -502,6 +506,7 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.part, VN * w.NS * h->J * 32, h, "iqn_part"))) return rc;
         if ((rc = alloc_zero(&w.hbuf, VN * h->J * 32, h, "iqn_h"))) return rc;
         if ((rc = alloc_zero(&w.qpart, VN * (h->J / 32) * 32 * 32, h, "iqn_qpart"))) return rc;
+        if ((rc = alloc_zero(&w.z, VN * c.n_actions * 32, h, "iqn_z"))) return rc;
         if ((rc = alloc_zero(&w.dq, KN * c.n_actions * 32, h, "iqn_dq"))) return rc;
         if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
         if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
@@ -899,19 +904,43 @@ int wgrad_args(idqn_handle_s* h, int layer, int nb, int n_chunks, CWgradArgs& a,
     return IDQN_OK;
 }
 
-int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
+// takes up to `rounds` rounds of S workgroups (two items each) of the deferred Dense_0 update for a conv launch's stream role
+bool overlap_take(idqn_handle_s* h, int S, int rounds, D0Stream& ds) {
+    auto& ov = h->ov;
+    if (S <= 0 || rounds <= 0 || ov.left < 2 * S) return false;
+    const int r = std::min(rounds, ov.left / (2 * S));
+    ds.w = ov.dw; ds.item0 = ov.next; ds.rounds = r; ds.n_sb = S;
+    ov.next += 2 * S * r;
+    ov.left -= 2 * S * r;
+    return true;
+}
+
+// spare != nullptr: plan only -- *spare = workgroups this launch would leave to a stream role (0: it cannot carry one)
+int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q, int budget = 0, int stream_rounds = 0, int* spare = nullptr) {
     CWgradArgs a;
     WgradPlan* pl;
-    int rc = wgrad_args(h, layer, nb, 0, a, pl);
+    const int per_chunk = h->cfg.n_heads * (layer == 0 ? 1 : h->conv[layer].K);
+    int rc = wgrad_args(h, layer, nb, budget > 0 ? std::max(1, budget / per_chunk) : 0, a, pl);
     if (rc) return rc;
+    const int NPX = layer == 0 ? 1 : 3, CT = h->conv[layer].CO / 32;
+    if (spare) {
+        *spare = convp_wgrad_stream_built(NPX, pl->MT, CT, pl->PG) ? std::max(0, 256 - pl->n_items) : 0;
+        return IDQN_OK;
+    }
     h->npc_used[layer] = pl->n_chunks;
-    return convp_launch_wgrad(a, layer == 0 ? 1 : 3, pl->MT, h->conv[layer].CO / 32, pl->n_items, pl->lds, q);
+    D0Stream ds;
+    if (stream_rounds > 0 && convp_wgrad_stream_built(NPX, pl->MT, CT, pl->PG) && overlap_take(h, 256 - pl->n_items, stream_rounds, ds))
+        return convp_launch_wgrad(a, NPX, pl->MT, CT, pl->n_items, pl->lds, q, &ds);
+    return convp_launch_wgrad(a, NPX, pl->MT, CT, pl->n_items, pl->lds, q);
 }
 
 // Data gradient of conv `layer` and weight gradient of the same layer in ONE launch (convp_pair.hip) when that pair of
 // kernels is built for the plans; *done = false: nothing was launched, the caller runs them one after the other.
-int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) {
+int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, int budget = 0, int stream_rounds = 0,
+                int* spare = nullptr) {
     *done = false;
+    if (spare) *spare = 0;
+    const int cus = budget > 0 ? budget : cu_budget();
     static const bool no_pair = getenv("IDQN_NO_PAIR") != nullptr;  // A/B switch
     if (no_pair || layer < 1 || layer > 2) return IDQN_OK;
     // experiment knobs: IDQN_PAIR_D<layer> = workgroups planned for the data gradient, IDQN_PAIR_C<layer> = position chunks
@@ -922,7 +951,7 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) 
         const char* e = getenv(nm);
         return e ? atoi(e) : dflt;
     };
-    const int d_target = knob("IDQN_PAIR_D", cu_budget() / 2);
+    const int d_target = knob("IDQN_PAIR_D", cus / 2);
     NetSet& s = h->train;
     const int role = layer == 2 ? 3 : 4, K = h->cfg.n_heads;
     const ConvL& l = h->conv[layer];
@@ -931,15 +960,25 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) 
     FwdPlan* pf;
     int rc = conv_args(h, s, role, nb, d_target, f, g, pf);
     if (rc) return rc;
-    const int n_chunks = std::min(knob("IDQN_PAIR_C", 1 << 20), (cu_budget() - pf->n_items) / (K * l.K));  // what is left of the chip, in whole position chunks
+    const int n_chunks = std::min(knob("IDQN_PAIR_C", 1 << 20), (cus - pf->n_items) / (K * l.K));  // what is left of the chip, in whole position chunks
     if (n_chunks < 1) return IDQN_OK;
     CWgradArgs w;
     WgradPlan* pw;
     if ((rc = wgrad_args(h, layer, nb, n_chunks, w, pw))) return rc;
     const int WCT = l.CO / 32, ntw = (pw->MT * WCT + 3) / 4;
-    if (pf->n_items + pw->n_items > cu_budget() || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
+    if (pf->n_items + pw->n_items > cus || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
+    if (spare) {  // plan only
+        if (pw->n_items >= 8 && convp_pair_stream_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG))
+            *spare = std::max(0, 256 - pf->n_items - pw->n_items);
+        return IDQN_OK;
+    }
     h->npc_used[layer] = pw->n_chunks;
     *done = true;
+    D0Stream ds;
+    if (stream_rounds > 0 && pw->n_items >= 8 && convp_pair_stream_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG) &&
+        overlap_take(h, 256 - pf->n_items - pw->n_items, stream_rounds, ds))
+        return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT,
+                                 pw->n_items, pw->lds, q, conv_prof(h, s, role, pf), &ds);
     return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT, pw->n_items,
                              pw->lds, q, conv_prof(h, s, role, pf));
 }
@@ -1118,8 +1157,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     dw.dh_outer = dh_outer; dw.dh_head = dh_head; dw.dh_inner = dh_inner;
     const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
-    dw.F = h->F; dw.J = h->J; dw.item0 = 0;
+    dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1;
+
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
+    if (fuse_dg && h->ov.n_def > 0) {
+        dw.upd_end = h->ov.next;  // first deferred item
+        h->ov.dw = dw;
+        h->ov.dw.upd_end = -1; h->ov.dw.dpart = nullptr;
+    }
     const dim3 wgrid((unsigned)dw.n_items);
     // profiling: the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so the
     // elapsed time is the kernel's, without the gaps that separate marker packets from their neighbours
@@ -1216,7 +1261,26 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
+    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel.  IDQN_OVERLAP=1: the update of its last items is
+    // deferred to stream roles of the Conv_2 pair and Conv_0 weight-gradient launches (they only emit their data-gradient
+    // share here); IDQN_OV_S2 / IDQN_OV_R2 / IDQN_OV_S0 / IDQN_OV_R0: stream workgroups and rounds per launch.
+    h->ov.n_def = h->ov.left = 0;
+    static const bool overlap = getenv("IDQN_OVERLAP") && atoi(getenv("IDQN_OVERLAP")) != 0;
+    if (overlap && fuse_dg && nb == 1 && h->planes) {
+        static const int S2 = getenv("IDQN_OV_S2") ? atoi(getenv("IDQN_OV_S2")) : 40, R2 = getenv("IDQN_OV_R2") ? atoi(getenv("IDQN_OV_R2")) : 2;
+        static const int S0 = getenv("IDQN_OV_S0") ? atoi(getenv("IDQN_OV_S0")) : 96, R0 = getenv("IDQN_OV_R0") ? atoi(getenv("IDQN_OV_R0")) : 1;
+        const int n_items = K * (h->F / 32) * (h->J / 256);
+        // S2 / S0 ask for that many CUs; the plans say how many workgroups the launches really leave (whole position chunks)
+        int sp2 = 0, sp0 = 0;
+        bool dummy;
+        int rcp = planes_pair(h, 2, nb, q, &dummy, 256 - S2, R2, &sp2);
+        if (!rcp) rcp = planes_wgrad(h, 0, nb, q, 256 - S0, R0, &sp0);
+        if (rcp) return rcp;
+        h->ov.S2 = S2; h->ov.r2 = sp2 > 0 ? R2 : 0; h->ov.S0 = S0; h->ov.r0 = sp0 > 0 ? R0 : 0;
+        h->ov.n_def = std::min(n_items / 2, 2 * (sp2 * h->ov.r2 + sp0 * h->ov.r0));
+        h->ov.left = h->ov.n_def;
+        h->ov.next = n_items - h->ov.n_def;
+    }
     int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
@@ -1252,12 +1316,25 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
         int rc = IDQN_OK;
         for (int i = 2; i >= 0 && !rc; --i) {
             bool paired = false;
-            if (i >= 1) rc = planes_pair(h, i, nb, q, &paired);
+            const bool ovl = h->ov.left > 0;  // deferred Dense_0 update items wait for a stream role
+            if (i == 2) rc = planes_pair(h, i, nb, q, &paired, ovl && h->ov.r2 ? 256 - h->ov.S2 : 0, ovl ? h->ov.r2 : 0);
+            else if (i == 1) rc = planes_pair(h, i, nb, q, &paired);
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
-            if (!rc) { rc = planes_wgrad(h, i, nb, q); tl_mark(h, q, nw[i]); }
+            if (!rc) {
+                if (i == 0 && ovl && h->ov.r0) rc = planes_wgrad(h, i, nb, q, 256 - h->ov.S0, h->ov.r0);
+                else rc = planes_wgrad(h, i, nb, q);
+                tl_mark(h, q, nw[i]);
+            }
         }
         if (rc) return rc;
+        if (h->ov.left > 0) {  // whatever no stream role took (a pair that is not built, an odd remainder): finish it here
+            DenseWgradArgs dw = h->ov.dw;
+            dw.item0 = h->ov.next;
+            hipLaunchKernelGGL((k_dense0_wgrad<true, 2>), dim3((unsigned)h->ov.left), dim3(256), 0, q, dw);
+            tl_mark(h, q, "dense0 wgrad + adam (deferred rest)");
+            h->ov.left = 0;
+        }
     } else {
         // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
         int rcb = build_dgrad_weights(h, q);
@@ -1536,8 +1613,12 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     // trunk of the 2K nets (online on s, target on s'), then the fraction blocks of the 3K virtual nets
     if ((rc = cnn_forward(h, h->train, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, batch, q, false))) return rc;
     if ((rc = iqn_heads_forward(h, w.wbase_v, w.V, K, h->train.a3, tau_dev, batch, q))) return rc;
+    IqnZArgs za;
+    za.qpart = w.qpart; za.wbase = w.wbase_v; za.z = w.z; za.b1_off = h->off_b1; za.N = w.N; za.NJC = h->J / 32; za.A = A;
+    hipLaunchKernelGGL(k_iqn_z, dim3((unsigned)(w.V * w.N)), dim3(256), 0, q, za);
+    tl_mark(h, q, "iqn quantile values");
     IqnLossArgs la;
-    la.qpart = w.qpart; la.wbase = w.wbase_v; la.b1_off = h->off_b1; la.K = K; la.N = w.N; la.NJC = h->J / 32; la.A = A;
+    la.z = w.z; la.K = K; la.N = w.N; la.A = A;
     la.B = batch; la.Bdiv = batch; la.action = action_dev; la.reward = reward_dev; la.terminal = terminal_dev; la.tau = tau_dev;
     la.gamma_n = h->gamma_n; la.dq = w.dq; la.losses = h->losses; la.count = h->count; la.cum = h->cum; la.finish_step = 1;
     la.dbg = w.dbg;

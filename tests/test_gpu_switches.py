@@ -5,6 +5,9 @@
   IDQN_NO_PAIR=1      conv data / weight gradients as two launches   -> same losses, parameters within fp32 round-off
                       (the weight gradient is cut into a different number of position chunks, i.e. summed in another order)
   IDQN_ACT_POLL=0     acting result by copy + synchronisation        -> same greedy actions as the polled mailbox
+  IDQN_OVERLAP=1      the last items of the fused Dense_0 update run as stream roles of the Conv_2 pair and Conv_0
+                      weight-gradient launches (csrc/dense0_update.h)   -> same losses, Dense_0 bit-identical, conv leaves
+                      within fp32 round-off (those launches are planned for fewer workgroups = other chunk sums)
 """
 import json
 import os
@@ -67,6 +70,13 @@ def test_unpaired_conv_backward_matches(default_run):
     np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
     for name, want in default_run["probe"].items():
         # six Adam steps at lr 6.25e-5 on gradients that differ in their last bits
+        np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_overlapped_dense0_update_matches(default_run):
+    got = _run(IDQN_OVERLAP="1")
+    np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
+    for name, want in default_run["probe"].items():
         np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
 
 
