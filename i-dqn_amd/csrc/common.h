@@ -47,6 +47,16 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Gradient arena addressing (include/idqn_hip.h): the cnn's Dense_0/kernel lives in a second region, every other leaf at
+// its parameter offset (minus that leaf's size when it comes later); fc: w0_begin == w0_end, gP = head stride.
+struct GradMap {
+    long gP, w0_begin, w0_end, g_w0_base;
+    __device__ __forceinline__ long at(int k, long e) const {
+        const long w0n = w0_end - w0_begin;
+        return e < w0_begin ? (long)k * gP + e : (e < w0_end ? g_w0_base + (long)k * w0n + (e - w0_begin) : (long)k * gP + e - w0n);
+    }
+};
+
 void idqn_set_error(const char* fmt, ...);
 
 #define IDQN_HIP_CHECK(expr)                                                                   \

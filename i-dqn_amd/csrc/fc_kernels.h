@@ -44,6 +44,10 @@ struct FcArgs {
     int finish_step;      // 1: also count += 1, cum += loss here (the Adam kernel reads bcinv, not count)
     const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
+    // generic kernel (k_fc_step) only -- the dense head of the general-shape cnn path (gcnn_kernels.h):
+    long s_stride;           // floats between the heads' own inputs in s / s2 (0: every head reads the same minibatch)
+    float* din;              // [K][B][d0] out: dL/d(input), masked by input > 0 (the conv features are ReLU outputs), or nullptr
+    GradMap gm;              // where a leaf's gradient lives in the arena
 };
 
 // out[b][o] = (relu?)(bias[o] + sum_i in[b][i] * W[i][o])
@@ -73,7 +77,9 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
     const float* pt = a.target + (long)k * a.P;
     float* G = a.grad + (long)k * a.P;
     // ---- target net on s'
-    for (int e = t; e < B * n.d[0]; e += 256) tA[(long)(e / n.d[0]) * dm + e % n.d[0]] = a.s2[e];
+    const float* s_in = a.s + (long)k * a.s_stride;
+    const float* s2_in = a.s2 + (long)k * a.s_stride;
+    for (int e = t; e < B * n.d[0]; e += 256) tA[(long)(e / n.d[0]) * dm + e % n.d[0]] = s2_in[e];
     __syncthreads();
     float *cur = tA, *nxt = tB;
     for (int l = 0; l < n.L; ++l) {
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
     for (int e = t; e < B * A; e += 256) a.q_dbg[((long)(a.K + k) * B) * A + e] = cur[(long)(e / A) * dm + e % A];
     __syncthreads();
     // ---- online net on s, activations kept
-    for (int e = t; e < B * n.d[0]; e += 256) acts[(long)(e / n.d[0]) * dm + e % n.d[0]] = a.s[e];
+    for (int e = t; e < B * n.d[0]; e += 256) acts[(long)(e / n.d[0]) * dm + e % n.d[0]] = s_in[e];
     __syncthreads();
     for (int l = 0; l < n.L; ++l)
         fc_layer(acts + (long)l * B * dm, dm, po + n.w_off[l], po + n.b_off[l], acts + (long)(l + 1) * B * dm, dm, B,
@@ -133,12 +139,22 @@ __global__ __launch_bounds__(256) void k_fc_step(FcArgs a) {
             int i = e / dout, o = e - i * dout;
             float s = 0.f;
             for (int b = 0; b < B; ++b) s = fmaf(in[(long)b * dm + i], delta[(long)b * dm + o], s);
-            G[n.w_off[l] + e] = s;
+            a.grad[a.gm.at(k, n.w_off[l] + e)] = s;
         }
         for (int o = t; o < dout; o += 256) {
             float s = 0.f;
             for (int b = 0; b < B; ++b) s += delta[(long)b * dm + o];
-            G[n.b_off[l] + o] = s;
+            a.grad[a.gm.at(k, n.b_off[l] + o)] = s;
+        }
+        if (l == 0 && a.din) {  // the conv trunk continues from here: dL/d(features), ReLU mask of the features included
+            for (int e = t; e < B * din; e += 256) {
+                int b = e / din, i = e - b * din;
+                float s = 0.f;
+                const float* wr = W + (long)i * dout;
+                const float* dr = delta + (long)b * dm;
+                for (int o = 0; o < dout; ++o) s = fmaf(dr[o], wr[o], s);
+                a.din[((long)k * B + b) * din + i] = in[(long)b * dm + i] > 0.f ? s : 0.f;
+            }
         }
         if (l > 0) {
             for (int e = t; e < B * din; e += 256) {  // dprev[b][i] = relu'(in[b][i]) * sum_o delta[b][o] W[i][o]

@@ -22,6 +22,7 @@
 #include "cnn_kernels.h"
 #include "fc_kernels.h"
 #include "iqn_kernels.h"
+#include "gcnn_kernels.h"
 
 namespace {
 
@@ -87,8 +88,20 @@ void add_leaf(Layout& L, const char* name, int ndim, const long* shape, long* of
 
 const int KS[3][2] = {{8, 4}, {4, 2}, {3, 1}};  // (kernel, stride) of Conv_0..2, architectures/dqn.py:43-51
 
+// Shapes the MFMA plane kernels (and the f32-MFMA conv kernels) are built for; every other cnn shape the reference's
+// DQNNet accepts runs on the general-shape kernels (gcnn_kernels.h).  IDQN_CNN_GENERAL=1 forces those (tests).
+bool cnn_fast_shape(const idqn_config_t& c) {
+    static const bool force_general = getenv("IDQN_CNN_GENERAL") && atoi(getenv("IDQN_CNN_GENERAL")) != 0;
+    if (c.n_quantiles > 0) return true;  // the i-IQN heads exist on the MFMA path only (its checks reject other shapes)
+    if (force_general) return false;
+    if (c.n_features != 4 || c.obs_c != 4 || c.obs_h < 8 || c.obs_w < 8 || c.n_actions > 32) return false;
+    for (int i = 0; i < 3; ++i)
+        if (c.features[i] != 32 && c.features[i] != 64) return false;
+    return c.features[3] % 128 == 0 && c.features[3] >= 128 && c.features[3] <= 512;
+}
+
 int build_layout(const idqn_config_t& c, Layout& L) {
-    IDQN_REQUIRE(c.n_heads >= 1 && c.n_actions >= 1 && c.n_actions <= 32, "n_heads >= 1 and 1 <= n_actions <= 32 required");
+    IDQN_REQUIRE(c.n_heads >= 1 && c.n_actions >= 1 && c.n_actions <= 4096, "n_heads >= 1 and 1 <= n_actions <= 4096 required");
     IDQN_REQUIRE(c.n_features >= 1 && c.n_features <= IDQN_MAX_FEATURES, "n_features out of range");
     IDQN_REQUIRE(c.max_batch >= 1, "max_batch must be positive");
     IDQN_REQUIRE(c.n_quantiles >= 0 && c.n_quantiles <= 64, "n_quantiles must be in [0, 64]");
@@ -96,7 +109,40 @@ int build_layout(const idqn_config_t& c, Layout& L) {
                  "i-IQN heads are built for the cnn arch and minibatches of at most 32 samples");
     long off = 0;
     char nm[32];
-    if (c.arch == IDQN_ARCH_CNN) {
+    if (c.arch == IDQN_ARCH_CNN && !cnn_fast_shape(c)) {
+        // general shape: three convs for features[0..2], Dense + ReLU for every features[3:], Dense(n_actions)
+        // (architectures/dqn.py:39-53,65-70)
+        IDQN_REQUIRE(c.n_quantiles == 0, "i-IQN heads need a shape the MFMA kernels are built for");
+        IDQN_REQUIRE(c.n_features >= 3, "cnn: at least 3 features (the three convs), got %d", c.n_features);
+        IDQN_REQUIRE(c.obs_h >= 1 && c.obs_w >= 1 && c.obs_c >= 1, "cnn: empty observation");
+        int h = c.obs_h, w = c.obs_w, ch = c.obs_c;
+        for (int i = 0; i < 3; ++i) {
+            IDQN_REQUIRE(c.features[i] >= 1, "cnn: conv width %d", c.features[i]);
+            long ks[4] = {KS[i][0], KS[i][0], ch, c.features[i]};
+            snprintf(nm, sizeof nm, "Conv_%d/kernel", i);
+            add_leaf(L, nm, 4, ks, &off);
+            long bs[1] = {c.features[i]};
+            snprintf(nm, sizeof nm, "Conv_%d/bias", i);
+            add_leaf(L, nm, 1, bs, &off);
+            int lo, hi;
+            same_pad(h, KS[i][0], KS[i][1], &h, &lo, &hi);
+            same_pad(w, KS[i][0], KS[i][1], &w, &lo, &hi);
+            ch = c.features[i];
+        }
+        long fan = (long)h * w * ch;
+        for (int i = 3; i <= c.n_features; ++i) {
+            long f = i < c.n_features ? c.features[i] : c.n_actions;
+            IDQN_REQUIRE(f >= 1, "cnn: dense width %ld", f);
+            long ws[2] = {fan, f};
+            snprintf(nm, sizeof nm, "Dense_%d/kernel", i - 3);
+            add_leaf(L, nm, 2, ws, &off);
+            long bs[1] = {f};
+            snprintf(nm, sizeof nm, "Dense_%d/bias", i - 3);
+            add_leaf(L, nm, 1, bs, &off);
+            fan = f;
+        }
+    } else if (c.arch == IDQN_ARCH_CNN) {
+        IDQN_REQUIRE(c.n_actions <= 32, "cnn (MFMA path): n_actions <= 32");
         IDQN_REQUIRE(c.n_features == 4, "cnn: exactly 4 features (three convs + one hidden dense) are built; got %d", c.n_features);
         IDQN_REQUIRE(c.obs_c == 4, "cnn: obs_c must be 4 (Conv_0 packs (kw, c) into 32 rows), got %d", c.obs_c);
         IDQN_REQUIRE(c.obs_h >= 8 && c.obs_w >= 8, "cnn: observation smaller than the first kernel");
@@ -132,6 +178,7 @@ int build_layout(const idqn_config_t& c, Layout& L) {
             add_leaf(L, "Embed_0/bias", 1, eb, &off);
         }
     } else if (c.arch == IDQN_ARCH_FC) {
+        IDQN_REQUIRE(c.n_actions <= FC_MAX_WIDTH, "fc: n_actions <= %d", FC_MAX_WIDTH);
         long fan = (long)c.obs_h * c.obs_w * c.obs_c;
         for (int i = 0; i <= c.n_features; ++i) {
             long f = i < c.n_features ? c.features[i] : c.n_actions;
@@ -176,6 +223,17 @@ struct IqnWs {
     long off_we = 0, off_be = 0;
 };
 
+// workspace of the general-shape cnn path (gcnn_kernels.h): NHWC f32 activations of the 2K nets, their gradients for the K
+// online nets, and the dense head as an FcNet over the flattened conv features
+struct GcnnWs {
+    bool on = false;
+    int Bmax = 0;
+    float *act[3] = {nullptr, nullptr, nullptr};   // [2K][Bmax][OH][OW][CO] of Conv_0..2 (act[2] flattened = the head's input)
+    float *dact[3] = {nullptr, nullptr, nullptr};  // [K][Bmax][...]: gradient w.r.t. the pre-activation of Conv_0..2
+    float *inf_act[3] = {nullptr, nullptr, nullptr};  // one net, 32 states (acting)
+    float* inf_ws = nullptr;
+};
+
 }  // namespace
 
 struct idqn_handle_s {
@@ -194,6 +252,7 @@ struct idqn_handle_s {
     long off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0;
     NetSet train, infer;
     IqnWs iqn;
+    GcnnWs gc;
     float* dpart = nullptr;  // partial Dense_0 data gradients of the fused weight-gradient kernel [n_jt][K * nb][F][32]
     float *da3 = nullptr, *da2 = nullptr, *da1 = nullptr, *qdbg = nullptr, *slab = nullptr;
     float *hbuf = nullptr, *qpart = nullptr, *bcinv = nullptr;
@@ -514,6 +573,123 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
     h->dominant = "k_dense0_wgrad";
+    return IDQN_OK;
+}
+
+// ---- general-shape cnn path (gcnn_kernels.h) -------------------------------------------------------------------------
+int gcnn_setup(idqn_handle_s* h) {
+    const idqn_config_t& c = h->cfg;
+    GcnnWs& g = h->gc;
+    g.on = true;
+    g.Bmax = c.max_batch;
+    int ih = c.obs_h, iw = c.obs_w, ci = c.obs_c, lo, hi;
+    for (int i = 0; i < 3; ++i) {
+        ConvL& l = h->conv[i];
+        l.K = KS[i][0]; l.S = KS[i][1]; l.CI = ci; l.CO = c.features[i]; l.IH = ih; l.IW = iw;
+        same_pad(ih, l.K, l.S, &l.OH, &l.PLh, &hi);
+        same_pad(iw, l.K, l.S, &l.OW, &l.PLw, &hi);
+        (void)lo;
+        l.w_off = h->L.leaves[2 * i].offset; l.b_off = h->L.leaves[2 * i + 1].offset;
+        ih = l.OH; iw = l.OW; ci = l.CO;
+    }
+    const int K = c.n_heads;
+    h->F = ih * iw * ci;
+    FcNet& n = h->fc;  // the dense head over the flattened features
+    n.L = c.n_features - 3 + 1;
+    IDQN_REQUIRE(n.L <= FC_MAX_LAYERS, "cnn: too many dense layers (%d)", n.L);
+    n.d[0] = h->F;
+    n.dmax = n.d[0];
+    for (int l = 0; l < n.L; ++l) {
+        n.d[l + 1] = 3 + l < c.n_features ? c.features[3 + l] : c.n_actions;
+        n.dmax = std::max(n.dmax, n.d[l + 1]);
+        n.w_off[l] = h->L.leaves[6 + 2 * l].offset;
+        n.b_off[l] = h->L.leaves[7 + 2 * l].offset;
+    }
+    int rc;
+    const long B = g.Bmax;
+    for (int i = 0; i < 3; ++i) {
+        const ConvL& l = h->conv[i];
+        const long per = (long)l.OH * l.OW * l.CO;
+        char nm[16];
+        snprintf(nm, sizeof nm, "g_act%d", i);
+        if ((rc = alloc_zero(&g.act[i], 2L * K * B * per, h, nm))) return rc;
+        snprintf(nm, sizeof nm, "g_dact%d", i);
+        if ((rc = alloc_zero(&g.dact[i], (long)K * B * per, h, nm))) return rc;
+        snprintf(nm, sizeof nm, "g_iact%d", i);
+        if ((rc = alloc_zero(&g.inf_act[i], 32L * per, h, nm))) return rc;
+    }
+    if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B), h, "fc_ws"))) return rc;
+    if ((rc = alloc_zero(&g.inf_ws, 2L * 32 * n.dmax, h, "g_infws"))) return rc;
+    if ((rc = alloc_zero(&h->qdbg, 2L * K * B * c.n_actions, h, "q"))) return rc;
+    // parameter pointers of the 2K training nets (online first), as the conv kernels index them
+    IDQN_HIP_CHECK(hipMalloc((void**)&h->train.wbase, sizeof(float*) * 2 * K));
+    h->owned.push_back((void*)h->train.wbase);
+    std::vector<const float*> wb(2 * K);
+    for (int k = 0; k < K; ++k) {
+        wb[k] = h->online + (long)k * h->L.head_stride;
+        wb[K + k] = h->target + (long)k * h->L.head_stride;
+    }
+    IDQN_HIP_CHECK(hipMemcpy(h->train.wbase, wb.data(), sizeof(float*) * 2 * K, hipMemcpyHostToDevice));
+    h->dominant = "k_fc_step";
+    return IDQN_OK;
+}
+
+GConvArgs gconv_args(idqn_handle_s* h, int layer, const float* const* wbase, int n_nets, int n_split, int B, const uint8_t* s0,
+                     const uint8_t* s1, const float* in, float* out) {
+    const ConvL& l = h->conv[layer];
+    GConvArgs a;
+    a.in_u8[0] = s0; a.in_u8[1] = s1; a.in = in; a.out = out; a.wbase = wbase; a.w_off = l.w_off; a.b_off = l.b_off;
+    a.n_nets = n_nets; a.n_split = n_split; a.B = B; a.IH = l.IH; a.IW = l.IW; a.CI = l.CI; a.OH = l.OH; a.OW = l.OW; a.CO = l.CO;
+    a.KS = l.K; a.S = l.S; a.PLh = l.PLh; a.PLw = l.PLw;
+    return a;
+}
+
+unsigned ggrid(long n) { return (unsigned)std::max(1L, std::min((n + 255) / 256, 65536L)); }
+
+// conv trunk of `n_nets` nets (the first n_split read s0, the rest s1) into act[0..2]
+int gcnn_trunk(idqn_handle_s* h, const float* const* wbase, int n_nets, int n_split, int B, const uint8_t* s0, const uint8_t* s1,
+               float* const act[3], hipStream_t q) {
+    for (int i = 0; i < 3; ++i) {
+        const GConvArgs a = gconv_args(h, i, wbase, n_nets, n_split, B, s0, s1, i == 0 ? nullptr : act[i - 1], act[i]);
+        hipLaunchKernelGGL(k_gconv_fwd, dim3(ggrid((long)n_nets * B * a.OH * a.OW * a.CO)), dim3(256), 0, q, a);
+    }
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
+int gcnn_learn(idqn_handle_s* h, const uint8_t* st, const uint8_t* st2, const int32_t* action, const float* reward,
+               const uint8_t* terminal, int B, int Bdiv, bool grads_only, bool profile, hipStream_t q) {
+    GcnnWs& g = h->gc;
+    const int K = h->cfg.n_heads;
+    IDQN_REQUIRE(B <= g.Bmax, "batch %d exceeds the workspace (%d)", B, g.Bmax);
+    int rc = gcnn_trunk(h, h->train.wbase, 2 * K, K, B, st, st2, g.act, q);
+    if (rc) return rc;
+    FcArgs a;
+    a.net = h->fc; a.online = h->online; a.target = h->target; a.grad = h->grad; a.P = h->L.head_stride;
+    a.s = g.act[2]; a.s2 = g.act[2] + (long)K * B * h->F; a.s_stride = (long)B * h->F; a.din = g.dact[2];
+    a.action = action; a.reward = reward; a.terminal = terminal; a.gamma_n = h->gamma_n; a.B = B; a.Bdiv = Bdiv; a.K = K;
+    a.ws = h->fc_ws; a.losses = h->losses; a.q_dbg = h->qdbg;
+    a.count = h->count; a.bcinv = h->bcinv; a.adam_b1 = h->ad.b1; a.adam_b2 = h->ad.b2;
+    a.cum = h->cum; a.finish_step = grads_only ? 0 : 1;
+    a.is_weight = h->is_weight; a.td_abs = h->td_abs;
+    a.gm = GradMap{h->gP, h->g_w0_begin, h->g_w0_end, h->g_w0_base};
+    if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
+    hipLaunchKernelGGL(k_fc_step, dim3(K), dim3(256), 0, q, a);
+    if (profile && h->ev_used + 2 <= (int)h->ev.size()) {
+        IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], q));
+        h->ev_used += 2;
+    }
+    // conv backward, top down: weight gradient of layer i from dact[i], then dact[i - 1] = (W^T dact[i]) * [act[i - 1] > 0]
+    for (int i = 2; i >= 0; --i) {
+        GConvBwdArgs b;
+        b.f = gconv_args(h, i, h->train.wbase, K, K, B, st, st, i == 0 ? nullptr : g.act[i - 1], nullptr);
+        b.dy = g.dact[i]; b.din = i > 0 ? g.dact[i - 1] : nullptr; b.grad = h->grad;
+        b.gm = GradMap{h->gP, h->g_w0_begin, h->g_w0_end, h->g_w0_base};
+        const long nw = (long)b.f.KS * b.f.KS * b.f.CI * b.f.CO + b.f.CO;
+        hipLaunchKernelGGL(k_gconv_wgrad, dim3(ggrid(nw), K), dim3(256), 0, q, b);
+        if (i > 0) hipLaunchKernelGGL(k_gconv_dgrad, dim3(ggrid((long)K * B * b.f.IH * b.f.IW * b.f.CI)), dim3(256), 0, q, b);
+    }
+    IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }
 
@@ -1433,7 +1609,9 @@ extern "C" int idqn_create(const idqn_config_t* cfg, float* online_dev, float* t
         IDQN_REQUIRE(!mode || !strcmp(mode, "f32") || !strcmp(mode, "bf16x3"), "IDQN_CONV must be f32 or bf16x3, got '%s'", mode);
     }
     rc = alloc_zero(&h->bcinv, 2L * cfg->n_heads + 64, h, "bcinv");
-    if (!rc) rc = cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h);
+    const bool general = cfg->arch == IDQN_ARCH_CNN && !cnn_fast_shape(*cfg);
+    if (general) h->planes = false;
+    if (!rc) rc = general ? gcnn_setup(h) : (cfg->arch == IDQN_ARCH_CNN ? cnn_setup(h) : fc_setup(h));
     if (rc) { idqn_destroy(h); return rc; }
     h->ev.resize(2 * 2048);
     for (auto& e : h->ev)
@@ -1480,6 +1658,14 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
     }
     tl_mark(h, q, nullptr);
     int rc;
+    if (h->gc.on) {
+        IDQN_REQUIRE(!(stop0 || stopb), "the IDQN_F_STOP_* flags belong to the MFMA cnn path");
+        if ((rc = gcnn_learn(h, (const uint8_t*)state_dev, (const uint8_t*)next_state_dev, action_dev, reward_dev, terminal_dev, batch,
+                             batch_mean_divisor, grads_only, profile, q)))
+            return rc;
+        if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
+        return IDQN_OK;
+    }
     if (h->cfg.arch == IDQN_ARCH_CNN) {
         auto issue = [&](hipStream_t qs) -> int {
             int r;
@@ -1539,6 +1725,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         a.count = h->count; a.bcinv = h->bcinv; a.adam_b1 = h->ad.b1; a.adam_b2 = h->ad.b2;
         a.cum = h->cum; a.finish_step = grads_only ? 0 : 1;
         a.is_weight = h->is_weight; a.td_abs = h->td_abs;
+        a.s_stride = 0; a.din = nullptr; a.gm = GradMap{h->gP, h->g_w0_begin, h->g_w0_end, h->g_w0_base};
         if (profile && h->ev_used + 2 <= (int)h->ev.size()) IDQN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], q));
         const FcPlan& fp = h->fc_plan_;
         const size_t lds = (size_t)fp.floats * 4;
@@ -1810,6 +1997,19 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     hipStream_t q = (hipStream_t)stream;
     const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
     static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
+    if (h->gc.on) {  // general-shape cnn: trunk of the one net on the n states, then the generic dense forward
+        const float* const* wb = h->train.wbase + (which * h->cfg.n_heads + head);
+        int rc = gcnn_trunk(h, wb, 1, 1, n, (const uint8_t*)states_dev, (const uint8_t*)states_dev, h->gc.inf_act, q);
+        if (rc) return rc;
+        FcQArgs a;
+        a.net = h->fc; a.params = params; a.s = h->gc.inf_act[2]; a.n = n; a.q_out = q_out_dev; a.ws = h->gc.inf_ws;
+        hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
+        if (action_out_dev)
+            hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev,
+                               (volatile int32_t*)(h->act_use_mail ? h->act_mail_dev : nullptr), h->act_seq);
+        IDQN_HIP_CHECK(hipGetLastError());
+        return IDQN_OK;
+    }
     if (h->cfg.arch == IDQN_ARCH_CNN && n == 1 && !act_generic && h->J <= 512 && h->cfg.n_actions <= 32) {
         // one state: the latency path (act_kernels.h) -- pixels and parameter leaves as they are, five small launches
         const float* in = nullptr;
@@ -1905,7 +2105,7 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
     // sequence number the host polls (IDQN_ACT_POLL=0: a device-to-host copy and a stream synchronisation instead).
     static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
     static const bool no_poll = getenv("IDQN_ACT_POLL") && atoi(getenv("IDQN_ACT_POLL")) == 0;
-    const bool poll = !no_poll && (cnn ? (!act_generic && h->J <= 512 && h->cfg.n_actions <= 32) : true);
+    const bool poll = !no_poll && ((cnn && !h->gc.on) ? (!act_generic && h->J <= 512 && h->cfg.n_actions <= 32) : true);
     if (poll && !h->act_mail) {
         IDQN_HIP_CHECK(hipHostMalloc((void**)&h->act_mail, 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(h->act_mail, 0, 64);

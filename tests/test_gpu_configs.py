@@ -20,22 +20,85 @@ def _golden_agent(name):
     return _agent(name)
 
 
+from test_gpu_fp_path import conv_mode  # noqa: E402,F401  (fixture: both conv arithmetic modes)
+
+
+def _oracle_preacts(ph, state):
+    """fp64 pre-activations of the three convs of one head (architectures/dqn.py:43-51)."""
+    from oracle import qnet_ref as Q
+
+    a, ys = state.astype(np.float64) / 255.0, []
+    for li, (k, s) in enumerate(Q.CNN_GEOM):
+        y, _ = Q.conv_fwd(a, ph[f"Conv_{li}/kernel"].astype(np.float64), ph[f"Conv_{li}/bias"].astype(np.float64), s)
+        ys.append(y)
+        a = np.maximum(y, 0)
+    return ys
+
+
 @pytest.mark.parametrize("name", ["cnn_atari_k5_b256", "cnn_atari_k64"])
-def test_full_size_configs_against_goldens(name):
+def test_full_size_configs_against_goldens(name, conv_mode):
     """Config 4's global batch (K = 5, B = 256: eight 32-sample blocks through every kernel) and config 5's head count
-    (K = 64, B = 32) on ONE device: per-head losses within 1e-5, post-Adam parameters at the probe indices."""
-    agent, bs, rec, _ = _golden_agent(name)
-    K = agent._K
+    (K = 64, B = 32) on ONE device, in both conv arithmetic modes: per-head losses within 1e-5, post-Adam parameters at the
+    probe indices at fp32 accuracy -- EXCEPT where a ReLU unit's pre-activation lies within fp32 round-off of zero and the
+    fp32 path takes the other branch than the fp64 oracle.  That exception is checked, not assumed: every head with a
+    parameter probe off by more than 3e-7 must show at least one such flipped unit, and every flipped unit's fp64
+    pre-activation must be no larger than fp32 round-off of its layer (1e-5 of the layer's largest pre-activation)."""
+    from oracle import qnet_ref as Q
+    from test_gpu_fp_path import _unpack_act, _unpack_planes
+
+    agent, bs, rec, (arch, obs, A, feats, K, B, steps, p, pt, batches) = _golden_agent(name)
     losses = agent._learn(bs[0]).cpu().numpy()
     want = np.asarray(rec["steps"][0]["losses"])
     assert np.abs(losses - want).max() <= LOSS_ATOL, np.abs(losses - want).max()
     flat = agent._flat(agent._online)
+    off_heads = set()
     for leaf, d in rec["steps"][0]["leaves"].items():
         err = np.abs(flat[leaf].reshape(K, -1)[:, d["idx"]] - np.asarray(d["param"]))
-        # With 64 heads x 1.2 M ReLU units each, a few pre-activations land within an fp32 ulp of zero and take the other
-        # branch than in fp64 (the f32 MFMA path shows the same, on other units): the affected head's conv gradients move
-        # by ~1 %, i.e. a fraction of one Adam update.  Everything else must sit at fp32 accuracy.
+        off_heads |= set(np.nonzero((err > 3e-7).any(axis=1))[0].tolist())
         assert (err <= 3e-7).mean() >= 0.98 and err.max() <= 2 * rec["hyper"]["lr"], (leaf, err.max(), (err <= 3e-7).mean())
+    # --- the ReLU-flip account ---
+    planes = conv_mode == "bf16x3"
+    nb = (B + 31) // 32
+    H, W, C = obs
+    geo = []
+    for (k, s), f in zip(Q.CNN_GEOM, feats[:3]):
+        oh, lh, hh = Q.same_pad(H, k, s)
+        ow, lw, hw = Q.same_pad(W, k, s)
+        geo.append(dict(IH=H, IW=W, CI=C, OH=oh, OW=ow, CO=f, lo_h=lh, hi_h=hh, lo_w=lw, hi_w=hw))
+        H, W, C = oh, ow, f
+    bufs = {}
+    for li, nm in enumerate(["a1", "a2"]):  # online nets = the first K * nb slots of every activation buffer
+        gi = geo[li + 1]
+        Hp, Wp = gi["IH"] + gi["lo_h"] + gi["hi_h"], gi["IW"] + gi["lo_w"] + gi["hi_w"]
+        per_slot = Hp * Wp * gi["CI"] * 32 * (3 if planes else 1) // (2 if planes else 1)  # float32 words per slot
+        bufs[nm] = (agent._debug(nm + ("p" if planes else ""))[: K * nb * per_slot].cpu(), gi, Hp, Wp)
+    go = geo[2]
+    a3 = agent._debug("a3")[: K * nb * go["OH"] * go["OW"] * go["CO"] * 32].cpu()
+    state = batches[0][0]
+    checked = sorted(off_heads | {0, K - 1})
+    flips_of = {}
+    for k in checked:
+        ys = _oracle_preacts(Q.head(p, k), state)
+        n_flip = 0
+        for li in range(3):
+            got = []
+            for bb in range(nb):
+                if li < 2:
+                    t, gi, Hp, Wp = bufs[["a1", "a2"][li]]
+                    un = _unpack_planes if planes else _unpack_act
+                    got.append(un(t, K * nb, k * nb + bb, gi["IH"], gi["IW"], gi["CI"], gi["lo_h"], gi["lo_w"], Hp, Wp))
+                else:
+                    got.append(_unpack_act(a3, K * nb, k * nb + bb, go["OH"], go["OW"], go["CO"], 0, 0, go["OH"], go["OW"]))
+            act = np.concatenate(got, axis=0)[:B]
+            y = ys[li]
+            flipped = (act > 0) != (y > 0)
+            n_flip += int(flipped.sum())
+            if flipped.any():
+                assert np.abs(y[flipped]).max() <= 1e-5 * np.abs(y).max(), (name, k, li, np.abs(y[flipped]).max(), np.abs(y).max())
+        flips_of[k] = n_flip
+    print(f"[{name} {conv_mode}] heads with a probe off by > 3e-7: {sorted(off_heads)}; flipped ReLU units per checked head: {flips_of}")
+    for k in off_heads:
+        assert flips_of[k] >= 1, (name, k, "parameter probes differ by more than 3e-7 although no ReLU unit took the other branch")
 
 
 def test_config4_prioritized_learner_on_a_million_leaf_tree():

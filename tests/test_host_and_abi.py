@@ -42,9 +42,18 @@ def test_layout_matches_the_reference_pytree():
 def test_unsupported_shapes_are_refused_loudly():
     from slimdqn import _hip
 
-    for feats in ([32, 64, 60, 512], [32, 64, 64, 500], [32, 64, 64]):
+    # every cnn shape the reference's DQNNet takes has a layout (shapes outside the MFMA kernels run on the general-shape
+    # kernels, csrc/gcnn_kernels.h), with the flax leaf names in creation order
+    for feats, n_dense in (([32, 64, 60, 512], 2), ([32, 64, 64, 500], 2), ([32, 64, 64], 1), ([2, 3, 1, 15], 2), ([8, 8, 8, 30, 20], 3)):
+        leaves, stride = _hip.layout(_hip.make_config("cnn", 5, 6, (84, 84, 4), feats, 32, 1e-4, 1e-8, 0.99))
+        names = [n for n, _, _ in leaves]
+        assert names[:6] == [f"Conv_{i}/{w}" for i in range(3) for w in ("kernel", "bias")]
+        assert names[6:] == [f"Dense_{i}/{w}" for i in range(n_dense) for w in ("kernel", "bias")]
+        assert leaves[-2][2][1] == 6 and stride % 64 == 0
+    # what has no meaning is still refused: fewer than three convs, zero widths, the quantile heads on a general shape
+    for feats, kw in (([32, 64], {}), ([32, 0, 64, 512], {}), ([32, 64, 60, 512], {"n_quantiles": 8})):
         with pytest.raises(_hip.HipExtensionError):
-            _hip.layout(_hip.make_config("cnn", 5, 6, (84, 84, 4), feats, 32, 1e-4, 1e-8, 0.99))
+            _hip.layout(_hip.make_config("cnn", 5, 6, (84, 84, 4), feats, 32, 1e-4, 1e-8, 0.99, **kw))
     from slimdqn.networks.architectures.dqn import DQNNet
 
     with pytest.raises(NotImplementedError):
