@@ -178,11 +178,11 @@ int build_layout(const idqn_config_t& c, Layout& L) {
             add_leaf(L, "Embed_0/bias", 1, eb, &off);
         }
     } else if (c.arch == IDQN_ARCH_FC) {
-        IDQN_REQUIRE(c.n_actions <= FC_MAX_WIDTH, "fc: n_actions <= %d", FC_MAX_WIDTH);
+
         long fan = (long)c.obs_h * c.obs_w * c.obs_c;
         for (int i = 0; i <= c.n_features; ++i) {
             long f = i < c.n_features ? c.features[i] : c.n_actions;
-            IDQN_REQUIRE(f >= 1 && f <= FC_MAX_WIDTH && fan <= FC_MAX_WIDTH, "fc: layer widths must be in [1, %d]", FC_MAX_WIDTH);
+            IDQN_REQUIRE(f >= 1 && fan >= 1, "fc: layer widths must be positive");  // (wider than FC_MAX_WIDTH: the generic kernels)
             long ws[2] = {fan, f};
             snprintf(nm, sizeof nm, "Dense_%d/kernel", i);
             add_leaf(L, nm, 2, ws, &off);
@@ -710,8 +710,7 @@ int fc_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
     h->fc_plan_ = fc_plan(n);
-    IDQN_REQUIRE(n.dmax <= FC_MAX_WIDTH, "fc: layer width %d exceeds %d", n.dmax, FC_MAX_WIDTH);
-    if (getenv("IDQN_FC_GENERIC")) h->fc_plan_.BS = 0;
+    if (getenv("IDQN_FC_GENERIC") || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
     if (h->fc_plan_.BS) {
         const int bytes = (int)(h->fc_plan_.floats * 4);
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -719,7 +718,7 @@ int fc_setup(idqn_handle_s* h) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     h->fcm_plan_ = fc_mfma_plan(n);
-    if (getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA")) h->fcm_plan_.floats = 0;  // A/B switches
+    if (getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
     if (h->fcm_plan_.floats)
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(h->fcm_plan_.floats * 4)));
@@ -2062,7 +2061,7 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         FcQArgs a;
         a.net = h->fc; a.params = params; a.s = (const float*)states_dev; a.n = n; a.q_out = q_out_dev;
         a.ws = h->fc_ws + (long)h->cfg.n_heads * ((long)(h->fc.L + 3) * h->cfg.max_batch * h->fc.dmax + 2 * h->cfg.max_batch);
-        if (n == 1) hipLaunchKernelGGL(k_fc_q1, dim3(1), dim3(512), 0, q, a);  // acting: one state
+        if (n == 1 && h->fc.dmax <= FC_MAX_WIDTH) hipLaunchKernelGGL(k_fc_q1, dim3(1), dim3(512), 0, q, a);  // acting: one state
         else hipLaunchKernelGGL(k_fc_q, dim3(1), dim3(256), 0, q, a);
         if (action_out_dev)
             hipLaunchKernelGGL(k_argmax_rows, dim3(1), dim3(64), 0, q, q_out_dev, n, h->cfg.n_actions, action_out_dev,

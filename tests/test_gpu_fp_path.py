@@ -342,7 +342,8 @@ def test_dqn_entry_points_run_as_scripts(env_name, tmp_path):
     ("fc", 8, [100, 100], 4, 3, 7),
     ("fc", (6, 1), [50], 2, 9, 64),
     ("fc", 8, [200, 200], 4, 2, 40),       # 16-sample blocks and weight column tiles in the LDS kernel
-    ("fc", 12, [512, 300, 64], 6, 2, 33),  # 8-sample blocks, four layers, widest supported layer
+    ("fc", 12, [512, 300, 64], 6, 2, 33),  # 8-sample blocks, four layers, widest layer the LDS kernels take
+    ("fc", 10, [700, 33], 3, 2, 12),       # wider than that: the generic kernel (any width), acting through k_fc_q
     ("fc", 5, [7, 9], 3, 2, 32),           # odd widths
 ])
 def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B, conv_mode):

@@ -1,5 +1,6 @@
 # End-of-round measurement set (one GPU call): default bench line, A=18 repeat, rocprofv3 kernel stats, PMC passes,
-# one-rank RCCL rehearsal of both data-parallel modes, head-parallel line, trainer loop.  Outputs under gpurun_out/final/.
+# one-rank RCCL rehearsal of both data-parallel modes, head-parallel line, emulated-rank lines, the i-IQN line + its kernel
+# stats, trainer loop.  Outputs under gpurun_out/final/.
 mkdir -p gpurun_out/final && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/final
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
@@ -10,15 +11,22 @@ bash tools/gpu_pmc.sh > $O/pmc.log 2>&1; tail -5 $O/pmc.log
 timeout -k 10 300 python bench.py --gpus 1 --force-dp --no-cpu-baseline > $O/bench_dp1_factored.json 2> $O/dp1_factored.err; echo "dp factored rc=$?"
 IDQN_DP_MODE=allreduce timeout -k 10 300 python bench.py --gpus 1 --force-dp --no-cpu-baseline > $O/bench_dp1_allreduce.json 2> $O/dp1_allreduce.err; echo "dp allreduce rc=$?"
 timeout -k 10 300 python bench.py --gpus 1 --heads-per-gpu 8 --steps 300 --warmup 30 > $O/bench_hp8.json 2> $O/hp8.err; echo "hp rc=$?"
+for n in 1 2 4 8; do timeout -k 10 200 python bench.py --emulate-ranks $n --steps 200 --repeats 3 > $O/bench_emulate$n.json 2> $O/emulate$n.err; echo "emulate $n rc=$?"; done
+timeout -k 10 400 python bench.py --algo iiqn --steps 30 --warmup 5 --repeats 3 > $O/bench_iiqn.json 2> $O/bench_iiqn.err; echo "iiqn rc=$?"
+rm -rf $O/prof_iiqn; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_iiqn -- python bench.py --algo iiqn --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/prof_iiqn.log 2>&1
+cp $O/prof_iiqn/*/*_kernel_stats.csv $O/iiqn_kernel_stats.csv && echo "iiqn kernel stats ok"
+IDQN_OVERLAP=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_overlap.json 2> $O/bench_overlap.err; echo "overlap rc=$?"
 timeout -k 10 300 python tools/bench_loop.py > $O/loop_all.log 2>&1; grep -E "us per|env steps" $O/loop_all.log > $O/loop.txt; cat $O/loop.txt
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/final/bench.json"))
-print("BENCH %.1f steps/s  %.4f ms/step  dominant %.1f us %.0f GB/s frac %.3f  step frac_mfma %.3f frac_hbm %.3f  cpu %.2f steps/s on %d cores  x%.0f" % (
+print("BENCH %.1f steps/s  %.4f ms/step  dominant %.1f us %.0f GB/s frac %.3f  step frac_mfma %.3f frac_hbm %.3f  cpu %.2f steps/s on %d cores  x%.0f  jax: %s" % (
     d["value"], d["ms_per_step"], d["roofline"]["launch_ms"]*1e3, d["roofline"]["achieved"], d["roofline"]["frac"],
-    d["step_roofline"]["frac_mfma"], d["step_roofline"]["frac_hbm"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["gpu_over_cpu"]))
+    d["step_roofline"]["frac_mfma"], d["step_roofline"]["frac_hbm"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["gpu_over_cpu"],
+    d["cpu_baseline"]["jax"]["status"]))
 for k in d["kernels"]: print("  %-36s %7.1f us" % (k["launch"], k["us"]))
-for f in ("bench_a18","bench_dp1_factored","bench_dp1_allreduce","bench_hp8"):
+print("sampling", json.dumps(d.get("sampling"))[:600])
+for f in ("bench_a18","bench_dp1_factored","bench_dp1_allreduce","bench_hp8","bench_emulate1","bench_emulate2","bench_emulate4","bench_emulate8","bench_iiqn","bench_overlap"):
     try:
         x=json.load(open("gpurun_out/final/%s.json"%f)); print(f, "%.1f %s  %.4f ms/step" % (x["value"], x["unit"], x["ms_per_step"]))
     except Exception as e: print(f, "failed", e)
