@@ -22,12 +22,6 @@
 
 #include "dense0_update.h"
 
-struct ActGeom {
-    int H, W, C;        // logical extent
-    int lo_h, lo_w;     // zero border before the first row / column
-    int Hp, Wp;         // padded extent
-    long block;         // floats per (net, batch block) = Hp * Wp * C * 32
-};
 
 // --------------------------------------------------------------------------------------------
 // input staging: uint8 NHWC minibatch -> f32 / 255 batch-minor, through an LDS tile (the (s, s')
@@ -916,6 +910,14 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     *reinterpret_cast<uint2*>(dst + e * 4) = make_uint2(q0a, q0b);
     *reinterpret_cast<uint2*>(dst + plane + e * 4) = make_uint2(q1a, q1b);
     *reinterpret_cast<uint2*>(dst + 2 * plane + e * 4) = make_uint2(q2a, q2b);
+}
+
+// The fused kernel over FULL 512-column rows (NQ = 4, dense width 512): the workgroup then holds the complete data gradient
+// of its 32 rows and finishes it itself (ReLU mask, bf16 planes, per-position sums) -- no partial buffer and no finalize
+// launch.  80 KB of LDS (two workgroups per CU), hence dynamic.
+__global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gs_dyn[];
+    dense0_wgrad_body<true, 4, true, false>(a, (int)blockIdx.x + a.item0, gs_dyn, (int)threadIdx.x);
 }
 
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false>

@@ -47,6 +47,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// zero-bordered activation / gradient buffer of one conv layer (rows of 32 samples)
+struct ActGeom {
+    int H, W, C;        // logical extent
+    int lo_h, lo_w;     // zero border before the first row / column
+    int Hp, Wp;         // padded extent
+    long block;         // floats per (net, batch block) = Hp * Wp * C * 32
+};
+
 // Gradient arena addressing (include/idqn_hip.h): the cnn's Dense_0/kernel lives in a second region, every other leaf at
 // its parameter offset (minus that leaf's size when it comes later); fc: w0_begin == w0_end, gP = head stride.
 struct GradMap {

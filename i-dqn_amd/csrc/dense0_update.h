@@ -70,6 +70,12 @@ struct DenseWgradArgs {
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
     int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
+    // NQ = 4 (full 512-column rows) with FUSE_DG: the workgroup finishes dL/da3 itself -- what k_da3_finalize does otherwise
+    unsigned short* da3p;  // bf16 planes (convp.h layout, geometry g) or nullptr
+    float* da3f;           // f32 rows [K][nb][g.block] (f32 conv path) or nullptr
+    float* pb;             // [K * nb][H * W][C] sums over the 32 samples (Conv_2 bias gradient) or nullptr
+    ActGeom g;
+    int C;
     float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
     // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
     // dhp[plane][bb][k][J * 32]
@@ -83,6 +89,9 @@ struct DenseWgradArgs {
 // (16 B per lane), the gradient comes from LDS -- exactly the access pattern of the plain Adam kernel, which
 // reaches 6.9 TB/s on MI355X.  The first version kept the tile in accumulators and ran Adam from the MFMA
 // layout at 2 waves/SIMD (5.3 TB/s); this one needs ~100 registers and 32 KB of LDS (4-5 workgroups per CU).
+#ifndef D0W_DEPTH_ROWS
+#define D0W_DEPTH_ROWS 8
+#endif
 #ifndef D0W_DEPTH
 #define D0W_DEPTH 4  // row groups of theta / m / v in flight per thread in the fused kernel's streaming phase
 #endif
@@ -98,8 +107,9 @@ struct DenseWgradArgs {
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
-    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 4 * (64 / LPR), NIT = 32 / RPI;  // lanes/row, rows/iter, iters
-    static_assert(!FUSE_DG || (FUSE_ADAM && NQ == 2), "the fused data gradient rides on the fused 256-column kernel");
+    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 / RPI;  // lanes/row, rows/iter (256 threads), iters
+    static_assert(!FUSE_DG || (FUSE_ADAM && (NQ == 2 || NQ == 4)), "the fused data gradient rides on the fused 256- / 512-column kernels");
+    constexpr bool ROWS = FUSE_DG && NQ == 4;  // whole rows: the data gradient is complete here
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     // FUSE_DG with upd_end >= 0: items from upd_end on are DEFERRED -- their update runs later, in the stream role of a conv
     // launch; here such a workgroup only produces its share of the data gradient (theta rows -> LDS -> phase 3), because
@@ -112,12 +122,13 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     const int f0 = ft * 32, j0 = jt * JT, jw = wave * (32 * NQ);
     const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
     // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
-    const int prow = wave * (64 / LPR) + lane / LPR, pcol = (lane % LPR) * 4;
+    const int prow = t / LPR, pcol = (t % LPR) * 4;
     const long o0 = base + (long)prow * a.J + pcol;
     auto rot = [&](int row, int col) { return FUSE_DG ? row * JT + ((col + 4 * row) & (JT - 1)) : row * JT + col; };
     // phase-2 state runs DEPTH row groups ahead (a ring of named-index registers): the rows of the first DEPTH
     // iterations are requested before the MFMA phase, so the workgroup keeps streaming while it computes its tile
-    constexpr int DEPTH = D0W_DEPTH;
+    // (the full-row kernel has two workgroups per CU instead of three: deeper, to keep as many bytes in flight per CU)
+    constexpr int DEPTH = (FUSE_DG && NQ == 4) ? D0W_DEPTH_ROWS : D0W_DEPTH;
     float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
     if (FUSE_ADAM && upd) {
 #pragma unroll
@@ -241,9 +252,10 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             float dv[2][8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) dv[0][u] = Dp[(long)(2 * u) * 32];
+            constexpr int NCH = 2 * NQ;  // chunks of 8 MFMA steps (16 columns each) over this wave's 32 * NQ columns
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 MFMA steps (16 columns each)
-                if (c + 1 < 4) {
+            for (int c = 0; c < NCH; ++c) {
+                if (c + 1 < NCH) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) dv[(c + 1) & 1][u] = Dp[(long)(16 * (c + 1) + 2 * u) * 32];
                 }
@@ -267,8 +279,37 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                     const float4 y = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
                     s4.x += y.x; s4.y += y.y; s4.z += y.z; s4.w += y.w;
                 }
-                float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
-                *reinterpret_cast<float4*>(O + t * 4) = s4;
+                if (!ROWS) {
+                    float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
+                    *reinterpret_cast<float4*>(O + t * 4) = s4;
+                } else {
+                    // complete rows: ReLU mask of a3 and the three output forms of dL/da3 (as k_da3_finalize: one thread =
+                    // 4 samples of one row f, 8 threads a row)
+                    const int f = f0 + row, sl4 = (t & 7) * 4;
+                    const float4 m = *reinterpret_cast<const float4*>(a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner + (long)f * 32 + sl4);
+                    s4.x = m.x > 0.f ? s4.x : 0.f; s4.y = m.y > 0.f ? s4.y : 0.f; s4.z = m.z > 0.f ? s4.z : 0.f; s4.w = m.w > 0.f ? s4.w : 0.f;
+                    const long sl = (long)k * a.nb + bb;
+                    const int pos = f / a.C, c = f - pos * a.C;
+                    const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
+                    const long pix = (long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w);
+                    if (a.da3f) *reinterpret_cast<float4*>(a.da3f + sl * a.g.block + (pix * a.C + c) * 32 + sl4) = s4;
+                    if (a.da3p) {
+                        unsigned short* O = a.da3p + sl * a.g.block * 3 + pix * (3L * a.C * 32) + (long)c * 32 + sl4;
+                        unsigned q0a, q1a, q2a, q0b, q1b, q2b;
+                        split3_pk(s4.x, s4.y, q0a, q1a, q2a);
+                        split3_pk(s4.z, s4.w, q0b, q1b, q2b);
+                        *reinterpret_cast<uint2*>(O) = make_uint2(q0a, q0b);
+                        *reinterpret_cast<uint2*>(O + (long)a.C * 32) = make_uint2(q1a, q1b);
+                        *reinterpret_cast<uint2*>(O + 2L * a.C * 32) = make_uint2(q2a, q2b);
+                    }
+                    if (a.pb) {
+                        float r = (s4.x + s4.y) + (s4.z + s4.w);
+                        r += __shfl_xor(r, 1);
+                        r += __shfl_xor(r, 2);
+                        r += __shfl_xor(r, 4);
+                        if ((t & 7) == 0) a.pb[(sl * (a.g.H * a.g.W) + pos) * a.C + c] = r;
+                    }
+                }
             }
             __syncthreads();  // red is reused by the next batch block
         }

@@ -313,6 +313,7 @@ struct idqn_handle_s {
     // to the stream roles of the Conv_2 pair launch (S2 workgroups x r2 rounds) and of the Conv_0 weight-gradient launch
     // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
     struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
+    bool d0_rows = false;  // the last fused Dense_0 launch ran on full rows and finished dL/da3 itself
     hipEvent_t d0_wait = nullptr;  // experiment hook: the training forward waits for this event in front of its Dense_0 launch
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
@@ -1330,9 +1331,17 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     dw.w_off = h->off_w0; dw.P = h->L.head_stride;
     dw.a3_outer = a3_outer; dw.a3_head = a3_head; dw.a3_inner = a3_inner;
     dw.dh_outer = dh_outer; dw.dh_head = dh_head; dw.dh_inner = dh_inner;
-    const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
+    // IDQN_D0_ROWS=1: full 512-column rows (dense width 512, fused data gradient, nothing deferred) -- the kernel then finishes
+    // dL/da3 itself and k_da3_finalize is not launched.  Measured: the kernel takes 104-108 us against 95 + 9 for the
+    // two-column-tile kernel + finalize (two workgroups per CU instead of three, twice the MFMA phases per workgroup), the
+    // step 0.2974-0.3017 against 0.2941 ms (profiles/r3_dense0_rows_ab.txt): kept as a second schedule for the tests.
+    static const bool rows_on = getenv("IDQN_D0_ROWS") && atoi(getenv("IDQN_D0_ROWS")) != 0;
+    const bool rows = rows_on && fuse_adam && fuse_dg && h->J == 512 && h->ov.n_def == 0;
+    h->d0_rows = rows;
+    const int nq = rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
     dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1;
+    dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
     if (fuse_dg && h->ov.n_def > 0) {
@@ -1361,7 +1370,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, e0, e1, 0, dw); \
         else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, dw);             \
     } while (0)
-    if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    if (rows) {
+        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
+        const size_t lds = (size_t)(32 * 512 + 4096) * 4;
+        static LdsAttrMark attr;
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, dw);
+    } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
@@ -1459,7 +1475,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
-    if (fuse_dg) {
+    if (fuse_dg && !h->d0_rows) {
         Da3FinalizeArgs fa;
         fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
         fa.n_rows = (long)K * nb * h->F; fa.n_jt = h->J / 256; fa.F = h->F; fa.C = c2->CO; fa.K = K; fa.nb = nb; fa.g = h->gda3;

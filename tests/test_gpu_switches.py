@@ -8,6 +8,7 @@
   IDQN_OVERLAP=1      the last items of the fused Dense_0 update run as stream roles of the Conv_2 pair and Conv_0
                       weight-gradient launches (csrc/dense0_update.h)   -> same losses, Dense_0 bit-identical, conv leaves
                       within fp32 round-off (those launches are planned for fewer workgroups = other chunk sums)
+  IDQN_D0_ROWS=1      the fused Dense_0 kernel on whole rows, no finalize launch  -> same, conv leaves within round-off
 """
 import json
 import os
@@ -75,6 +76,15 @@ def test_unpaired_conv_backward_matches(default_run):
 
 def test_overlapped_dense0_update_matches(default_run):
     got = _run(IDQN_OVERLAP="1")
+    np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
+    for name, want in default_run["probe"].items():
+        np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_full_row_dense0_kernel_matches(default_run):
+    """IDQN_D0_ROWS=1: the fused Dense_0 kernel on whole 512-column rows finishes dL/da3 itself (no finalize launch); the
+    data gradient is summed in another order, so conv leaves agree to fp32 round-off, Dense_0 itself bit for bit."""
+    got = _run(IDQN_D0_ROWS="1")
     np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
     for name, want in default_run["probe"].items():
         np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
