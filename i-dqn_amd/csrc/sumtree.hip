@@ -36,6 +36,12 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
     __shared__ unsigned int cur[ST_MAX_N];
     const int tid = threadIdx.x;
     const unsigned int first_leaf = (1u << (depth - 1)) - 1u;
+#ifdef ST_PROF
+#define ST_STAMP(i) if (tid == 0) reinterpret_cast<long long*>(delta_scratch)[6000 + (i)] = wall_clock64();
+#else
+#define ST_STAMP(i)
+#endif
+    ST_STAMP(0)
     // 1. deltas against the CURRENT leaf values, before any de-duplication (sum_tree.py:33-34)
     for (int i = tid; i < m; i += ST_THREADS) {
         if (i < n) {
@@ -47,21 +53,33 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
         }
     }
     __syncthreads();
-    // 2. sort by (leaf, position): ascending leaves, first occurrence first (np.unique).  Up to one key per thread: every
-    //    thread counts the keys below its own (keys are unique, LDS broadcast reads, no barrier per round) and drops its key
-    //    at that rank -- a minibatch-sized write-back spent most of its time in the bitonic network's 36-55 barriers.
-    if (n <= ST_THREADS) {
-        const unsigned long long mine = tid < n ? key[tid] : ~0ull;
-        int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += 8) {
-            unsigned long long kk[8];
+    ST_STAMP(1)
+    // 2. sort by (leaf, position): ascending leaves, first occurrence first (np.unique).  Minibatch-sized sets sort by rank
+    //    counting (keys are unique; LDS broadcast reads, four barriers in all) instead of the bitonic network's 36-45.
+    if (m <= ST_THREADS / 2) {  // (n^2 comparisons: past 512 keys the bitonic network's 55 barriers are cheaper)
+        // P threads per key (P = 1024 / m, a power of two): thread (key i = tid % m, part = tid / m) counts the keys below
+        // key i among every P-th element; the partial counts meet in an LDS integer (order-free).  With one thread per
+        // key the 256-leaf write-back spent 13.8 us here: 12 of the 16 waves had nothing to count but still walked the loop.
+        const int P = ST_THREADS / m, i = tid & (m - 1), part = tid / m;
+        const unsigned long long mine = i < n ? key[i] : ~0ull;
+        if (tid < m) cur[tid] = 0u;  // (cur is free until phase 3)
+        __syncthreads();
+        if (i < n) {
+            int rank = 0;
+            for (int j0 = part; j0 < n; j0 += 8 * P) {
+                unsigned long long kk[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) kk[u] = key[min(j0 + u, n - 1)];
+                for (int u = 0; u < 8; ++u) kk[u] = key[min(j0 + u * P, n - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rank += (j0 + u < n && kk[u] < mine) ? 1 : 0;
+                for (int u = 0; u < 8; ++u) rank += (j0 + u * P < n && kk[u] < mine) ? 1 : 0;
+            }
+            atomicAdd(&cur[i], (unsigned int)rank);
         }
         __syncthreads();
-        if (tid < n) key[rank] = mine;
+        const unsigned int rk = tid < n ? cur[tid] : 0u;
+        const unsigned long long mine0 = tid < n ? key[tid] : ~0ull;
+        __syncthreads();
+        if (tid < n) key[rk] = mine0;
         __syncthreads();
     } else
     for (int k = 2; k <= m; k <<= 1) {
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
             __syncthreads();
         }
     }
+    ST_STAMP(2)
     // 3. sorted deltas; duplicates of a leaf (every occurrence but the first) contribute exactly +0.0
     double dl[ST_MAX_N / ST_THREADS];
 #pragma unroll
@@ -107,37 +126,58 @@ __global__ __launch_bounds__(ST_THREADS) void k_sumtree_set(double* __restrict__
     //    `depth` dependent ones); the head of each run accumulates its run in ascending leaf order, which is the
     //    order np.add.at applies the sorted deltas in (sum_tree.py:39-47).  cur[] holds the sorted leaf nodes; the
     //    ancestor `level` levels up of 0-based heap node x is ((x + 1) >> level) - 1.
+    ST_STAMP(3)
     const int pairs = n * depth;
-    for (int pr = tid; pr < pairs; pr += ST_THREADS) {
-        const int s0 = pr / depth, level = pr - s0 * depth;  // the long runs near the root land on different lanes
-        const unsigned int node = ((cur[s0] + 1u) >> level) - 1u;
-        if (s0 == 0 || ((cur[s0 - 1] + 1u) >> level) - 1u != node) {
-            // The run's deltas are added strictly one after the other (that order IS the result), but its LDS operands do
-            // not depend on the running sum: eight (delta, leaf) pairs are fetched per round, so the chain costs one fp64
-            // add per element instead of an LDS round trip per element (the root's run is all n elements: 34 -> ~12 us
-            // for a 256-leaf write-back).
-            double x = nodes[node];
-            int e = s0;
-            bool more = true;
-            while (more) {
-                double d[8];
-                unsigned int c[8];
+    // Eight (leaf, level) pairs per thread and round: the node reads of all eight are in flight together (one memory round
+    // trip per round instead of one per pair -- a 256-leaf write-back has 5376 pairs, i.e. 5-6 per thread).
+    for (int pr0 = tid; pr0 < pairs; pr0 += 8 * ST_THREADS) {
+        double xs[8];
+        unsigned int nd[8];
+        int st[8], lv[8];
+        bool head[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = min(e + u, n - 1);
-                    d[u] = sdelta[i];
-                    c[u] = cur[i];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    more = more && e + u < n && ((c[u] + 1u) >> level) - 1u == node;
-                    if (more) x = x + d[u];
-                }
-                e += 8;
+        for (int u = 0; u < 8; ++u) {
+            const int pr = pr0 + u * ST_THREADS;
+            head[u] = false;
+            if (pr < pairs) {
+                const int s0 = pr / depth, level = pr - s0 * depth;  // the long runs near the root land on different lanes
+                const unsigned int node = ((cur[s0] + 1u) >> level) - 1u;
+                st[u] = s0; lv[u] = level; nd[u] = node;
+                head[u] = s0 == 0 || ((cur[s0 - 1] + 1u) >> level) - 1u != node;
+                if (head[u]) xs[u] = nodes[node];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (!head[u]) continue;
+            // The run's deltas are added strictly one after the other (that order IS the result).  The end of the run does
+            // not depend on the running sum: it is found first (ancestors of sorted leaves never decrease: a binary search,
+            // skipped for the common run of one), so the dependent chain is ONE fp64 add per element -- with the end test
+            // inside the chain the root's run cost ~100 cycles per element (13.8 us of a 256-leaf write-back).
+            const unsigned int node = nd[u];
+            const int level = lv[u];
+            double x = xs[u];
+            int e = st[u], end = e + 1;
+            if (end < n && ((cur[end] + 1u) >> level) - 1u == node) {
+                int lo = end, hi = n;  // invariant: elements [st, lo] belong to the run, element hi does not (or hi == n)
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (((cur[mid] + 1u) >> level) - 1u == node) lo = mid; else hi = mid;
+                }
+                end = hi;
+            }
+            for (; e + 8 <= end; e += 8) {
+                double d[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) d[w] = sdelta[e + w];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) x = x + d[w];
+            }
+            for (; e < end; ++e) x = x + sdelta[e];
             nodes[node] = x;
         }
     }
+    ST_STAMP(4)
 }
 
 __global__ void k_sumtree_get(const double* __restrict__ nodes, int depth, const int32_t* __restrict__ idx, int n,
