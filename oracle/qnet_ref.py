@@ -1,6 +1,7 @@
 """CPU oracle (test infrastructure only): the i-DQN gradient step in numpy.
 
-Restates, for ``architecture_type in {"cnn", "fc"}``:
+Restates, for ``architecture_type in {"cnn", "fc"}`` (and, forward only, ``"impala"`` -- the architecture the reference's
+own unit tests use, tests/test_idqn.py:33; the HIP path has no impala kernels):
 
 * ``DQNNet.__call__`` (``slimdqn/networks/architectures/dqn.py:38-70``): ``x / 255`` (cnn only),
   three ``flax.linen.Conv`` with the library default ``padding="SAME"`` (8x8/4, 4x4/2, 3x3/1;
@@ -54,6 +55,16 @@ def leaf_shapes(arch, obs_dim, n_actions, features):
     elif arch == "fc":
         fan = int(np.prod(obs_dim)) if not isinstance(obs_dim, (int, np.integer)) else int(obs_dim)
         start = 0
+    elif arch == "impala":
+        # architectures/dqn.py:7-29,54-60: three Stacks (Conv 3x3 SAME -> max_pool 3x3 / 2 SAME -> two residual blocks of
+        # relu, Conv, relu, Conv), ReLU after the third, flatten; flax numbers a Stack's five convs Conv_0..Conv_4
+        h, w, c = obs_dim
+        for si in range(3):
+            for ci in range(5):
+                out.append((f"Stack_{si}/Conv_{ci}/kernel", (3, 3, c if ci == 0 else features[si], features[si])))
+                out.append((f"Stack_{si}/Conv_{ci}/bias", (features[si],)))
+            h, w, c = -(-h // 2), -(-w // 2), features[si]
+        fan, start = h * w * c, 3
     else:
         raise NotImplementedError(arch)
     di = 0
@@ -75,7 +86,7 @@ def init_params(seed, arch, obs_dim, n_actions, features, n_heads, dtype=np.floa
             continue
         rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
         fan_in, fan_out = rf * shape[-2], rf * shape[-1]
-        if arch == "cnn":
+        if arch == "cnn" or (arch == "impala" and ("Conv_0/" in name or name.startswith("Dense"))):
             lim = np.sqrt(6.0 / (fan_in + fan_out))
             params[name] = rng.uniform(-lim, lim, size=(n_heads,) + shape).astype(dtype)
         else:
@@ -126,6 +137,26 @@ def conv_bwd(x_shape, cols, w, s, dy, need_dx=True):
     return dxp[:, plo_h : plo_h + h, plo_w : plo_w + wd, :], dw, db
 
 
+def max_pool_same(x, k=3, s=2):
+    """flax nn.max_pool(window (k, k), strides (s, s), padding="SAME"): -inf padding, NHWC."""
+    b, h, w, c = x.shape
+    oh, plo_h, phi_h = same_pad(h, k, s)
+    ow, plo_w, phi_w = same_pad(w, k, s)
+    xp = np.pad(x, ((0, 0), (plo_h, phi_h), (plo_w, phi_w), (0, 0)), constant_values=-np.inf)
+    win = np.lib.stride_tricks.sliding_window_view(xp, (k, k), axis=(1, 2))[:, ::s, ::s][:, :oh, :ow]
+    return win.max(axis=(-2, -1))
+
+
+def impala_stack(ps, x, dtype=np.float64):
+    """architectures/dqn.py:7-29 (ps: the Stack's leaves "Conv_i/kernel|bias")."""
+    conv = lambda i, a: conv_fwd(a, ps[f"Conv_{i}/kernel"].astype(dtype), ps[f"Conv_{i}/bias"].astype(dtype), 1)[0]  # noqa: E731
+    x = max_pool_same(conv(0, x))
+    for blk in range(2):
+        y = np.maximum(conv(1 + 2 * blk, np.maximum(x, 0)), 0)
+        x = conv(2 + 2 * blk, y) + x
+    return x
+
+
 # ----------------------------------------------------------------------------------------------
 # network forward / backward (single head)
 # ----------------------------------------------------------------------------------------------
@@ -140,6 +171,15 @@ def forward(p, x, arch, dtype=np.float64, keep=False):
             out = np.maximum(y, 0)
             tape.append(("conv", li, a.shape, cols if keep else None, out))
             a = out
+        a = a.reshape(a.shape[0], -1)
+    elif arch == "impala":
+        if keep:
+            raise NotImplementedError("the impala restatement is forward-only (the reference's tests need no more; "
+                                      "torch_ref differentiates it through autograd)")
+        a = x.astype(dtype) / dtype(255.0)
+        for si in range(3):
+            a = impala_stack({n[len(f"Stack_{si}/"):]: v for n, v in p.items() if n.startswith(f"Stack_{si}/")}, a, dtype)
+        a = np.maximum(a, 0)
         a = a.reshape(a.shape[0], -1)
     else:
         a = np.asarray(x).astype(dtype).reshape(x.shape[0], -1)

@@ -32,6 +32,18 @@ def forward_head(p, x, arch, dtype=torch.float64):
             _, lo_w, hi_w = same_pad(a.shape[3], k, s)
             a = F.relu(F.conv2d(F.pad(a, (lo_w, hi_w, lo_h, hi_h)), w, p[f"Conv_{li}/bias"], stride=s))
         a = a.permute(0, 2, 3, 1).reshape(a.shape[0], -1)
+    elif arch == "impala":  # architectures/dqn.py:7-29,54-60
+        a = (x.to(dtype) / 255.0).permute(0, 3, 1, 2)
+        conv = lambda n, t: F.conv2d(F.pad(t, (1, 1, 1, 1)), p[n + "/kernel"].permute(3, 2, 0, 1), p[n + "/bias"])  # noqa: E731
+        for si in range(3):
+            a = conv(f"Stack_{si}/Conv_0", a)
+            _, lo_h, hi_h = same_pad(a.shape[2], 3, 2)
+            _, lo_w, hi_w = same_pad(a.shape[3], 3, 2)
+            a = F.max_pool2d(F.pad(a, (lo_w, hi_w, lo_h, hi_h), value=float("-inf")), 3, 2)
+            for blk in range(2):
+                y = F.relu(conv(f"Stack_{si}/Conv_{1 + 2 * blk}", F.relu(a)))
+                a = conv(f"Stack_{si}/Conv_{2 + 2 * blk}", y) + a
+        a = F.relu(a).permute(0, 2, 3, 1).reshape(a.shape[0], -1)
     else:
         a = x.to(dtype).reshape(x.shape[0], -1)
     n_dense = sum(1 for n in p if n.startswith("Dense_") and n.endswith("kernel"))

@@ -132,3 +132,47 @@ def test_adam_restatement_matches_torch_optim_adam_over_many_steps():
         p.grad = torch.from_numpy(g.copy())
         opt.step()
         np.testing.assert_allclose(th, p.detach().numpy(), rtol=1e-12, atol=1e-15)
+
+
+def test_impala_forward_and_the_reference_unit_tests_formulae():
+    """The architecture the reference's OWN unit tests instantiate (tests/test_idqn.py:27-33: "impala", four features
+    drawn from 1..9, 84x84x4 observations, 2..9 actions, gamma 0.94).  The oracle restates its forward pass
+    (architectures/dqn.py:7-29,54-60: Conv 3x3 SAME, max_pool 3x3 / 2 SAME with -inf padding, two residual blocks per
+    Stack) in numpy and in torch; the two must agree, and the three formulae those tests check -- compute_target,
+    loss, best_action (tests/test_idqn.py:44-84) -- are evaluated on it.  (Forward only: the HIP path has no impala
+    kernels -- SURVEY section 2 puts them out of scope -- and DQNNet refuses the architecture loudly.)"""
+    import torch
+
+    from oracle import torch_ref as T
+
+    rng = np.random.default_rng(11)
+    for _ in range(3):
+        feats = [int(x) for x in rng.integers(1, 10, size=4)]
+        A, K = int(rng.integers(2, 10)), int(rng.integers(1, 4))
+        obs = (84, 84, 4)
+        p = Q.init_params(int(rng.integers(1000)), "impala", obs, A, feats, K)
+        names = [n for n, _ in Q.leaf_shapes("impala", obs, A, feats)]
+        assert names[:10] == [f"Stack_0/Conv_{i}/{w}" for i in range(5) for w in ("kernel", "bias")] and names[-4:] == [
+            "Dense_0/kernel", "Dense_0/bias", "Dense_1/kernel", "Dense_1/bias"]
+        assert p["Dense_0/kernel"].shape == (K, 11 * 11 * feats[2], feats[3])  # 84 -> 42 -> 21 -> 11 under three SAME pools
+        s = rng.random((1,) + obs)  # tests/utils.py:16-33 feeds float states in [0, 1)
+        s2 = rng.random((1,) + obs)
+        k = int(rng.integers(K))
+        hp = Q.head(p, k)
+        q, q2 = Q.forward(hp, s, "impala"), Q.forward(hp, s2, "impala")
+        qt = T.forward_head({n: torch.as_tensor(a).double() for n, a in hp.items()}, torch.as_tensor(s), "impala").numpy()
+        assert q.shape == (1, A) and np.abs(q - qt).max() <= 1e-12 * max(1.0, np.abs(q).max())
+        for term in (0, 1):
+            reward, action = float(rng.normal()), int(rng.integers(A))
+            target = reward + (1 - term) * 0.94 * q2.max()                       # compute_target, idqn.py:120-124
+            assert Q.td_target(q2, np.array([reward]), np.array([term]), 0.94)[0] == pytest.approx(target, rel=1e-15)
+            loss = (q[0, action] - target) ** 2                                  # loss, idqn.py:114-118
+            assert loss == pytest.approx(np.square(target - q[0, action]), rel=1e-15)
+        assert int(np.argmax(q[0])) == int(q[0].argmax())                        # best_action, idqn.py:131 (first maximum)
+
+
+def test_max_pool_same_matches_flax_semantics():
+    x = np.arange(25, dtype=np.float64).reshape(1, 5, 5, 1) - 30.0  # all negative: a zero pad would win, -inf must not
+    y = Q.max_pool_same(x)
+    assert y.shape == (1, 3, 3, 1)
+    np.testing.assert_array_equal(y[0, :, :, 0], np.array([[6, 8, 9], [16, 18, 19], [21, 23, 24]]) - 30.0)
