@@ -902,6 +902,16 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     }
     if (rc) rc = plan_fwd_target(role & 7, n_nets, nb, g, target != cu_budget() ? target : (forced && forced <= 256 ? forced : target), 160 * 1024, pl);
     if (rc) return rc;
+    // A whole-chip forward launch whose workgroups would carry the same number of tiles per wave with ~18 % fewer of them
+    // takes the smaller grid: the matrix loop is as long, the staging traffic and the fill burst are smaller (Conv_1 / Conv_2
+    // forward at K = 5: 250 -> 210 workgroups, 24.5 -> 23.7 and 24.1 -> 23.2 us, profiles/r3_conv_cu_budget_sweep.txt;
+    // Conv_0 would need 6 tiles instead of 5 and keeps 250).  IDQN_CONV_TRIM=0 switches the rule off.
+    static const bool trim = !(getenv("IDQN_CONV_TRIM") && atoi(getenv("IDQN_CONV_TRIM")) == 0);
+    if (trim && !forced && target == cu_budget() && (role & 7) <= 2) {
+        FwdPlan p2;
+        if (plan_fwd_target(role & 7, n_nets, nb, g, target * 13 / 16, 160 * 1024, p2) == IDQN_OK && p2.NT == pl.NT && p2.n_items < pl.n_items)
+            pl = p2;
+    }
     if (getenv("IDQN_PLAN_PRINT"))
         fprintf(stderr, "[plan] fwd role %d nets %d nb %d target %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
                 "ranges/slot %d (NPA %d CT %d NQ %d)\n", role, n_nets, nb, target, pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds,
