@@ -435,6 +435,23 @@ static inline FcMfmaPlan fc_mfma_plan(const FcNet& n) {
     return p;
 }
 
+// The same kernel for nets whose weight matrix does NOT fit LDS beside the activations ([200, 200]: 181 KB): the weight
+// operand of the forward / data-gradient tiles then comes straight from global memory (L2-resident: ~170 KB per head), in
+// register chunks of FCM_CH MFMA steps requested one chunk ahead; activations and deltas stay in LDS, packed per layer
+// (sum of the layer widths rows instead of (L + 1) x the widest).
+#define FCM_CH 16
+static inline FcMfmaPlan fc_mfma_plan_g(const FcNet& n) {
+    FcMfmaPlan p;
+    long rows = 0;
+    for (int l = 0; l <= n.L; ++l) rows += n.d[l];
+    p.ldw = 0;
+    p.w_floats = 0;
+    p.drows = (n.dmax + 31) / 32 * 32;
+    p.floats = rows * FCM_BSP + 2L * p.drows * FCM_BSP + 32L * FCM_BSP + 96;
+    if (p.floats * 4 > FC_LDS_BUDGET) p.floats = 0;
+    return p;
+}
+
 // W [din][dout] (global) -> Wl [din + 1][ldw]: valid elements, zeros in the columns up to the next multiple of 32 and in
 // row din (the k padding of an odd din / the n padding of the last column tile)
 __device__ __forceinline__ void fcm_stage_w(const float* W, float* Wl, int din, int dout, int ldw) {
@@ -471,14 +488,70 @@ __device__ __forceinline__ void fcm_forward(const float* inT, const float* Wl, c
     __syncthreads();
 }
 
+// The forward with the weight operand read from global memory: lane (bl, h) of MFMA step s needs W[2 s + h][column]; a
+// half-wave's 32 columns are one 128-byte line.  Columns past dout are clamped (their results are not written), rows past
+// din read as zero.
+__device__ __forceinline__ void fcm_forward_g(const float* inT, const float* W, const float* bias, float* outT, int din,
+                                              int dout, bool relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    const int ks = (din + 1) / 2, nch = (ks + FCM_CH - 1) / FCM_CH;
+    for (int ct = wave; ct * 32 < dout; ct += FCM_T / 64) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* A = inT + h * FCM_BSP + bl;
+        const float* Wc = W + min(ct * 32 + bl, dout - 1);
+        float b0[FCM_CH], b1[FCM_CH];
+#define FCM_LOAD(c, dst)                                                  \
+    _Pragma("unroll") for (int u = 0; u < FCM_CH; ++u) {                  \
+        const int kk = 2 * ((c) * FCM_CH + u) + h;                        \
+        dst[u] = kk < din ? Wc[(long)kk * dout] : 0.f;                    \
+    }
+#define FCM_MMA(c, src)                                                   \
+    _Pragma("unroll") for (int u = 0; u < FCM_CH; ++u) {                  \
+        const int s0 = (c) * FCM_CH + u;                                  \
+        if (s0 < ks) acc = mfma32(A[2 * s0 * FCM_BSP], src[u], acc);      \
+    }
+        FCM_LOAD(0, b0)
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) { FCM_LOAD(c + 1, b1) }
+            FCM_MMA(c, b0)
+            if (c + 2 < nch) { FCM_LOAD(c + 2, b0) }
+            if (c + 1 < nch) { FCM_MMA(c + 1, b1) }
+        }
+#undef FCM_LOAD
+#undef FCM_MMA
+        const int col = ct * 32 + bl;
+        if (col < dout) {
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r] + bv;
+                outT[col * FCM_BSP + mfma_row(r, h)] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// WG = false: every weight matrix is staged whole in LDS (fc_mfma_plan); WG = true: weights from global (fc_mfma_plan_g)
+template <bool WG>
 __global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int drows, long w_floats) {
     extern __shared__ __attribute__((aligned(16))) float fl[];
     const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     const FcNet& n = a.net;
     const int B = a.B, A = n.d[n.L], dm = n.dmax;
     float* Wl = fl;
-    float* acts = Wl + w_floats;                         // [L + 1][dm][BSP]
-    float* dA = acts + (long)(n.L + 1) * dm * FCM_BSP;   // [drows][BSP]
+    float* acts = Wl + w_floats;                         // [L + 1][dm][BSP]; WG: packed, layer l starts at row sum of d[0..l)
+    auto act = [&](int l) {
+        int row = l * dm;
+        if (WG) {
+            row = 0;
+            for (int j = 0; j < l; ++j) row += n.d[j];
+        }
+        return acts + (long)row * FCM_BSP;
+    };
+    float* dA = act(n.L + 1);                            // [drows][BSP]
     float* dB = dA + (long)drows * FCM_BSP;
     float* qmax = dB + (long)(drows + 32) * FCM_BSP;     // behind the slack rows
     float* sq = qmax + 32;
@@ -501,8 +574,12 @@ __global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int d
         // ---- target net on s'
         float *cur = dA, *nxt = dB;
         for (int l = 0; l < n.L; ++l) {
-            fcm_stage_w(pt + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
-            fcm_forward(cur, Wl, pt + n.b_off[l], nxt, n.d[l], n.d[l + 1], ldw, l != n.L - 1);
+            if (WG) {
+                fcm_forward_g(cur, pt + n.w_off[l], pt + n.b_off[l], nxt, n.d[l], n.d[l + 1], l != n.L - 1);
+            } else {
+                fcm_stage_w(pt + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
+                fcm_forward(cur, Wl, pt + n.b_off[l], nxt, n.d[l], n.d[l + 1], ldw, l != n.L - 1);
+            }
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
         if (t < 32) {  // max over actions, in action order
@@ -514,11 +591,14 @@ __global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int d
         __syncthreads();
         // ---- online net on s, activations kept
         for (int l = 0; l < n.L; ++l) {
-            fcm_stage_w(po + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
-            fcm_forward(acts + (long)l * dm * FCM_BSP, Wl, po + n.b_off[l], acts + (long)(l + 1) * dm * FCM_BSP, n.d[l], n.d[l + 1],
-                        ldw, l != n.L - 1);
+            if (WG) {
+                fcm_forward_g(act(l), po + n.w_off[l], po + n.b_off[l], act(l + 1), n.d[l], n.d[l + 1], l != n.L - 1);
+            } else {
+                fcm_stage_w(po + n.w_off[l], Wl, n.d[l], n.d[l + 1], ldw);
+                fcm_forward(act(l), Wl, po + n.b_off[l], act(l + 1), n.d[l], n.d[l + 1], ldw, l != n.L - 1);
+            }
         }
-        const float* q = acts + (long)n.L * dm * FCM_BSP;  // [A][BSP]
+        const float* q = act(n.L);  // [A][BSP]
         for (int e = t; e < nbk * A; e += FCM_T) a.q_dbg[((long)k * B + b0) * A + e] = q[(e % A) * FCM_BSP + e / A];
         // ---- TD error, loss, dL/dq  (idqn.py:111-124)
         float* delta = dA;
@@ -549,8 +629,8 @@ __global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int d
         float* dprev = dB;
         for (int l = n.L - 1; l >= 0; --l) {
             const int din = n.d[l], dout = n.d[l + 1];
-            const float* inT = acts + (long)l * dm * FCM_BSP;
-            if (l != n.L - 1) fcm_stage_w(po + n.w_off[l], Wl, din, dout, ldw);
+            const float* inT = act(l);
+            if (!WG && l != n.L - 1) fcm_stage_w(po + n.w_off[l], Wl, din, dout, ldw);
             // gW[i][o] = sum_b inT[i][b] * delta[o][b]: tiles of 32 rows i x 32 columns o, k = the 32 samples
             const int nti = (din + 31) / 32, nto = (dout + 31) / 32;
             for (int tile = wave; tile < nti * nto; tile += FCM_T / 64) {
@@ -588,8 +668,35 @@ __global__ __launch_bounds__(FCM_T) void k_fc_step_mfma(FcArgs a, int ldw, int d
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const float* Ap = delta + h * FCM_BSP + bl;                  // A[b = bl][k = o = 2 s + h]
-                    const float* Bp = Wl + (long)(ti * 32 + bl) * ldw + h;       // B[k = o][i = bl]   (rows past din: junk, not written)
-                    for (int s0 = 0; s0 < ks; ++s0) acc = mfma32(Ap[2 * s0 * FCM_BSP], Bp[2 * s0], acc);
+                    if (WG) {
+                        // B[k = o][i = bl] = W[i][o] from global: a lane walks its own row (rows past din clamped, not
+                        // written), 2 s + h; a 128-byte line serves 16 steps of both half-waves from L1
+                        const float* Wr = po + n.w_off[l] + (long)min(ti * 32 + bl, din - 1) * dout;
+                        const int nch = (ks + FCM_CH - 1) / FCM_CH;
+                        float b0[FCM_CH], b1[FCM_CH];
+#define FCM_LOAD(c, dst)                                                  \
+    _Pragma("unroll") for (int u = 0; u < FCM_CH; ++u) {                  \
+        const int o = 2 * ((c) * FCM_CH + u) + h;                         \
+        dst[u] = o < dout ? Wr[o] : 0.f;                                  \
+    }
+#define FCM_MMA(c, src)                                                   \
+    _Pragma("unroll") for (int u = 0; u < FCM_CH; ++u) {                  \
+        const int s0 = (c) * FCM_CH + u;                                  \
+        if (s0 < ks) acc = mfma32(Ap[2 * s0 * FCM_BSP], src[u], acc);     \
+    }
+                        FCM_LOAD(0, b0)
+                        for (int c = 0; c < nch; c += 2) {
+                            if (c + 1 < nch) { FCM_LOAD(c + 1, b1) }
+                            FCM_MMA(c, b0)
+                            if (c + 2 < nch) { FCM_LOAD(c + 2, b0) }
+                            if (c + 1 < nch) { FCM_MMA(c + 1, b1) }
+                        }
+#undef FCM_LOAD
+#undef FCM_MMA
+                    } else {
+                        const float* Bp = Wl + (long)(ti * 32 + bl) * ldw + h;   // B[k = o][i = bl]   (rows past din: junk, not written)
+                        for (int s0 = 0; s0 < ks; ++s0) acc = mfma32(Ap[2 * s0 * FCM_BSP], Bp[2 * s0], acc);
+                    }
                     const int i = ti * 32 + bl;
                     if (i < din) {
 #pragma unroll

@@ -293,7 +293,8 @@ struct idqn_handle_s {
     FcNet fc;
     float* fc_ws = nullptr;
     FcPlan fc_plan_;  // LDS plan of k_fc_step_lds (BS = 0: the net does not fit and the generic kernel runs)
-    FcMfmaPlan fcm_plan_;  // LDS plan of k_fc_step_mfma (floats = 0: the largest weight matrix does not fit LDS whole)
+    FcMfmaPlan fcm_plan_;  // LDS plan of k_fc_step_mfma (floats = 0: neither the staged-weights nor the global-weights layout fits)
+    bool fcm_global_ = false;  // the plan is fc_mfma_plan_g: weight operands from global memory
     // timeline of a whole step (IDQN_F_PROFILE_ALL): one event after every launch; idqn_profile_table averages per name
     std::vector<hipEvent_t> tl_ev;
     std::vector<const char*> tl_name;
@@ -720,9 +721,20 @@ int fc_setup(idqn_handle_s* h) {
     }
     h->fcm_plan_ = fc_mfma_plan(n);
     if (getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
-    if (h->fcm_plan_.floats)
-        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(h->fcm_plan_.floats * 4)));
+    h->fcm_global_ = false;
+    if (!h->fcm_plan_.floats && !(getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA") || getenv("IDQN_FC_NO_MFMA_G") || n.dmax > FC_MAX_WIDTH)) {
+        // the matrix does not fit LDS beside the activations: the same kernel with the weight operand read from global memory
+        h->fcm_plan_ = fc_mfma_plan_g(n);
+        h->fcm_global_ = h->fcm_plan_.floats != 0;
+    }
+    if (h->fcm_plan_.floats) {
+        if (h->fcm_global_)
+            IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(h->fcm_plan_.floats * 4)));
+        else
+            IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(h->fcm_plan_.floats * 4)));
+    }
     h->dominant = "k_fc_step";
     return IDQN_OK;
 }
@@ -1755,7 +1767,8 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         const FcPlan& fp = h->fc_plan_;
         const size_t lds = (size_t)fp.floats * 4;
         const FcMfmaPlan& fm = h->fcm_plan_;
-        if (fm.floats) hipLaunchKernelGGL(k_fc_step_mfma, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
+        if (fm.floats && h->fcm_global_) hipLaunchKernelGGL(k_fc_step_mfma<true>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
+        else if (fm.floats) hipLaunchKernelGGL(k_fc_step_mfma<false>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
         else if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else if (fp.BS == 16) hipLaunchKernelGGL(k_fc_step_lds<16>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else if (fp.BS == 8) hipLaunchKernelGGL(k_fc_step_lds<8>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);

@@ -341,7 +341,9 @@ def test_dqn_entry_points_run_as_scripts(env_name, tmp_path):
     ("cnn", (20, 20, 4), [32, 32, 32, 128], 4, 2, 256),    # eight sample blocks (BASELINE config 4's global batch)
     ("fc", 8, [100, 100], 4, 3, 7),
     ("fc", (6, 1), [50], 2, 9, 64),
-    ("fc", 8, [200, 200], 4, 2, 40),       # 16-sample blocks and weight column tiles in the LDS kernel
+    ("fc", 8, [200, 200], 4, 2, 40),       # the MFMA kernel with weight operands from global memory, two sample blocks
+    ("fc", 9, [255, 131], 5, 2, 70),       # the same with odd widths (k padding, clamped edge tiles), three blocks
+    ("fc", 8, [200, 200, 200], 4, 1, 32),  # three hidden layers of that size still fit (activations packed per layer)
     ("fc", 12, [512, 300, 64], 6, 2, 33),  # 8-sample blocks, four layers, widest layer the LDS kernels take
     ("fc", 10, [700, 33], 3, 2, 12),       # wider than that: the generic kernel (any width), acting through k_fc_q
     ("fc", 5, [7, 9], 3, 2, 32),           # odd widths

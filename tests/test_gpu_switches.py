@@ -9,6 +9,8 @@
                       weight-gradient launches (csrc/dense0_update.h)   -> same losses, Dense_0 bit-identical, conv leaves
                       within fp32 round-off (those launches are planned for fewer workgroups = other chunk sums)
   IDQN_D0_ROWS=1      the fused Dense_0 kernel on whole rows, no finalize launch  -> same, conv leaves within round-off
+  IDQN_FC_NO_MFMA_G=1 / IDQN_FC_NO_MFMA=1 / IDQN_FC_GENERIC=1   the MLP step on the LDS kernel / the generic kernel instead of
+                      the MFMA kernels (csrc/fc_kernels.h)  -> same losses and parameters within fp32 round-off
 """
 import json
 import os
@@ -126,3 +128,45 @@ def test_trainer_loop_with_and_without_step_graph():
     assert a["count"] == b["count"] and a["count"] >= 40
     assert a["probe"] == b["probe"]
     assert a["target"] == b["target"]
+
+
+FC_CHILD = r"""
+import json, sys, os
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn.networks.idqn import iDQN
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+out = {}
+for name, K, feats, B in (("lunar", 3, [100, 100], 32), ("wide", 5, [200, 200], 48)):
+    rng = np.random.default_rng(11)
+    agent = iDQN(5, 8, 4, K, feats, "fc", 3e-4, 0.99, 1, 1, 10**9, 10**9)
+    b = Batch(torch.from_numpy(rng.standard_normal((B, 8)).astype(np.float32)).cuda(),
+              torch.from_numpy(rng.integers(0, 4, B).astype(np.int32)).cuda(),
+              torch.from_numpy(rng.standard_normal(B).astype(np.float32)).cuda(),
+              torch.from_numpy(rng.standard_normal((B, 8)).astype(np.float32)).cuda(),
+              torch.from_numpy((rng.random(B) < 0.1).astype(np.uint8)).cuda())
+    losses = [agent._learn(b).cpu().numpy().astype(np.float64).tolist() for _ in range(5)]
+    flat = agent._flat(agent._online)
+    out[name] = {"losses": losses, "probe": {n: v.reshape(K, -1)[:, :: max(1, v[0].size // 53)].astype(np.float64).tolist() for n, v in flat.items()}}
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_mlp_kernel_variants_agree():
+    """The MLP step has four kernels (MFMA with staged weights, MFMA with weights from global memory, LDS FMA, generic);
+    which one runs is a matter of what fits LDS.  Forced onto the slower ones, the same seeded steps must give the same
+    losses and parameters to fp32 round-off (the sums run in another order)."""
+    def run(**env):
+        e = dict(os.environ, **env)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FC_CHILD], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+
+    base = run()
+    for env in ({"IDQN_FC_NO_MFMA_G": "1"}, {"IDQN_FC_NO_MFMA": "1"}, {"IDQN_FC_GENERIC": "1"}):
+        got = run(**env)
+        for name in base:
+            np.testing.assert_allclose(np.asarray(got[name]["losses"]), np.asarray(base[name]["losses"]), rtol=0, atol=2e-6, err_msg=str(env))
+            for leaf, want in base[name]["probe"].items():
+                np.testing.assert_allclose(np.asarray(got[name]["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=f"{env} {name} {leaf}")
