@@ -14,6 +14,7 @@
 // then the plain step's conv backward, fused Dense_0 weight gradient + Adam (over the N blocks) and small-leaf Adam.
 #pragma once
 #include "cnn_kernels.h"
+#include "iqn_gemm.h"
 
 constexpr int IQN_EMBED = 64;  // cos features per fraction (IQN paper, section 3; Dopamine quantile_embedding_dim)
 

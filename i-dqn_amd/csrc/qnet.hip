@@ -1803,7 +1803,20 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
     d.net_rot = 0;
-    hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
+    static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+    if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
+        IqnD0FwdArgs g;
+        g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
+        g.V = V; g.nb = w.N; g.NS = w.NS; g.F = h->F; g.J = h->J;
+        const size_t lds = 2 * (size_t)IG_STAGE;
+        const dim3 grid((unsigned)(V * (w.N / 8) * w.NS * (h->J / 256)));
+        static LdsAttrMark attr;
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_iqn_d0_fwd<2>, grid, dim3(512), lds, q, g);
+    } else {
+        hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    }
     tl_mark(h, q, "iqn dense0 fwd");
     HiddenArgs hi;
     hi.part = w.part; hi.wbase = wbase_v; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = w.N; hi.NS = w.NS;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# the i-IQN bench line under a list of environment settings ("A=1 B=2" per argument; "" = defaults): step time + the big launches
+cd "${GRAFT_REPO_ROOT:?}"
+i=0
+for e in "$@"; do
+  i=$((i+1))
+  env $e timeout -k 10 300 python bench.py --algo iiqn --no-cpu-baseline --steps 15 --warmup 3 --repeats 1 > gpurun_out/ie_$i.json 2> gpurun_out/ie_$i.err || { echo "[$e] failed"; tail -3 gpurun_out/ie_$i.err; exit 1; }
+  python3 - "$e" $i <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/ie_{sys.argv[2]}.json"))
+k = {r["launch"]: r["us"] for r in d["kernels"]}
+print(f"{sys.argv[1] or '(defaults)':40s} {d['ms_per_step']:.4f} ms | fwd {k['iqn dense0 fwd']:7.1f} dgrad {k['iqn dense0 dgrad']:7.1f} wgrad {k['dense0 wgrad + adam']:7.1f} planes {k.get('factor planes', 0):6.1f} embed {k['iqn embedding x features']:6.1f} embed_bwd {k['iqn embedding backward']:6.1f}")
+PY
+done
