@@ -10,7 +10,10 @@
 // into the three bf16 planes once, and parks the fragments -- exactly the 16-byte vectors the MFMA takes -- in LDS; after
 // one barrier each wave runs its 4 x 2 tiles (48 MFMAs) against fragments read back from LDS.  Per k-step and workgroup:
 // 32 KB fetched and 128 element-pairs split per lane-pair for 384 MFMAs (the per-block kernel: 80 KB and 4x the split work).
-//   forward   part[v][bb][s][j][b] = sum over the split's rows f of W[f][j] * x[v][bb][f][b]      (k_iqn_d0_fwd)
+//   forward        part[v][bb][s][j][b] = sum over the split's rows f of W[f][j] * x[v][bb][f][b]      (k_iqn_d0_fwd)
+//   data gradient  dx[k][bb][f][b] = sum over j of W[f][j] * dh[k][bb][j][b]                             (k_iqn_d0_dgrad)
+//   weight gradient g[ks][k][f][j] = sum over the blocks of split ks and b of x[k][bb][f][b] * dh[k][bb][j][b]  (k_iqn_d0_wgrad)
+//                  followed by k_iqn_d0_adam: g = g[0] + g[1] (fixed order), Adam on Dense_0/kernel in one streaming pass
 // The k-steps of a split are taken in the same order and the six products in the same order as in k_dense0_fwd3: the
 // partials are bit-identical to that kernel's.
 #pragma once
@@ -174,4 +177,301 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
             for (int r = 0; r < 16; ++r) P[(long)(col0 + mfma_row(r, h)) * 32] = acc[i][j][r];
         }
     }
+}
+
+// ---- data gradient: dx = W0 . dh for every fraction block of the K online nets ------------------------------------------
+// The per-block kernel (k_dense0_dgrad) runs on the f32 MFMA (1/16 of the bf16 rate; fine for the plain step, where it is
+// bound by streaming W once): 0.48 ms for 32 blocks per net.  Same workgroup shape as the forward: a 256 (f rows) x 256
+// (8 blocks) tile, k = the J hidden units in steps of 16; operand tiles: dh of one block (rows j, 8 dwords per lane, as the
+// forward's activation tile) and 32 rows of W (16 consecutive floats of a lane's own row per k-step = 2 float4 per
+// half-wave lane).  MFMA orientation as in k_dense0_dgrad (A = dh: rows = samples, B = W: columns = f): a lane ends up
+// with ONE row f and 4 x 4 consecutive samples -> float4 stores.
+struct IqnD0DgradArgs {
+    const float* dh;            // [K][nb][J][32]
+    const float* const* wbase;  // [K] online nets
+    float* dx;                  // [K][nb][F][32]
+    long w_off;
+    int K, nb, F, J;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
+    // item = (net, 256-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
+    int item = xcd_contiguous_id();
+    const int nbg = a.nb / 8, nfg = (a.F + 255) / 256;
+    const int bg = item % nbg;
+    item /= nbg;
+    const int fg = item % nfg;
+    const int k = item / nfg;
+    const int NC = a.J / 16;
+    // producer role: W tile `wave` = rows f = 256 fg + 32 wave + bl (clamped past F: computed, not stored), lane (bl, h)
+    // holds columns 16 c + 8 h .. + 7; dh tile `wave` = block 8 bg + wave, rows j = 16 c + 8 h + jj, sample bl
+    const int frow = min(fg * 256 + wave * 32 + bl, a.F - 1);
+    const float* Wp = a.wbase[k] + a.w_off + (long)frow * a.J + 8 * h;
+    const float* Dp = a.dh + ((long)k * a.nb + bg * 8 + wave) * a.J * 32 + (long)(8 * h) * 32 + bl;
+    // consumer role: W tiles 4 wn .. 4 wn + 3 against blocks 2 wm, 2 wm + 1
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float wr[D][8], xr[D][8];
+    auto fetch = [&](int slot, int c) {
+        const float4 w0 = *reinterpret_cast<const float4*>(Wp + 16 * c), w1 = *reinterpret_cast<const float4*>(Wp + 16 * c + 4);
+        wr[slot][0] = w0.x; wr[slot][1] = w0.y; wr[slot][2] = w0.z; wr[slot][3] = w0.w;
+        wr[slot][4] = w1.x; wr[slot][5] = w1.y; wr[slot][6] = w1.z; wr[slot][7] = w1.w;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) xr[slot][jj] = Dp[(long)(16 * c + jj) * 32];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, min(d, NC - 1));
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;
+    unsigned char* const my_w = ig_lds + wave * IG_TILE + lane * 16;
+    unsigned char* const my_x = ig_lds + (8 + wave) * IG_TILE + lane * 16;
+    const unsigned char* const rd_w = ig_lds + (4 * wn) * IG_TILE + lane * 16;
+    const unsigned char* const rd_x = ig_lds + (8 + 2 * wm) * IG_TILE + lane * 16;
+    ig_park(wr[0], my_w);
+    ig_park(xr[0], my_x);
+    fetch(0, min(D, NC - 1));
+    for (int c0 = 0; c0 < NC; c0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            if (c < NC) {  // (uniform over the workgroup)
+                const int nslot = (u + 1) % D, stg = (u & 1) * IG_STAGE, nstg = ((u + 1) & 1) * IG_STAGE;
+                lds_barrier();
+                bf16x8 xf[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[j][p] = *LDS_PTR(const bf16x8, rd_x + stg + j * IG_TILE + p * 1024);
+                unsigned p0[4], p1[4], p2[4];
+                bf16x8 wf[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[0][p] = *LDS_PTR(const bf16x8, rd_w + stg + p * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < 3) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wf[(i + 1) & 1][p] = *LDS_PTR(const bf16x8, rd_w + stg + (i + 1) * IG_TILE + p * 1024);
+                    }
+                    const bf16x8 w0 = wf[i & 1][0], w1 = wf[i & 1][1], w2 = wf[i & 1][2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][0] = mfma_bf16(xf[0][2], w0, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][2], w0, acc[i][1]);
+                    acc[i][0] = mfma_bf16(xf[0][0], w2, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][0], w2, acc[i][1]);
+                    acc[i][0] = mfma_bf16(xf[0][1], w1, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][1], w1, acc[i][1]);
+                    {
+                        const int m = (2 * i) & 3;
+                        if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        else split3_pk(xr[nslot][2 * m], xr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][0] = mfma_bf16(xf[0][1], w0, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][1], w0, acc[i][1]);
+                    acc[i][0] = mfma_bf16(xf[0][0], w1, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][0], w1, acc[i][1]);
+                    acc[i][0] = mfma_bf16(xf[0][0], w0, acc[i][0]);
+                    acc[i][1] = mfma_bf16(xf[1][0], w0, acc[i][1]);
+                    {
+                        const int m = (2 * i + 1) & 3;
+                        if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        else split3_pk(xr[nslot][2 * m], xr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        if (m == 3) {
+                            unsigned char* dst = (i < 2 ? my_w : my_x) + nstg;
+                            *LDS_PTR(u32x4, dst) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                            *LDS_PTR(u32x4, dst + 1024) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+                            *LDS_PTR(u32x4, dst + 2048) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(nslot, min(c + 1 + D, NC - 1));
+            }
+        }
+    }
+    // this lane of tile (i, j): row f = 256 fg + 32 (4 wn + i) + bl, samples (r & 3) + 8 (r >> 2) + 4 h of block 8 bg + 2 wm + j
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = fg * 256 + (4 * wn + i) * 32 + bl;
+        if (f >= a.F) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* O = a.dx + (((long)k * a.nb + bg * 8 + 2 * wm + j) * a.F + f) * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(O + 8 * g) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------------
+// The plain step's fused kernel (dense0_update.h) contracts the sample blocks inside the workgroups that stream theta / m / v:
+// one 32 x 256 tile each, every factor fragment fetched per tile -- right for 1..8 blocks (HBM-bound), 0.41 + 0.07 ms at 32
+// blocks (the fragment traffic of 980 x 32 tile-blocks).  Here: the same 256 x 256 GEMM tile (f rows x j columns), k = the
+// samples of the blocks, 16 per k-step (two k-steps per block); both operands are k-contiguous in memory (a lane's 8 samples
+// of its own row = 2 float4).  The block range is cut in `KS` splits so that K x 31 x 2 x KS workgroups fill the chip
+// more evenly; each split writes its own partial, k_iqn_d0_adam adds them in split order (reproducible) inside the Adam pass.
+struct IqnD0WgradArgs {
+    const float* x;    // [K][nb][F][32]  (the online virtual nets come first in xq)
+    const float* dh;   // [K][nb][J][32]
+    float* g[2];       // partial sums [K][F][J] of split 0 / 1
+    int K, nb, F, J, KS;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void k_iqn_d0_wgrad(IqnD0WgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
+    int item = xcd_contiguous_id();
+    const int n_jh = a.J / 256, nfg = (a.F + 255) / 256;
+    const int jh = item % n_jh;
+    item /= n_jh;
+    const int ks = item % a.KS;
+    item /= a.KS;
+    const int fg = item % nfg;
+    const int k = item / nfg;
+    const int nbs = a.nb / a.KS, b0 = ks * nbs, NC = 2 * nbs;  // k-step c: block b0 + c / 2, samples 16 (c & 1) + 8 h .. + 7
+    // producer role: x tile `wave` = rows f = 256 fg + 32 wave + bl (clamped past F), dh tile `wave` = columns j = 256 jh + 32 wave + bl
+    const int frow = min(fg * 256 + wave * 32 + bl, a.F - 1);
+    const float* Xp = a.x + ((long)k * a.nb + b0) * a.F * 32 + (long)frow * 32 + 8 * h;
+    const float* Dp = a.dh + ((long)k * a.nb + b0) * a.J * 32 + (long)(jh * 256 + wave * 32 + bl) * 32 + 8 * h;
+    const long xblk = (long)a.F * 32, dblk = (long)a.J * 32;
+    // consumer role: x tiles 4 wn .. 4 wn + 3 (rows) against dh tiles 2 wm, 2 wm + 1 (columns)
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float wr[D][8], xr[D][8];
+    auto fetch = [&](int slot, int c) {
+        const long ob = (long)(c >> 1), oh = 16 * (c & 1);
+        const float4 x0 = *reinterpret_cast<const float4*>(Xp + ob * xblk + oh), x1 = *reinterpret_cast<const float4*>(Xp + ob * xblk + oh + 4);
+        const float4 d0 = *reinterpret_cast<const float4*>(Dp + ob * dblk + oh), d1 = *reinterpret_cast<const float4*>(Dp + ob * dblk + oh + 4);
+        wr[slot][0] = x0.x; wr[slot][1] = x0.y; wr[slot][2] = x0.z; wr[slot][3] = x0.w;
+        wr[slot][4] = x1.x; wr[slot][5] = x1.y; wr[slot][6] = x1.z; wr[slot][7] = x1.w;
+        xr[slot][0] = d0.x; xr[slot][1] = d0.y; xr[slot][2] = d0.z; xr[slot][3] = d0.w;
+        xr[slot][4] = d1.x; xr[slot][5] = d1.y; xr[slot][6] = d1.z; xr[slot][7] = d1.w;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, min(d, NC - 1));
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;
+    unsigned char* const my_w = ig_lds + wave * IG_TILE + lane * 16;
+    unsigned char* const my_x = ig_lds + (8 + wave) * IG_TILE + lane * 16;
+    const unsigned char* const rd_w = ig_lds + (4 * wn) * IG_TILE + lane * 16;
+    const unsigned char* const rd_x = ig_lds + (8 + 2 * wm) * IG_TILE + lane * 16;
+    ig_park(wr[0], my_w);
+    ig_park(xr[0], my_x);
+    fetch(0, min(D, NC - 1));
+    for (int c0 = 0; c0 < NC; c0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            if (c < NC) {  // (uniform over the workgroup)
+                const int nslot = (u + 1) % D, stg = (u & 1) * IG_STAGE, nstg = ((u + 1) & 1) * IG_STAGE;
+                lds_barrier();
+                bf16x8 xf[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[j][p] = *LDS_PTR(const bf16x8, rd_x + stg + j * IG_TILE + p * 1024);
+                unsigned p0[4], p1[4], p2[4];
+                bf16x8 wf[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[0][p] = *LDS_PTR(const bf16x8, rd_w + stg + p * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < 3) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wf[(i + 1) & 1][p] = *LDS_PTR(const bf16x8, rd_w + stg + (i + 1) * IG_TILE + p * 1024);
+                    }
+                    const bf16x8 w0 = wf[i & 1][0], w1 = wf[i & 1][1], w2 = wf[i & 1][2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][0] = mfma_bf16(w2, xf[0][0], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w2, xf[1][0], acc[i][1]);
+                    acc[i][0] = mfma_bf16(w0, xf[0][2], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w0, xf[1][2], acc[i][1]);
+                    acc[i][0] = mfma_bf16(w1, xf[0][1], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w1, xf[1][1], acc[i][1]);
+                    {
+                        const int m = (2 * i) & 3;
+                        if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        else split3_pk(xr[nslot][2 * m], xr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][0] = mfma_bf16(w1, xf[0][0], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w1, xf[1][0], acc[i][1]);
+                    acc[i][0] = mfma_bf16(w0, xf[0][1], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w0, xf[1][1], acc[i][1]);
+                    acc[i][0] = mfma_bf16(w0, xf[0][0], acc[i][0]);
+                    acc[i][1] = mfma_bf16(w0, xf[1][0], acc[i][1]);
+                    {
+                        const int m = (2 * i + 1) & 3;
+                        if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        else split3_pk(xr[nslot][2 * m], xr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
+                        if (m == 3) {
+                            unsigned char* dst = (i < 2 ? my_w : my_x) + nstg;
+                            *LDS_PTR(u32x4, dst) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                            *LDS_PTR(u32x4, dst + 1024) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+                            *LDS_PTR(u32x4, dst + 2048) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(nslot, min(c + 1 + D, NC - 1));
+            }
+        }
+    }
+    // tile (i, j): rows f = 256 fg + 32 (4 wn + i) + mfma_row(r, h), column j = 256 jh + 32 (2 wm + j) + bl: a store
+    // instruction writes two 128-byte row pieces
+    float* G = a.g[ks] + (long)k * a.F * a.J + jh * 256 + bl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f0 = fg * 256 + (4 * wn + i) * 32;
+        if (f0 >= a.F) continue;  // F is a multiple of 32: whole tiles are in or out
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) G[(long)(f0 + mfma_row(r, h)) * a.J + (2 * wm + j) * 32] = acc[i][j][r];
+    }
+}
+
+// Adam on Dense_0/kernel from the partial gradient sums: one float4 per thread, every stream non-temporal (dense0_update.h)
+struct IqnD0AdamArgs {
+    const float* g[2];
+    float *theta, *mu, *nu;  // parameter arenas, head stride P, Dense_0/kernel at w_off
+    const float* bcinv;
+    AdamConsts ad;
+    long P, w_off, n;        // n = F * J
+    int KS;
+};
+__global__ __launch_bounds__(256) void k_iqn_d0_adam(IqnD0AdamArgs a) {
+    const int k = blockIdx.y;
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= a.n) return;
+    const long o = (long)k * a.P + a.w_off + e;
+    float4 th = ld4<true>(a.theta + o), m = ld4<true>(a.mu + o), v = ld4<true>(a.nu + o);
+    float4 g = ld4<true>(a.g[0] + (long)k * a.n + e);
+    if (a.KS > 1) {
+        const float4 g1 = ld4<true>(a.g[1] + (long)k * a.n + e);
+        g.x += g1.x; g.y += g1.y; g.z += g1.z; g.w += g1.w;
+    }
+    const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
+    adam_elem(a.ad, bc1, bc2, g.x, th.x, m.x, v.x);
+    adam_elem(a.ad, bc1, bc2, g.y, th.y, m.y, v.y);
+    adam_elem(a.ad, bc1, bc2, g.z, th.z, m.z, v.z);
+    adam_elem(a.ad, bc1, bc2, g.w, th.w, m.w, v.w);
+    st4<true>(a.theta + o, th);
+    st4<true>(a.mu + o, m);
+    st4<true>(a.nu + o, v);
 }

@@ -220,6 +220,7 @@ struct IqnWs {
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
+    float* g1 = nullptr;  // second partial of the Dense_0 weight gradient [K][F * J] (iqn_gemm.h), N a multiple of 16 only
     long off_we = 0, off_be = 0;
 };
 
@@ -572,6 +573,7 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
         if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
         if ((rc = alloc_zero(&w.dpsi, (long)K * h->F * 32, h, "iqn_dpsi"))) return rc;
+        if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
     h->dominant = "k_dense0_wgrad";
@@ -1875,7 +1877,17 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         dd.dh = w.dh; dd.raw = w.dx; dd.wbase = h->train.wbase; dd.w_off = h->off_w0;
         dd.K = K; dd.nb = w.N; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = h->conv[2].CO; dd.g = h->gda3;
         dd.n_items = (long)K * w.N * cdiv(dd.n_ft, 4);
-        hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+        static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+        if (gemm && w.N % 8 == 0 && h->J % 16 == 0) {
+            IqnD0DgradArgs g;
+            g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
+            const size_t lds = 2 * (size_t)IG_STAGE;
+            static LdsAttrMark attr;
+            if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3((unsigned)(K * (w.N / 8) * cdiv(h->F, 256))), dim3(512), lds, q, g);
+        } else {
+            hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
+        }
         tl_mark(h, q, "iqn dense0 dgrad");
     }
     IqnEmbedBwdArgs eb;
@@ -1891,8 +1903,25 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
         tl_mark(h, q, "da3 finalize (sum, mask, planes)");
     }
-    // Dense_0 weight gradient over the N fraction blocks of every head, fused with Adam (x of the online virtual nets, dh)
-    if ((rc = launch_dense0_wgrad(h, w.xq, w.dh, w.N, w.N, 0, (long)w.N * h->F * 32, (long)h->F * 32, 0, (long)w.N * h->J * 32,
+    // Dense_0 weight gradient over the N fraction blocks of every head + Adam: as a GEMM with two block splits and one
+    // streaming Adam pass (iqn_gemm.h), or (IDQN_IQN_GEMM=0, N not a multiple of 16) the plain step's fused kernel
+    static const bool gemm_w = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+    if (gemm_w && w.g1 && w.N % 16 == 0) {
+        const long n = (long)h->F * h->J;
+        IqnD0WgradArgs g;
+        g.x = w.xq; g.dh = w.dh; g.g[0] = h->grad + h->g_w0_base; g.g[1] = w.g1; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J; g.KS = 2;
+        const size_t lds = 2 * (size_t)IG_STAGE;
+        static LdsAttrMark attr;
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_wgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_iqn_d0_wgrad<2>, dim3((unsigned)(K * cdiv(h->F, 256) * g.KS * (h->J / 256))), dim3(512), lds, q, g);
+        tl_mark(h, q, "iqn dense0 wgrad");
+        IqnD0AdamArgs aa;
+        aa.g[0] = g.g[0]; aa.g[1] = g.g[1]; aa.theta = h->online; aa.mu = h->mu; aa.nu = h->nu; aa.bcinv = h->bcinv; aa.ad = h->ad;
+        aa.P = h->L.head_stride; aa.w_off = h->off_w0; aa.n = n; aa.KS = g.KS;
+        hipLaunchKernelGGL(k_iqn_d0_adam, dim3((unsigned)cdiv(n / 4, 256), (unsigned)K), dim3(256), 0, q, aa);
+        tl_mark(h, q, "iqn dense0 adam");
+        IDQN_HIP_CHECK(hipGetLastError());
+    } else if ((rc = launch_dense0_wgrad(h, w.xq, w.dh, w.N, w.N, 0, (long)w.N * h->F * 32, (long)h->F * 32, 0, (long)w.N * h->J * 32,
                                   (long)h->J * 32, true, (flags & IDQN_F_PROFILE) != 0, q, false)))
         return rc;
     if ((rc = cnn_backward_rest(h, batch, true, q))) return rc;
