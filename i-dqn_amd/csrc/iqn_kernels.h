@@ -43,33 +43,50 @@ struct IqnEmbedArgs {
     int K, N, F;
 };
 __global__ __launch_bounds__(256) void k_iqn_embed(IqnEmbedArgs a) {
+    // grid = (f tiles / 4, virtual net, fraction group): a wave keeps its 64 x 32 tile of We, its 32 x 32 tile of psi and
+    // the bias for all the fractions of its group (they belong to one virtual net) and requests the cos rows of fraction
+    // q + 1 before the products of fraction q -- one fetch of the shared operands and one exposed load latency per group
+    // instead of per (fraction, tile)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int ft = blockIdx.x * 4 + wave;
     if (ft >= a.F / 32) return;
-    const int slot = blockIdx.y, v = slot / a.N, type = v / a.K, k = v - type * a.K;
+    const int v = blockIdx.y, type = v / a.K, k = v - type * a.K;
+    const int nq = a.N / (int)gridDim.z, q0 = blockIdx.z * nq;
     const int f0 = ft * 32;
     const float* P = a.wbase[v];
     const float* We = P + a.we_off + f0 + r;
-    const float* C = a.cosb + (long)slot * IQN_EMBED * 32 + r;
-    float wa[32], cb[32];
+    float wa[32], cb[2][32];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        wa[s] = We[(long)(2 * s + h) * a.F];
-        cb[s] = C[(2 * s + h) * 32];
-    }
-    f32x16 acc;
+    for (int s = 0; s < 32; ++s) wa[s] = We[(long)(2 * s + h) * a.F];
+    const float* C0 = a.cosb + (long)(v * a.N + q0) * IQN_EMBED * 32 + r;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[s], acc);
+    for (int s = 0; s < 32; ++s) cb[0][s] = C0[(2 * s + h) * 32];
     const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
-    float* X = a.x + (long)slot * a.F * 32;
+    float be[16], ps[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int f = f0 + mfma_row(i, h);
-        const float e = acc[i] + P[a.be_off + f];
-        X[(long)f * 32 + r] = fmaxf(e, 0.f) * psi[(long)f * 32 + r];
+        be[i] = P[a.be_off + f];
+        ps[i] = psi[(long)f * 32 + r];
     }
+#define IE_STEP(q, st)                                                                              \
+    {                                                                                               \
+        if ((q) + 1 < nq) {                                                                         \
+            const float* Cn = C0 + (long)((q) + 1) * IQN_EMBED * 32;                                \
+            _Pragma("unroll") for (int s = 0; s < 32; ++s) cb[(st) ^ 1][s] = Cn[(2 * s + h) * 32]; \
+        }                                                                                           \
+        f32x16 acc;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
+        _Pragma("unroll") for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[st][s], acc);         \
+        float* X = a.x + (long)(v * a.N + q0 + (q)) * a.F * 32;                                     \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                              \
+            X[(long)(f0 + mfma_row(i, h)) * 32 + r] = fmaxf(acc[i] + be[i], 0.f) * ps[i];           \
+    }
+    for (int q = 0; q < nq; q += 2) {
+        IE_STEP(q, 0)
+        if (q + 1 < nq) IE_STEP(q + 1, 1)
+    }
+#undef IE_STEP
 }
 
 // Z[slot][action][b] = b1[action] + the Dense_1 chunk partials in chunk order: one workgroup per (virtual net, fraction).
@@ -268,15 +285,18 @@ struct IqnEmbedBwdArgs {
     const float* const* wbase;
     const float* psi;   // [2K][F * 32]
     const float* dx;    // [K][N][F][32]
-    float* dpsi;        // [K][F][32]  (not yet masked by psi > 0)
-    float* grad;
-    long we_off, be_off, gP, g_we_off, g_be_off;
+    float* dpsi;        // [QG][K][F][32] partial sums over the fractions of group qg (not yet masked by psi > 0)
+    float* gpart;       // [QG][K][65][F]: rows 0..63 = dL/dWe, row 64 = dL/dbe of group qg (k_iqn_embed_grad_sum adds the groups)
+    long we_off, be_off;
     int K, N, F;
 };
 __global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
     __shared__ float tile[4][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int ft = blockIdx.x * 4 + wave, k = blockIdx.y;
+    // grid = (f tiles / 4, head, fraction group): the N fractions of a tile are dealt to gridDim.z workgroups -- one wave
+    // walking all 32 of them was a single chain of dependent load / MFMA rounds (0.35 ms at 1.2 waves per SIMD)
+    const int ft = blockIdx.x * 4 + wave, k = blockIdx.y, qg = blockIdx.z;
+    const int nq = a.N / (int)gridDim.z, q_begin = qg * nq;
     const bool live = ft < a.F / 32;  // (idle waves still join no barrier: the LDS tile is per wave)
     if (!live) return;
     const int f0 = ft * 32;
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
     f32x16 gw0, gw1;  // dWe rows i = 0..31 / 32..63 x the tile's 32 features
 #pragma unroll
     for (int i = 0; i < 16; ++i) { gw0[i] = 0.f; gw1[i] = 0.f; }
-    for (int q = 0; q < a.N; ++q) {
+    for (int q = q_begin; q < q_begin + nq; ++q) {
         const int slot = k * a.N + q;
         const float* C = a.cosb + (long)slot * IQN_EMBED * 32;
         float cb[32];
@@ -331,8 +351,8 @@ __global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    float* DP = a.dpsi + (long)k * a.F * 32;
-    float* G = a.grad + (long)k * a.gP;
+    float* DP = a.dpsi + ((long)qg * a.K + k) * a.F * 32;
+    float* G = a.gpart + ((long)qg * a.K + k) * 65 * a.F;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int fl = mfma_row(i, h);
@@ -340,10 +360,32 @@ __global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
         float d = dbe[i];
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-        if (r == 0) G[a.g_be_off + f0 + fl] = d;
-        G[a.g_we_off + (long)mfma_row(i, h) * a.F + f0 + r] = gw0[i];
-        G[a.g_we_off + (long)(32 + mfma_row(i, h)) * a.F + f0 + r] = gw1[i];
+        if (r == 0) G[64L * a.F + f0 + fl] = d;
+        G[(long)mfma_row(i, h) * a.F + f0 + r] = gw0[i];
+        G[(long)(32 + mfma_row(i, h)) * a.F + f0 + r] = gw1[i];
     }
+}
+
+// dL/dWe, dL/dbe = the fraction groups' partials added in group order -> gradient arena.  One float4 per thread.
+struct IqnEmbedGradSumArgs {
+    const float* gpart;  // [QG][K][65][F]
+    float* grad;
+    long gP, g_we_off, g_be_off;
+    int K, F, QG;
+};
+__global__ __launch_bounds__(256) void k_iqn_embed_grad_sum(IqnEmbedGradSumArgs a) {
+    const int k = blockIdx.y;
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4, n = 65L * a.F;
+    if (e >= n) return;
+    const float* p = a.gpart + (long)k * n + e;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int g = 1; g < a.QG; ++g) {
+        const float4 y = *reinterpret_cast<const float4*>(p + (long)g * a.K * n);
+        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+    }
+    float* G = a.grad + (long)k * a.gP;
+    const long we_n = 64L * a.F;  // F is a multiple of 4: a float4 never straddles the two leaves
+    *reinterpret_cast<float4*>(e < we_n ? G + a.g_we_off + e : G + a.g_be_off + (e - we_n)) = s;
 }
 
 // mean over the N fractions of Z (acting): q[a] of ONE state = lane 0 of every block.  One wave per action.

@@ -220,6 +220,8 @@ struct IqnWs {
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
+    int QG = 1;              // fraction groups of the embedding backward (partials dpsi / gpart)
+    float* gpart = nullptr;  // [QG][K][65][F]
     float* g1 = nullptr;  // second partial of the Dense_0 weight gradient [K][F * J] (iqn_gemm.h), N a multiple of 16 only
     long off_we = 0, off_be = 0;
 };
@@ -572,7 +574,11 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.dq, KN * c.n_actions * 32, h, "iqn_dq"))) return rc;
         if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
         if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
-        if ((rc = alloc_zero(&w.dpsi, (long)K * h->F * 32, h, "iqn_dpsi"))) return rc;
+        // the embedding backward deals the fractions of a feature tile to QG workgroups (IDQN_IQN_EMBED_QG; a divisor of N)
+        w.QG = getenv("IDQN_IQN_EMBED_QG") ? std::max(1, atoi(getenv("IDQN_IQN_EMBED_QG"))) : 4;
+        while (w.QG > 1 && w.N % w.QG != 0) --w.QG;
+        if ((rc = alloc_zero(&w.dpsi, (long)w.QG * K * h->F * 32, h, "iqn_dpsi"))) return rc;
+        if ((rc = alloc_zero(&w.gpart, (long)w.QG * K * 65 * h->F, h, "iqn_gpart"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
@@ -1798,7 +1804,12 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     IqnEmbedArgs ea;
     ea.cosb = w.cosb; ea.wbase = wbase_v; ea.psi = psi; ea.x = w.xq; ea.we_off = w.off_we; ea.be_off = w.off_be;
     ea.K = K_for_index; ea.N = w.N; ea.F = h->F;
-    hipLaunchKernelGGL(k_iqn_embed, dim3((unsigned)cdiv(h->F / 32, 4), (unsigned)(V * w.N)), dim3(256), 0, q, ea);
+    {   // fractions per wave: 8 when that still leaves >= 8 waves per SIMD to overlap, else fewer (IDQN_IQN_EMBED_Q overrides)
+        static const int qenv = getenv("IDQN_IQN_EMBED_Q") ? atoi(getenv("IDQN_IQN_EMBED_Q")) : 0;
+        int per = qenv > 0 ? qenv : 8;
+        while (per > 1 && (w.N % per != 0)) --per;
+        hipLaunchKernelGGL(k_iqn_embed, dim3((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per)), dim3(256), 0, q, ea);
+    }
     tl_mark(h, q, "iqn embedding x features");
     DenseFwdArgs d;
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
@@ -1890,16 +1901,25 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         }
         tl_mark(h, q, "iqn dense0 dgrad");
     }
+    const int QG = w.QG;
     IqnEmbedBwdArgs eb;
-    eb.cosb = w.cosb; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.grad = h->grad;
-    eb.we_off = w.off_we; eb.be_off = w.off_be; eb.gP = h->gP; eb.g_we_off = w.off_we - w0n; eb.g_be_off = w.off_be - w0n;
+    eb.cosb = w.cosb; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
+    eb.we_off = w.off_we; eb.be_off = w.off_be;
     eb.K = K; eb.N = w.N; eb.F = h->F;
-    hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K), dim3(256), 0, q, eb);
+    hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), 0, q, eb);
     tl_mark(h, q, "iqn embedding backward");
-    {   // dL/dpsi -> ReLU mask, bf16 planes, per-position sums: what the conv backward of the plain step reads
+    {
+        IqnEmbedGradSumArgs gs;
+        gs.gpart = w.gpart; gs.grad = h->grad; gs.gP = h->gP; gs.g_we_off = w.off_we - w0n; gs.g_be_off = w.off_be - w0n;
+        gs.K = K; gs.F = h->F; gs.QG = QG;
+        hipLaunchKernelGGL(k_iqn_embed_grad_sum, dim3((unsigned)cdiv(65L * h->F / 4, 256), K), dim3(256), 0, q, gs);
+        tl_mark(h, q, "iqn embedding grads (group sums)");
+    }
+    {   // dL/dpsi (the fraction groups' partials, in group order) -> ReLU mask, bf16 planes, per-position sums: what the conv
+        // backward of the plain step reads
         Da3FinalizeArgs fa;
         fa.dpart = w.dpsi; fa.a3 = h->train.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
-        fa.n_rows = (long)K * h->F; fa.n_jt = 1; fa.F = h->F; fa.C = h->conv[2].CO; fa.K = K; fa.nb = 1; fa.g = h->gda3;
+        fa.n_rows = (long)K * h->F; fa.n_jt = QG; fa.F = h->F; fa.C = h->conv[2].CO; fa.K = K; fa.nb = 1; fa.g = h->gda3;
         hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
         tl_mark(h, q, "da3 finalize (sum, mask, planes)");
     }
