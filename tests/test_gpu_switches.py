@@ -9,6 +9,9 @@
                       weight-gradient launches (csrc/dense0_update.h)   -> same losses, Dense_0 bit-identical, conv leaves
                       within fp32 round-off (those launches are planned for fewer workgroups = other chunk sums)
   IDQN_D0_ROWS=1      the fused Dense_0 kernel on whole rows, no finalize launch  -> same, conv leaves within round-off
+  IDQN_IQN_GEMM=0     the i-IQN heads' Dense_0 on the plain step's per-block kernels instead of the tiled GEMMs
+                      (csrc/iqn_gemm.h)  -> first-step losses bit-identical (the forward sums in the same order), parameters
+                      within fp32 round-off after a few steps
   IDQN_FC_NO_MFMA_G=1 / IDQN_FC_NO_MFMA=1 / IDQN_FC_GENERIC=1   the MLP step on the LDS kernel / the generic kernel instead of
                       the MFMA kernels (csrc/fc_kernels.h)  -> same losses and parameters within fp32 round-off
 """
@@ -170,3 +173,41 @@ def test_mlp_kernel_variants_agree():
             np.testing.assert_allclose(np.asarray(got[name]["losses"]), np.asarray(base[name]["losses"]), rtol=0, atol=2e-6, err_msg=str(env))
             for leaf, want in base[name]["probe"].items():
                 np.testing.assert_allclose(np.asarray(got[name]["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=f"{env} {name} {leaf}")
+
+
+IQN_CHILD = r"""
+import json, sys, os
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn.networks.iiqn import iIQN
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+rng = np.random.default_rng(21)
+obs, A, K, N, B = (20, 20, 4), 4, 2, 16, 32
+agent = iIQN(9, obs, A, K, [32, 32, 32, 256], "cnn", 2.5e-4, 0.99, 1, 1, 10**9, 10**9, adam_eps=1e-6, n_quantiles=N)
+b = Batch(rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8), rng.integers(0, A, size=B).astype(np.int32),
+          rng.standard_normal(B).astype(np.float32), rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8), rng.random(B) < 0.1)
+taus = rng.random((K, 3, N, B)).astype(np.float32) * 0.98 + 0.01
+losses = [agent._learn(b, taus=taus).cpu().numpy().astype(np.float64).tolist() for _ in range(4)]
+flat = agent._flat(agent._online)
+probe = {n: v.reshape(K, -1)[:, :: max(1, v[0].size // 71)].astype(np.float64).tolist() for n, v in flat.items()}
+print("RESULT" + json.dumps({"losses": losses, "probe": probe}))
+"""
+
+
+def test_iqn_gemm_kernels_match_the_per_block_kernels():
+    """N = 16 fraction blocks: all three Dense_0 GEMMs of the quantile heads run by default; IDQN_IQN_GEMM=0 sends the same
+    step through the per-block kernels of the plain step.  The forward GEMM keeps that kernel's summation order (first
+    loss bit-identical); the gradients sum in another order and the data gradient moves from the f32 to the split-bf16
+    products: parameters agree to fp32 round-off."""
+    def run(**env):
+        e = dict(os.environ, **env)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + IQN_CHILD], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+
+    a, b = run(), run(IDQN_IQN_GEMM="0")
+    assert a["losses"][0] == b["losses"][0]
+    np.testing.assert_allclose(np.asarray(a["losses"]), np.asarray(b["losses"]), rtol=2e-6, atol=2e-6)
+    for leaf, want in b["probe"].items():
+        np.testing.assert_allclose(np.asarray(a["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=leaf)
