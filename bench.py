@@ -576,6 +576,7 @@ def iiqn_bench(args, json_fd, Batch):
         "iqn dense0 fwd": (3 * gemm, 6, MFMA_BF16_PEAK),
         "iqn dense0 dgrad": (gemm, 6, MFMA_BF16_PEAK),
         "iqn dense0 wgrad": (gemm, 6, MFMA_BF16_PEAK),
+        "iqn dense0 dgrad + wgrad": (2 * gemm, 6, MFMA_BF16_PEAK),
         "iqn embedding x features": (2.0 * 3 * K_HEADS * rows * 64 * F, 1, MFMA_F32_PEAK),
         "iqn embedding backward": (2.0 * 2 * K_HEADS * rows * 64 * F, 1, MFMA_F32_PEAK),
     }

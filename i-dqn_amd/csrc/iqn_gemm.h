@@ -195,11 +195,9 @@ struct IqnD0DgradArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+__device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
     // item = (net, 256-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
-    int item = xcd_contiguous_id();
     const int nbg = a.nb / 8, nfg = (a.F + 255) / 256;
     const int bg = item % nbg;
     item /= nbg;
@@ -327,10 +325,14 @@ struct IqnD0WgradArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(512) void k_iqn_d0_wgrad(IqnD0WgradArgs a) {
+__global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    iqn_d0_dgrad_body<D>(a, xcd_contiguous_id(), ig_lds);
+}
+
+template <int D>
+__device__ __forceinline__ void iqn_d0_wgrad_body(const IqnD0WgradArgs& a, int item, unsigned char* ig_lds) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
-    int item = xcd_contiguous_id();
     const int n_jh = a.J / 256, nfg = (a.F + 255) / 256;
     const int jh = item % n_jh;
     item /= n_jh;
@@ -443,6 +445,27 @@ __global__ __launch_bounds__(512) void k_iqn_d0_wgrad(IqnD0WgradArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) G[(long)(f0 + mfma_row(r, h)) * a.J + (2 * wm + j) * 32] = acc[i][j][r];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void k_iqn_d0_wgrad(IqnD0WgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    iqn_d0_wgrad_body<D>(a, xcd_contiguous_id(), ig_lds);
+}
+
+// Both gradients in ONE launch: they are independent (dx needs W and dh, g needs x and dh), each has 620 equal workgroups at
+// K = 5 -- 2.4 rounds of the 256 CUs, i.e. three rounds with the last one 42 % full; together 4.8 rounds, five.  The first
+// n_dgrad workgroups take data-gradient items, the rest weight-gradient items.
+template <int D>
+__global__ __launch_bounds__(512) void k_iqn_d0_bwd(IqnD0DgradArgs d, int n_dgrad, IqnD0WgradArgs w) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    if ((int)blockIdx.x < n_dgrad) {
+        iqn_d0_dgrad_body<D>(d, xcd_contiguous_id_n(n_dgrad), ig_lds);
+    } else {
+        const int n = (int)gridDim.x - n_dgrad, b = (int)blockIdx.x - n_dgrad;
+        const int q = n >> 3, r = n & 7, x = b & 7;
+        iqn_d0_wgrad_body<D>(w, (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3), ig_lds);
     }
 }
 

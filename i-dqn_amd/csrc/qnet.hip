@@ -1882,6 +1882,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     da.K = K; da.N = w.N; da.J = h->J; da.A = A; da.dh = w.dh; da.grad = h->grad;
     hipLaunchKernelGGL(k_iqn_dh, dim3(h->J / 32, K), dim3(256), 0, q, da);
     tl_mark(h, q, "iqn dh + dense1 grads");
+    bool wgrad_done = false;
     {   // W0 . dh for every fraction block (plain rows)
         DenseDgradArgs dd;
         memset(&dd, 0, sizeof(dd));
@@ -1893,13 +1894,25 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
             IqnD0DgradArgs g;
             g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
             const size_t lds = 2 * (size_t)IG_STAGE;
-            static LdsAttrMark attr;
-            if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3((unsigned)(K * (w.N / 8) * cdiv(h->F, 256))), dim3(512), lds, q, g);
+            const int n_d = K * (w.N / 8) * cdiv(h->F, 256);
+            // the weight-gradient GEMM rides in the same launch (IDQN_IQN_MERGE=0: two launches)
+            static const bool merge = !(getenv("IDQN_IQN_MERGE") && atoi(getenv("IDQN_IQN_MERGE")) == 0);
+            if (merge && w.g1 && w.N % 16 == 0) {
+                IqnD0WgradArgs gw;
+                gw.x = w.xq; gw.dh = w.dh; gw.g[0] = h->grad + h->g_w0_base; gw.g[1] = w.g1; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 2;
+                static LdsAttrMark attr;
+                if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_iqn_d0_bwd<2>, dim3((unsigned)(n_d + K * cdiv(h->F, 256) * gw.KS * (h->J / 256))), dim3(512), lds, q, g, n_d, gw);
+                wgrad_done = true;
+            } else {
+                static LdsAttrMark attr;
+                if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3((unsigned)n_d), dim3(512), lds, q, g);
+            }
         } else {
             hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
         }
-        tl_mark(h, q, "iqn dense0 dgrad");
+        tl_mark(h, q, wgrad_done ? "iqn dense0 dgrad + wgrad" : "iqn dense0 dgrad");
     }
     const int QG = w.QG;
     IqnEmbedBwdArgs eb;
@@ -1933,8 +1946,10 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         const size_t lds = 2 * (size_t)IG_STAGE;
         static LdsAttrMark attr;
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_wgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_iqn_d0_wgrad<2>, dim3((unsigned)(K * cdiv(h->F, 256) * g.KS * (h->J / 256))), dim3(512), lds, q, g);
-        tl_mark(h, q, "iqn dense0 wgrad");
+        if (!wgrad_done) {
+            hipLaunchKernelGGL(k_iqn_d0_wgrad<2>, dim3((unsigned)(K * cdiv(h->F, 256) * g.KS * (h->J / 256))), dim3(512), lds, q, g);
+            tl_mark(h, q, "iqn dense0 wgrad");
+        }
         IqnD0AdamArgs aa;
         aa.g[0] = g.g[0]; aa.g[1] = g.g[1]; aa.theta = h->online; aa.mu = h->mu; aa.nu = h->nu; aa.bcinv = h->bcinv; aa.ad = h->ad;
         aa.P = h->L.head_stride; aa.w_off = h->off_w0; aa.n = n; aa.KS = g.KS;

@@ -10,6 +10,6 @@ import json, sys
 d = json.load(open(f"gpurun_out/ie_{sys.argv[2]}.json"))
 k = {r["launch"]: r["us"] for r in d["kernels"]}
 wg = k.get('dense0 wgrad + adam', 0) + k.get('factor planes', 0) + k.get('iqn dense0 wgrad', 0) + k.get('iqn dense0 adam', 0)
-print(f"{sys.argv[1] or '(defaults)':40s} {d['ms_per_step']:.4f} ms | fwd {k['iqn dense0 fwd']:7.1f} dgrad {k['iqn dense0 dgrad']:7.1f} wgrad+adam {wg:7.1f} embed {k['iqn embedding x features']:6.1f} embed_bwd {k['iqn embedding backward']:6.1f}")
+print(f"{sys.argv[1] or '(defaults)':40s} {d['ms_per_step']:.4f} ms | fwd {k['iqn dense0 fwd']:7.1f} dgrad {k.get('iqn dense0 dgrad', 0) + k.get('iqn dense0 dgrad + wgrad', 0):7.1f} wgrad+adam {wg:7.1f} embed {k['iqn embedding x features']:6.1f} embed_bwd {k['iqn embedding backward']:6.1f}")
 PY
 done
