@@ -218,15 +218,18 @@ struct IqnDhArgs {
     long w1_off, gP, g_b0_off, g_w1_off, g_b1_off;
     int K, N, J, A;
     float* dh;    // [K][N][J][32]
-    float* grad;  // gradient arena
+    float* hpart; // [QG][K][J * A + J + A]: Dense_1 kernel, Dense_0 bias, Dense_1 bias gradient sums over the fractions of group qg
 };
+// grid = (J / 32 chunks, head, fraction group): 80 workgroups walking all N blocks in turn were one latency chain per block
+// (90 us at N = 32); the groups' gradient partials are added in group order by k_iqn_head_grad_sum.
 __global__ __launch_bounds__(256) void k_iqn_dh(IqnDhArgs a) {
     __shared__ float hs[32][33], dqs[32 * 32], w1s[32 * 32];
-    const int jc = blockIdx.x, k = blockIdx.y, t = threadIdx.x, b = t & 31, jj = t >> 5;
+    const int jc = blockIdx.x, k = blockIdx.y, qg = blockIdx.z, t = threadIdx.x, b = t & 31, jj = t >> 5;
+    const int nq = a.N / (int)gridDim.z, q_begin = qg * nq;
     const float* w1 = a.wbase[k] + a.w1_off + (long)jc * 32 * a.A;
     for (int e = t; e < 32 * a.A; e += 256) w1s[e] = w1[e];
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f;
-    for (int q = 0; q < a.N; ++q) {
+    for (int q = q_begin; q < q_begin + nq; ++q) {
         const float* hb = a.hbuf + ((long)(k * a.N + q) * a.J + jc * 32) * 32;
         const float* dq = a.dq + ((long)k * a.N + q) * a.A * 32;
         __syncthreads();  // the previous block's tiles have been consumed
@@ -265,16 +268,33 @@ __global__ __launch_bounds__(256) void k_iqn_dh(IqnDhArgs a) {
             gb1 += s;
         }
     }
-    float* G = a.grad + (long)k * a.gP;
+    const long hn = (long)a.J * a.A + a.J + a.A;
+    float* G = a.hpart + ((long)qg * a.K + k) * hn;  // [J * A | J | A]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (b == 0) G[a.g_b0_off + jc * 32 + jj + 8 * i] = gb0[i];
+        if (b == 0) G[(long)a.J * a.A + jc * 32 + jj + 8 * i] = gb0[i];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int o = t + 256 * m;
-        if (o < 32 * a.A) G[a.g_w1_off + (long)jc * 32 * a.A + o] = gw[m];
+        if (o < 32 * a.A) G[(long)jc * 32 * a.A + o] = gw[m];
     }
-    if (jc == 0 && t < a.A) G[a.g_b1_off + t] = gb1;
+    if (jc == 0 && t < a.A) G[(long)a.J * a.A + a.J + t] = gb1;
+}
+
+struct IqnHeadGradSumArgs {
+    const float* hpart;  // [QG][K][J * A + J + A]
+    float* grad;
+    long gP, g_b0_off, g_w1_off, g_b1_off;
+    int K, J, A, QG;
+};
+__global__ __launch_bounds__(256) void k_iqn_head_grad_sum(IqnHeadGradSumArgs a) {
+    const int k = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x, wn = (long)a.J * a.A, hn = wn + a.J + a.A;
+    if (e >= hn) return;
+    float s = a.hpart[(long)k * hn + e];
+    for (int g = 1; g < a.QG; ++g) s += a.hpart[((long)g * a.K + k) * hn + e];
+    float* G = a.grad + (long)k * a.gP;
+    G[e < wn ? a.g_w1_off + e : (e < wn + a.J ? a.g_b0_off + (e - wn) : a.g_b1_off + (e - wn - a.J))] = s;
 }
 
 // Backward of the Hadamard product and of the embedding, one wave per (head, 32-feature tile), fractions in order:

@@ -222,6 +222,8 @@ struct IqnWs {
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
     int QG = 1;              // fraction groups of the embedding backward (partials dpsi / gpart)
     float* gpart = nullptr;  // [QG][K][65][F]
+    int HG = 1;              // fraction groups of k_iqn_dh (partials hpart)
+    float* hpart = nullptr;  // [HG][K][J * A + J + A]
     float* g1 = nullptr;  // second partial of the Dense_0 weight gradient [K][F * J] (iqn_gemm.h), N a multiple of 16 only
     long off_we = 0, off_be = 0;
 };
@@ -579,6 +581,9 @@ int cnn_setup(idqn_handle_s* h) {
         while (w.QG > 1 && w.N % w.QG != 0) --w.QG;
         if ((rc = alloc_zero(&w.dpsi, (long)w.QG * K * h->F * 32, h, "iqn_dpsi"))) return rc;
         if ((rc = alloc_zero(&w.gpart, (long)w.QG * K * 65 * h->F, h, "iqn_gpart"))) return rc;
+        w.HG = getenv("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(getenv("IDQN_IQN_DH_GROUPS"))) : 8;
+        while (w.HG > 1 && w.N % w.HG != 0) --w.HG;
+        if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
@@ -1877,11 +1882,18 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     tl_mark(h, q, "iqn quantile huber loss");
     const long w0n = h->g_w0_end - h->g_w0_begin;
     IqnDhArgs da;
-    da.hbuf = w.hbuf; da.dq = w.dq; da.wbase = w.wbase_v; da.w1_off = h->off_w1; da.gP = h->gP;
-    da.g_b0_off = h->off_b0 - w0n; da.g_w1_off = h->off_w1 - w0n; da.g_b1_off = h->off_b1 - w0n;
-    da.K = K; da.N = w.N; da.J = h->J; da.A = A; da.dh = w.dh; da.grad = h->grad;
-    hipLaunchKernelGGL(k_iqn_dh, dim3(h->J / 32, K), dim3(256), 0, q, da);
+    da.hbuf = w.hbuf; da.dq = w.dq; da.wbase = w.wbase_v; da.w1_off = h->off_w1;
+    da.K = K; da.N = w.N; da.J = h->J; da.A = A; da.dh = w.dh; da.hpart = w.hpart;
+    hipLaunchKernelGGL(k_iqn_dh, dim3(h->J / 32, K, w.HG), dim3(256), 0, q, da);
     tl_mark(h, q, "iqn dh + dense1 grads");
+    {
+        IqnHeadGradSumArgs hs;
+        hs.hpart = w.hpart; hs.grad = h->grad; hs.gP = h->gP;
+        hs.g_b0_off = h->off_b0 - w0n; hs.g_w1_off = h->off_w1 - w0n; hs.g_b1_off = h->off_b1 - w0n;
+        hs.K = K; hs.J = h->J; hs.A = A; hs.QG = w.HG;
+        hipLaunchKernelGGL(k_iqn_head_grad_sum, dim3((unsigned)cdiv((long)h->J * A + h->J + A, 256), K), dim3(256), 0, q, hs);
+        tl_mark(h, q, "iqn head grads (group sums)");
+    }
     bool wgrad_done = false;
     {   // W0 . dh for every fraction block (plain rows)
         DenseDgradArgs dd;
