@@ -23,14 +23,18 @@ constexpr int IQN_EMBED = 64;  // cos features per fraction (IQN paper, section 
 struct IqnCosArgs {
     const float* tau;
     float* cosb;
+    float* cost;  // the same block transposed, cost[slot][b][i - 1] (the embedding backward reads it as an MFMA A operand), or nullptr
     int K, N, B;
 };
 __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
     const int slot = blockIdx.x, q = slot % a.N, v = slot / a.N, type = v / a.K, k = v - type * a.K;
     const int b = threadIdx.x & 31;
     const double tau = b < a.B ? (double)a.tau[(((long)k * 3 + type) * a.N + q) * a.B + b] : 0.5;
-    for (int i = threadIdx.x >> 5; i < IQN_EMBED; i += 8)
-        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = (float)cospi((double)(i + 1) * tau);
+    for (int i = threadIdx.x >> 5; i < IQN_EMBED; i += 8) {
+        const float c = (float)cospi((double)(i + 1) * tau);
+        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = c;
+        if (a.cost) a.cost[((long)slot * 32 + b) * IQN_EMBED + i] = c;
+    }
 }
 
 // x = psi * relu(We^T cos + be): one wave = one tile of 32 features x 32 samples of one (virtual net, fraction) block.
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256) void k_iqn_head_grad_sum(IqnHeadGradSumArgs a)
 //   dWe[i][f] += sum_b cos[i][b] dphi[f][b]  (MFMA over the 32 samples, dphi through a per-wave LDS tile);  dbe[f] += sum_b dphi.
 struct IqnEmbedBwdArgs {
     const float* cosb;  // [V * N][64][32] (online virtual nets = the first K * N slots)
+    const float* cost;  // [V * N][32][64] the same, transposed
     const float* const* wbase;
     const float* psi;   // [2K][F * 32]
     const float* dx;    // [K][N][F][32]
@@ -310,15 +315,19 @@ struct IqnEmbedBwdArgs {
     long we_off, be_off;
     int K, N, F;
 };
-__global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
+    // grid = (f tiles / 4, head, fraction group): the N fractions of a tile are dealt to gridDim.z workgroups (one wave
+    // walking all 32 of them was a single chain of dependent load / MFMA rounds: 0.35 ms at 1.2 waves per SIMD).
+    // The four waves of a workgroup (four feature tiles) share the fraction's cos block: it is copied to LDS once per
+    // fraction by LDS-DMA, in both orientations ([i][b]: B operand of the recomputed embedding; [b][i]: A operand of
+    // dL/dWe, conflict-free either way), one fraction ahead, like the next fraction's dx rows (registers).
     __shared__ float tile[4][32][33];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    // grid = (f tiles / 4, head, fraction group): the N fractions of a tile are dealt to gridDim.z workgroups -- one wave
-    // walking all 32 of them was a single chain of dependent load / MFMA rounds (0.35 ms at 1.2 waves per SIMD)
-    const int ft = blockIdx.x * 4 + wave, k = blockIdx.y, qg = blockIdx.z;
+    __shared__ __attribute__((aligned(1024))) float cs[2][2][IQN_EMBED * 32];  // [buffer][cos | cos^T]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int k = blockIdx.y, qg = blockIdx.z;
     const int nq = a.N / (int)gridDim.z, q_begin = qg * nq;
-    const bool live = ft < a.F / 32;  // (idle waves still join no barrier: the LDS tile is per wave)
-    if (!live) return;
+    const bool live = (int)blockIdx.x * 4 + wave < a.F / 32;  // idle waves of the last workgroup still copy and join the barriers
+    const int ft = min((int)blockIdx.x * 4 + wave, a.F / 32 - 1);
     const int f0 = ft * 32;
     const float* P = a.wbase[k];
     const float* We = P + a.we_off + f0 + r;
@@ -338,39 +347,64 @@ __global__ __launch_bounds__(256) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
     f32x16 gw0, gw1;  // dWe rows i = 0..31 / 32..63 x the tile's 32 features
 #pragma unroll
     for (int i = 0; i < 16; ++i) { gw0[i] = 0.f; gw1[i] = 0.f; }
-    for (int q = q_begin; q < q_begin + nq; ++q) {
-        const int slot = k * a.N + q;
-        const float* C = a.cosb + (long)slot * IQN_EMBED * 32;
-        float cb[32];
+    const unsigned lds_cs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&cs[0][0][0];
+    // this wave's quarter of the 16 KB [cos | cos^T] of fraction q -> buffer `buf` (four 1 KB pieces)
+    auto stage = [&](int q, int buf) {
+        const long slot = (long)k * a.N + q;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) cb[s] = C[(2 * s + h) * 32 + r];
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[s], acc);
-        const float* DX = a.dx + (long)slot * a.F * 32;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int fl = mfma_row(i, h);
-            const float e = acc[i] + be[i];
-            const float dx = DX[(long)(f0 + fl) * 32 + r];
-            dps[i] = fmaf(dx, fmaxf(e, 0.f), dps[i]);
-            const float dphi = e > 0.f ? dx * ps[i] : 0.f;
-            dbe[i] += dphi;
-            tile[wave][fl][r] = dphi;  // [feature][sample]
+        for (int c = 0; c < 4; ++c) {
+            const int piece = wave * 4 + c, which = piece >> 3, off = (piece & 7) * 256;
+            const float* src = (which ? a.cost : a.cosb) + slot * (IQN_EMBED * 32) + off;
+            dma16((unsigned)lane * 16, (unsigned long)src, lds_cs + (unsigned)(((buf * 2 + which) * IQN_EMBED * 32 + off) * 4));
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // dWe[i][f] += sum_b cos[i][b] * dphi[f][b]: A = cos (row i = r (+32), k = sample 2 s + h), B = dphi (k = sample, col f = r)
+    };
+    float dxr[2][16];
+    auto fetch_dx = [&](int q, int st) {
+        const float* DX = a.dx + ((long)k * a.N + q) * a.F * 32;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float bv = tile[wave][r][2 * s + h];
-            gw0 = mfma32(C[r * 32 + 2 * s + h], bv, gw0);
-            gw1 = mfma32(C[(32 + r) * 32 + 2 * s + h], bv, gw1);
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 16; ++i) dxr[st][i] = DX[(long)(f0 + mfma_row(i, h)) * 32 + r];
+    };
+    stage(q_begin, 0);
+    fetch_dx(q_begin, 0);
+#define EB_STEP(qi, st)                                                                                  \
+    {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this fraction's copies and dx rows */         \
+        __builtin_amdgcn_s_barrier();                    /* ... of every wave; buffer st ^ 1 is free */   \
+        if ((qi) + 1 < nq) {                                                                             \
+            stage(q_begin + (qi) + 1, (st) ^ 1);                                                         \
+            fetch_dx(q_begin + (qi) + 1, (st) ^ 1);                                                      \
+        }                                                                                                \
+        const float* Cb = &cs[st][0][0];                                                                 \
+        const float* Ct = &cs[st][1][0];                                                                 \
+        f32x16 acc;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                     \
+        _Pragma("unroll") for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], Cb[(2 * s + h) * 32 + r], acc); \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                 \
+            const int fl = mfma_row(i, h);                                                               \
+            const float e = acc[i] + be[i];                                                              \
+            const float dx = dxr[st][i];                                                                 \
+            dps[i] = fmaf(dx, fmaxf(e, 0.f), dps[i]);                                                    \
+            const float dphi = e > 0.f ? dx * ps[i] : 0.f;                                               \
+            dbe[i] += dphi;                                                                              \
+            tile[wave][fl][r] = dphi; /* [feature][sample] */                                            \
+        }                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        /* dWe[i][f] += sum_b cos[i][b] * dphi[f][b]: A = cos^T (k = sample 2 s + h, row i = r (+32)), B = dphi (col f = r) */ \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                                 \
+            const float bv = tile[wave][r][2 * s + h];                                                   \
+            gw0 = mfma32(Ct[(2 * s + h) * IQN_EMBED + r], bv, gw0);                                      \
+            gw1 = mfma32(Ct[(2 * s + h) * IQN_EMBED + 32 + r], bv, gw1);                                 \
+        }                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
     }
+    for (int qi = 0; qi < nq; qi += 2) {
+        EB_STEP(qi, 0)
+        if (qi + 1 < nq) EB_STEP(qi + 1, 1)
+    }
+#undef EB_STEP
+    if (!live) return;
     float* DP = a.dpsi + ((long)qg * a.K + k) * a.F * 32;
     float* G = a.gpart + ((long)qg * a.K + k) * 65 * a.F;
 #pragma unroll

@@ -218,6 +218,7 @@ struct WgradPlan { int n_items = 0, n_chunks = 0, chunk_major = 0, MT = 0, PG = 
 struct IqnWs {
     int N = 0, V = 0, NS = 2;
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
+    float* cost = nullptr;  // cosb transposed per slot [V * N][32][64]
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
     int QG = 1;              // fraction groups of the embedding backward (partials dpsi / gpart)
@@ -568,6 +569,7 @@ int cnn_setup(idqn_handle_s* h) {
         }
         IDQN_HIP_CHECK(hipMemcpy(w.wbase_v, wv.data(), sizeof(float*) * w.V, hipMemcpyHostToDevice));
         if ((rc = alloc_zero(&w.cosb, VN * IQN_EMBED * 32, h, "iqn_cos"))) return rc;
+        if ((rc = alloc_zero(&w.cost, VN * IQN_EMBED * 32, h, "iqn_cost"))) return rc;
         if ((rc = alloc_zero(&w.xq, VN * h->F * 32, h, "iqn_x"))) return rc;
         if ((rc = alloc_zero(&w.part, VN * w.NS * h->J * 32, h, "iqn_part"))) return rc;
         if ((rc = alloc_zero(&w.hbuf, VN * h->J * 32, h, "iqn_h"))) return rc;
@@ -1803,7 +1805,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
                       int B, hipStream_t q) {
     IqnWs& w = h->iqn;
     IqnCosArgs ca;
-    ca.tau = tau; ca.cosb = w.cosb; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
     IqnEmbedArgs ea;
@@ -1928,7 +1930,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     }
     const int QG = w.QG;
     IqnEmbedBwdArgs eb;
-    eb.cosb = w.cosb; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
+    eb.cosb = w.cosb; eb.cost = w.cost; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
     eb.we_off = w.off_we; eb.be_off = w.off_be;
     eb.K = K; eb.N = w.N; eb.F = h->F;
     hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), 0, q, eb);
