@@ -24,16 +24,31 @@ struct IqnCosArgs {
     const float* tau;
     float* cosb;
     float* cost;  // the same block transposed, cost[slot][b][i - 1] (the embedding backward reads it as an MFMA A operand), or nullptr
+    unsigned short* cosp;  // the block as MFMA B fragments in three exact bf16 planes: cosp[slot][k-step t][plane][lane (b, h)][8]
+                           // = cos feature i = 16 t + 8 h + jj of sample b (k_iqn_embed3), or nullptr
     int K, N, B;
 };
 __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
     const int slot = blockIdx.x, q = slot % a.N, v = slot / a.N, type = v / a.K, k = v - type * a.K;
     const int b = threadIdx.x & 31;
     const double tau = b < a.B ? (double)a.tau[(((long)k * 3 + type) * a.N + q) * a.B + b] : 0.5;
-    for (int i = threadIdx.x >> 5; i < IQN_EMBED; i += 8) {
-        const float c = (float)cospi((double)(i + 1) * tau);
-        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = c;
-        if (a.cost) a.cost[((long)slot * 32 + b) * IQN_EMBED + i] = c;
+    const int g = threadIdx.x >> 5;  // this thread: features i = 8 g .. 8 g + 7 = k-step g >> 1, half g & 1
+    float c[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int i = 8 * g + jj;
+        c[jj] = (float)cospi((double)(i + 1) * tau);
+        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = c[jj];
+        if (a.cost) a.cost[((long)slot * 32 + b) * IQN_EMBED + i] = c[jj];
+    }
+    if (a.cosp) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) split3_pk(c[2 * m], c[2 * m + 1], p0[m], p1[m], p2[m]);
+        unsigned short* O = a.cosp + (((long)slot * 4 + (g >> 1)) * 3) * 512 + ((g & 1) * 32 + b) * 8;
+        *reinterpret_cast<u32x4*>(O) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+        *reinterpret_cast<u32x4*>(O + 512) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+        *reinterpret_cast<u32x4*>(O + 1024) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
     }
 }
 
@@ -91,6 +106,99 @@ __global__ __launch_bounds__(256) void k_iqn_embed(IqnEmbedArgs a) {
         if (q + 1 < nq) IE_STEP(q + 1, 1)
     }
 #undef IE_STEP
+}
+
+// ---- the embedding on the bf16 matrix cores (f32 accuracy: three exact planes, six products -- convp.h) -------------------
+// k_iqn_embed runs 32 f32 MFMAs (2048 cycles) per 32 x 32 tile: 0.20 ms for the K = 5 step, MFMA-bound.  Both operands are
+// small and shared by many tiles, so they are split ONCE per step into fragment-ordered planes (k_iqn_cos writes the cos
+// blocks, k_iqn_we_pack the embedding kernels) and the tile costs 24 bf16 MFMAs (768 cycles) and no split work.
+struct IqnWePackArgs {
+    const float* const* wbase;  // [n_nets]
+    unsigned short* wep;        // [n_nets][F / 32][k-step t][plane][lane (f, h)][8] = We[16 t + 8 h + jj][32 ft + f]
+    long we_off;
+    int F;
+};
+__global__ __launch_bounds__(256) void k_iqn_we_pack(IqnWePackArgs a) {
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
+    const int ft = blockIdx.x, net = blockIdx.y;
+    const float* We = a.wbase[net] + a.we_off + (long)(16 * t + 8 * h) * a.F + ft * 32 + bl;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) v[jj] = We[(long)jj * a.F];
+    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) split3_pk(v[2 * m], v[2 * m + 1], p0[m], p1[m], p2[m]);
+    unsigned short* O = a.wep + ((((long)net * (a.F / 32) + ft) * 4 + t) * 3) * 512 + lane * 8;
+    *reinterpret_cast<u32x4*>(O) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+    *reinterpret_cast<u32x4*>(O + 512) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(O + 1024) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+}
+
+struct IqnEmbed3Args {
+    const unsigned short* cosp;  // [V * N][4][3][64][8]
+    const unsigned short* wep;   // [n_packed][F / 32][4][3][64][8]
+    const float* const* wbase;   // [V] (bias)
+    const float* psi;
+    float* x;
+    long be_off;
+    int K, N, F, n_packed;       // virtual net v reads packed net v < n_packed ? v : v - K  (the two target sets share one)
+};
+__global__ __launch_bounds__(256) void k_iqn_embed3(IqnEmbed3Args a) {
+    // grid and roles as k_iqn_embed: a wave keeps its tile's We fragments (48 registers), psi tile and bias for the fractions of
+    // its group and requests the cos fragments of fraction q + 1 before the products of fraction q
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int ft = blockIdx.x * 4 + wave;
+    if (ft >= a.F / 32) return;
+    const int v = blockIdx.y, type = v / a.K, k = v - type * a.K;
+    const int nq = a.N / (int)gridDim.z, q0 = blockIdx.z * nq;
+    const int f0 = ft * 32, pv = v < a.n_packed ? v : v - a.K;
+    const unsigned short* Wf = a.wep + (((long)pv * (a.F / 32) + ft) * 12) * 512 + lane * 8;
+    bf16x8 wf[4][3], cf[2][4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(Wf + (t * 3 + p) * 512);
+    const unsigned short* C0 = a.cosp + ((long)(v * a.N + q0) * 12) * 512 + lane * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cf[0][t][p] = *reinterpret_cast<const bf16x8*>(C0 + (t * 3 + p) * 512);
+    const float* P = a.wbase[v];
+    const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
+    float be[16], ps[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = f0 + mfma_row(i, h);
+        be[i] = P[a.be_off + f];
+        ps[i] = psi[(long)f * 32 + r];
+    }
+#define IE3_STEP(q, st)                                                                             \
+    {                                                                                               \
+        if ((q) + 1 < nq) {                                                                         \
+            const unsigned short* Cn = C0 + (long)((q) + 1) * 12 * 512;                             \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                           \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p)                                       \
+                    cf[(st) ^ 1][t][p] = *reinterpret_cast<const bf16x8*>(Cn + (t * 3 + p) * 512);  \
+        }                                                                                           \
+        f32x16 acc;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
+            acc = mfma_bf16(wf[t][2], cf[st][t][0], acc);                                           \
+            acc = mfma_bf16(wf[t][0], cf[st][t][2], acc);                                           \
+            acc = mfma_bf16(wf[t][1], cf[st][t][1], acc);                                           \
+            acc = mfma_bf16(wf[t][1], cf[st][t][0], acc);                                           \
+            acc = mfma_bf16(wf[t][0], cf[st][t][1], acc);                                           \
+            acc = mfma_bf16(wf[t][0], cf[st][t][0], acc);                                           \
+        }                                                                                           \
+        float* X = a.x + (long)(v * a.N + q0 + (q)) * a.F * 32;                                     \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                              \
+            __builtin_nontemporal_store(fmaxf(acc[i] + be[i], 0.f) * ps[i], X + (long)(f0 + mfma_row(i, h)) * 32 + r); \
+    }
+    for (int q = 0; q < nq; q += 2) {
+        IE3_STEP(q, 0)
+        if (q + 1 < nq) IE3_STEP(q + 1, 1)
+    }
+#undef IE3_STEP
 }
 
 // Z[slot][action][b] = b1[action] + the Dense_1 chunk partials in chunk order: one workgroup per (virtual net, fraction).

@@ -219,6 +219,7 @@ struct IqnWs {
     int N = 0, V = 0, NS = 2;
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
     float* cost = nullptr;  // cosb transposed per slot [V * N][32][64]
+    unsigned short *cosp = nullptr, *wep = nullptr;  // bf16 fragment planes of the cos blocks [V * N][12][512] and of We [2K][F / 32][12][512]
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
     int QG = 1;              // fraction groups of the embedding backward (partials dpsi / gpart)
@@ -570,6 +571,13 @@ int cnn_setup(idqn_handle_s* h) {
         IDQN_HIP_CHECK(hipMemcpy(w.wbase_v, wv.data(), sizeof(float*) * w.V, hipMemcpyHostToDevice));
         if ((rc = alloc_zero(&w.cosb, VN * IQN_EMBED * 32, h, "iqn_cos"))) return rc;
         if ((rc = alloc_zero(&w.cost, VN * IQN_EMBED * 32, h, "iqn_cost"))) return rc;
+        {
+            float* tmp = nullptr;  // (alloc_zero counts floats: 12 x 512 bf16 = 3072 floats per block)
+            if ((rc = alloc_zero(&tmp, VN * 3072, h, "iqn_cosp"))) return rc;
+            w.cosp = (unsigned short*)tmp;
+            if ((rc = alloc_zero(&tmp, 2L * K * (h->F / 32) * 3072, h, "iqn_wep"))) return rc;
+            w.wep = (unsigned short*)tmp;
+        }
         if ((rc = alloc_zero(&w.xq, VN * h->F * 32, h, "iqn_x"))) return rc;
         if ((rc = alloc_zero(&w.part, VN * w.NS * h->J * 32, h, "iqn_part"))) return rc;
         if ((rc = alloc_zero(&w.hbuf, VN * h->J * 32, h, "iqn_h"))) return rc;
@@ -1805,7 +1813,9 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
                       int B, hipStream_t q) {
     IqnWs& w = h->iqn;
     IqnCosArgs ca;
-    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
+    static const bool embed3 = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
+    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
     IqnEmbedArgs ea;
@@ -1815,7 +1825,20 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
         static const int qenv = getenv("IDQN_IQN_EMBED_Q") ? atoi(getenv("IDQN_IQN_EMBED_Q")) : 0;
         int per = qenv > 0 ? qenv : 8;
         while (per > 1 && (w.N % per != 0)) --per;
-        hipLaunchKernelGGL(k_iqn_embed, dim3((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per)), dim3(256), 0, q, ea);
+        const dim3 grid((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per));
+        if (embed3) {
+            const int n_packed = std::min(V, 2 * K_for_index);  // virtual nets 2K .. 3K - 1 are the target nets again
+            IqnWePackArgs pa;
+            pa.wbase = wbase_v; pa.wep = w.wep; pa.we_off = w.off_we; pa.F = h->F;
+            hipLaunchKernelGGL(k_iqn_we_pack, dim3((unsigned)(h->F / 32), (unsigned)n_packed), dim3(256), 0, q, pa);
+            tl_mark(h, q, "iqn embedding kernel planes");
+            IqnEmbed3Args e3;
+            e3.cosp = w.cosp; e3.wep = w.wep; e3.wbase = wbase_v; e3.psi = psi; e3.x = w.xq; e3.be_off = w.off_be;
+            e3.K = K_for_index; e3.N = w.N; e3.F = h->F; e3.n_packed = n_packed;
+            hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
+        } else {
+            hipLaunchKernelGGL(k_iqn_embed, grid, dim3(256), 0, q, ea);
+        }
     }
     tl_mark(h, q, "iqn embedding x features");
     DenseFwdArgs d;
