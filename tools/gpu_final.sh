@@ -1,6 +1,6 @@
 # End-of-round measurement set (one GPU call): default bench line, A=18 repeat, rocprofv3 kernel stats, PMC passes,
 # one-rank RCCL rehearsal of both data-parallel modes, head-parallel line, emulated-rank lines, the i-IQN line + its kernel
-# stats, trainer loop.  Outputs under gpurun_out/final/.
+# stats, trainer loop, MLP step.  Outputs under gpurun_out/final/.
 mkdir -p gpurun_out/final && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/final
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
@@ -16,7 +16,8 @@ timeout -k 10 400 python bench.py --algo iiqn --steps 30 --warmup 5 --repeats 3 
 rm -rf $O/prof_iiqn; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_iiqn -- python bench.py --algo iiqn --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/prof_iiqn.log 2>&1
 cp $O/prof_iiqn/*/*_kernel_stats.csv $O/iiqn_kernel_stats.csv && echo "iiqn kernel stats ok"
 IDQN_OVERLAP=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_overlap.json 2> $O/bench_overlap.err; echo "overlap rc=$?"
-timeout -k 10 300 python tools/bench_loop.py > $O/loop_all.log 2>&1; grep -E "us per|env steps" $O/loop_all.log > $O/loop.txt; cat $O/loop.txt
+timeout -k 10 300 python tools/bench_loop.py > $O/loop_all.log 2>&1; grep -E "us per|env steps" $O/loop_all.log > $O/loop.txt
+timeout -k 10 200 python tools/bench_fc.py 2>/dev/null | grep -E "^fc " >> $O/loop.txt; cat $O/loop.txt
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/final/bench.json"))
