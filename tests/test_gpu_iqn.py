@@ -100,3 +100,27 @@ def test_iqn_learns_a_known_target():
     for _ in range(60):
         last = agent._learn(batch).cpu().numpy()
     assert (last < 0.2 * first).all(), (first, last)
+
+
+def test_iqn_step_is_reproducible_bit_for_bit():
+    """The tiled GEMMs cut the sample range of the weight gradient in two and the embedding / dL/dh kernels deal the
+    fractions to several workgroups: every such partial is added in a fixed order (no atomics), so two runs of the same
+    steps from the same state end with identical bits -- at N = 16, where every GEMM kernel and every grouped kernel runs."""
+    from slimdqn.networks.iiqn import iIQN
+
+    rng = np.random.default_rng(3)
+    obs, A, K, N, B = (20, 20, 4), 4, 2, 16, 32
+    s = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
+    s2 = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
+    batch = Batch(s, rng.integers(0, A, size=B).astype(np.int32), rng.standard_normal(B).astype(np.float32), s2, rng.random(B) < 0.1)
+    taus = [rng.random((K, 3, N, B)).astype(np.float32) * 0.98 + 0.01 for _ in range(3)]
+    runs = []
+    for _ in range(2):
+        agent = iIQN(11, obs, A, K, [32, 64, 32, 256], "cnn", 2.5e-4, 0.99, 1, 1, 10**9, 10**9, adam_eps=1e-6, n_quantiles=N)
+        losses = [agent._learn(batch, taus=t).cpu().numpy().copy() for t in taus]
+        runs.append((losses, agent._flat(agent._online), agent._flat(agent._mu)))
+    for la, lb in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(la, lb)
+    for leaf in runs[0][1]:
+        assert np.array_equal(runs[0][1][leaf], runs[1][1][leaf]), leaf
+        assert np.array_equal(runs[0][2][leaf], runs[1][2][leaf]), leaf
