@@ -594,7 +594,7 @@ def iiqn_bench(args, json_fd, Batch):
                 "frac": ach / (peak / 1e12), "traffic": None, "launch_ms": dom["us"] * 1e-3,
                 "algorithmic_flops": f32eq, "issued_flops": f32eq * mult,
                 "note": ("f32-accurate contraction as six bf16 products per f32 product: issued bf16 FLOPs (6 x algorithmic) against "
-                         "the dense bf16 MFMA peak at 2.4 GHz; the chip holds 1.5-1.7 GHz under this load" if mult == 6 else
+                         "the dense bf16 MFMA peak at 2.4 GHz; measured in-kernel clock of this launch 2.06 GHz (tools/probes/iqn_clock.py)" if mult == 6 else
                          "f32 MFMA FLOPs against the f32 MFMA peak")}
     out = {"metric": "i-IQN grad-steps/sec, Nature-CNN K=5 batch=32, 32 quantile samples", "value": steps / elapsed,
            "unit": "grad-steps/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 10), "ms_per_step": elapsed / steps * 1e3,

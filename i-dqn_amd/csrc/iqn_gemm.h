@@ -25,6 +25,8 @@ struct IqnD0FwdArgs {
     float* part;                // [V][nb][NS][J][32]
     long w_off;
     int V, nb, NS, F, J;
+    long long* clk;  // diagnostic (IDQN_IQN_CLOCK=1) or nullptr: per workgroup {s_memtime, s_memrealtime} before and after the
+                     // k loop -- the in-kernel clock is their ratio x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
 };
 
 constexpr int IG_TILE = 3 * 1024;        // one operand tile of a k-step: 3 planes x 64 lanes x 16 B
@@ -88,6 +90,8 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
     unsigned char* const my_x = ig_lds + (8 + wave) * IG_TILE + lane * 16;
     const unsigned char* const rd_w = ig_lds + (4 * wn) * IG_TILE + lane * 16;
     const unsigned char* const rd_x = ig_lds + (8 + 2 * wm) * IG_TILE + lane * 16;
+    long long c_t0 = 0, c_r0 = 0;
+    if (a.clk) { c_t0 = __builtin_amdgcn_s_memtime(); c_r0 = __builtin_amdgcn_s_memrealtime(); }
     ig_park(wr[0], my_w);
     ig_park(xr[0], my_x);
     {   // slot 0 is free again: k-step D
@@ -165,6 +169,10 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
                 }
             }
         }
+    }
+    if (a.clk && threadIdx.x == 0) {
+        long long* c = a.clk + (long)blockIdx.x * 4;
+        c[0] = c_t0; c[1] = c_r0; c[2] = __builtin_amdgcn_s_memtime(); c[3] = __builtin_amdgcn_s_memrealtime();
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -226,6 +226,7 @@ struct IqnWs {
     float* gpart = nullptr;  // [QG][K][65][F]
     int HG = 1;              // fraction groups of k_iqn_dh (partials hpart)
     float* hpart = nullptr;  // [HG][K][J * A + J + A]
+    float* clk = nullptr;  // IDQN_IQN_CLOCK=1: clock stamps of the forward GEMM's workgroups [<= 1024][4] int64 (debug buffer "iqn_clk")
     float* g1 = nullptr;  // second partial of the Dense_0 weight gradient [K][F * J] (iqn_gemm.h), N a multiple of 16 only
     long off_we = 0, off_be = 0;
 };
@@ -594,6 +595,7 @@ int cnn_setup(idqn_handle_s* h) {
         w.HG = getenv("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(getenv("IDQN_IQN_DH_GROUPS"))) : 8;
         while (w.HG > 1 && w.N % w.HG != 0) --w.HG;
         if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
+        if (getenv("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, 1024 * 4 * 2, h, "iqn_clk"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
@@ -1851,7 +1853,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;
         g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
-        g.V = V; g.nb = w.N; g.NS = w.NS; g.F = h->F; g.J = h->J;
+        g.V = V; g.nb = w.N; g.NS = w.NS; g.F = h->F; g.J = h->J; g.clk = (long long*)w.clk;
         const size_t lds = 2 * (size_t)IG_STAGE;
         const dim3 grid((unsigned)(V * (w.N / 8) * w.NS * (h->J / 256)));
         static LdsAttrMark attr;

@@ -1,0 +1,34 @@
+"""In-kernel clock of the i-IQN Dense_0 forward GEMM (diagnostic build path: IDQN_IQN_CLOCK=1 makes every workgroup stamp
+s_memtime / s_memrealtime around its k loop).  ~2 s of back-to-back steps on random data first (MI355X_MICROARCH.md, DVFS
+give-back item 6), then the median over workgroups of  d(s_memtime) / d(s_memrealtime) x 100 MHz."""
+import ctypes as C, os, sys, time
+os.environ["IDQN_IQN_CLOCK"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn import _hip
+from slimdqn.networks.iiqn import iIQN
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+rng = np.random.default_rng(0)
+agent = iIQN(0, (84, 84, 4), 6, 5, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4, n_quantiles=32)
+b = Batch(torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+          torch.from_numpy(rng.integers(0, 6, 32).astype(np.int32)).cuda(),
+          torch.from_numpy(rng.standard_normal(32).astype(np.float32)).cuda(),
+          torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+          torch.from_numpy((rng.random(32) < 0.05).astype(np.uint8)).cuda())
+t0 = time.perf_counter()
+n = 0
+while time.perf_counter() - t0 < 2.5:
+    for _ in range(50): agent._learn(b)
+    torch.cuda.synchronize(); n += 50
+p, nbytes = C.c_void_p(), C.c_int64()
+_hip.check(_hip.lib().idqn_debug_buffer(agent._handle, b"iqn_clk", C.byref(p), C.byref(nbytes)), "iqn_clk")
+out = torch.empty(nbytes.value // 8, dtype=torch.int64, device="cuda")
+C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(nbytes.value), 3)
+c = out.cpu().numpy().reshape(-1, 4)[:240]
+dt, dr = (c[:, 2] - c[:, 0]).astype(np.float64), (c[:, 3] - c[:, 1]).astype(np.float64)
+ok = dr > 0
+ghz = dt[ok] / dr[ok] * 0.1
+print(f"{n} steps; forward GEMM k loop: {np.median(dr[ok]) / 100:.1f} us per workgroup (median), in-kernel clock "
+      f"median {np.median(ghz):.3f} GHz  p10 {np.percentile(ghz, 10):.3f}  p90 {np.percentile(ghz, 90):.3f}  ({ok.sum()} workgroups)")
