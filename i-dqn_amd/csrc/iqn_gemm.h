@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
     unsigned char* const my_x = ig_lds + (8 + wave) * IG_TILE + lane * 16;
     const unsigned char* const rd_w = ig_lds + (4 * wn) * IG_TILE + lane * 16;
     const unsigned char* const rd_x = ig_lds + (8 + 2 * wm) * IG_TILE + lane * 16;
-    long long c_t0 = 0, c_r0 = 0;
+    long long c_t0 = 0, c_r0 = 0, d_lgkm = 0, d_bar = 0;
     if (a.clk) { c_t0 = __builtin_amdgcn_s_memtime(); c_r0 = __builtin_amdgcn_s_memrealtime(); }
     ig_park(wr[0], my_w);
     ig_park(xr[0], my_x);
@@ -108,6 +108,14 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
             const int c = c0 + u;
             if (c < NC) {  // (uniform over the workgroup)
                 const int nslot = (u + 1) % D, stg = (u & 1) * IG_STAGE, nstg = ((u + 1) & 1) * IG_STAGE;
+                if (a.clk) {
+                    const long long b0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const long long b1 = __builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_s_barrier();
+                    const long long b2 = __builtin_amdgcn_s_memtime();
+                    d_lgkm += b1 - b0; d_bar += b2 - b1;
+                } else
                 lds_barrier();
                 bf16x8 xf[2][3];
 #pragma unroll
@@ -173,6 +181,10 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
     if (a.clk && threadIdx.x == 0) {
         long long* c = a.clk + (long)blockIdx.x * 4;
         c[0] = c_t0; c[1] = c_r0; c[2] = __builtin_amdgcn_s_memtime(); c[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (a.clk && lane == 0) {  // per wave: cycles waiting for its own LDS writes / in the barrier
+        long long* c = a.clk + 1024 + ((long)blockIdx.x * 8 + wave) * 2;
+        c[0] = d_lgkm; c[1] = d_bar;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -26,9 +26,15 @@ p, nbytes = C.c_void_p(), C.c_int64()
 _hip.check(_hip.lib().idqn_debug_buffer(agent._handle, b"iqn_clk", C.byref(p), C.byref(nbytes)), "iqn_clk")
 out = torch.empty(nbytes.value // 8, dtype=torch.int64, device="cuda")
 C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(nbytes.value), 3)
-c = out.cpu().numpy().reshape(-1, 4)[:240]
+raw = out.cpu().numpy()
+c = raw[:1024].reshape(-1, 4)[:240]
+w = raw[1024:1024 + 240 * 16].reshape(240, 8, 2).astype(np.float64)
 dt, dr = (c[:, 2] - c[:, 0]).astype(np.float64), (c[:, 3] - c[:, 1]).astype(np.float64)
 ok = dr > 0
 ghz = dt[ok] / dr[ok] * 0.1
 print(f"{n} steps; forward GEMM k loop: {np.median(dr[ok]) / 100:.1f} us per workgroup (median), in-kernel clock "
       f"median {np.median(ghz):.3f} GHz  p10 {np.percentile(ghz, 10):.3f}  p90 {np.percentile(ghz, 90):.3f}  ({ok.sum()} workgroups)")
+nk = 242
+print("per k-step, cycles: wait for own LDS writes  median over waves %.0f   in the barrier  median %.0f  (wave 0: %.0f, wave 7: %.0f; p90 %.0f)" % (
+    np.median(w[:, :, 0]) / nk, np.median(w[:, :, 1]) / nk, np.median(w[:, 0, 1]) / nk, np.median(w[:, 7, 1]) / nk, np.percentile(w[:, :, 1], 90) / nk))
+print("barrier wait per k-step by wave:", " ".join("%.0f" % (np.median(w[:, i, 1]) / nk) for i in range(8)))
