@@ -211,3 +211,11 @@ def test_iqn_gemm_kernels_match_the_per_block_kernels():
     np.testing.assert_allclose(np.asarray(a["losses"]), np.asarray(b["losses"]), rtol=2e-6, atol=2e-6)
     for leaf, want in b["probe"].items():
         np.testing.assert_allclose(np.asarray(a["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=leaf)
+    # the other launch-structure switches of the quantile heads: the embedding on the f32 MFMA instead of the pre-split bf16
+    # planes, the two gradient GEMMs as two launches, other fraction groupings of the embedding / dL/dh kernels
+    for env in ({"IDQN_IQN_EMBED3": "0"}, {"IDQN_IQN_MERGE": "0"},
+                {"IDQN_IQN_EMBED_Q": "2", "IDQN_IQN_EMBED_QG": "8", "IDQN_IQN_DH_GROUPS": "2"}):
+        c = run(**env)
+        np.testing.assert_allclose(np.asarray(c["losses"]), np.asarray(a["losses"]), rtol=2e-6, atol=2e-6, err_msg=str(env))
+        for leaf, want in a["probe"].items():
+            np.testing.assert_allclose(np.asarray(c["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=f"{env} {leaf}")
