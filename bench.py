@@ -570,7 +570,7 @@ def iiqn_bench(args, json_fd, Batch):
     rows = N * BATCH  # (sample, fraction) rows per virtual net
     # FLOPs of the contraction-bound launches (i-IQN section).  The Dense_0 GEMMs (csrc/iqn_gemm.h) issue six bf16
     # products per f32 product (the exact three-plane split): priced on the bf16 MFMA peak with 6x the f32-equivalent count;
-    # likewise the embedding forward (k_iqn_embed3); the embedding backward runs on the f32 MFMA.
+    # likewise the embedding forward and backward (k_iqn_embed3, k_iqn_embed_bwd3).
     gemm = 2.0 * K_HEADS * rows * F * J
     work = {
         "iqn dense0 fwd": (3 * gemm, 6, MFMA_BF16_PEAK),
@@ -578,7 +578,7 @@ def iiqn_bench(args, json_fd, Batch):
         "iqn dense0 wgrad": (gemm, 6, MFMA_BF16_PEAK),
         "iqn dense0 dgrad + wgrad": (2 * gemm, 6, MFMA_BF16_PEAK),
         "iqn embedding x features": (2.0 * 3 * K_HEADS * rows * 64 * F, 6, MFMA_BF16_PEAK),
-        "iqn embedding backward": (2.0 * 2 * K_HEADS * rows * 64 * F, 1, MFMA_F32_PEAK),
+        "iqn embedding backward": (2.0 * 2 * K_HEADS * rows * 64 * F, 6, MFMA_BF16_PEAK),
     }
     for kr in kernels:  # per-launch MFMA rate beside the time
         if kr["launch"] in work:

@@ -26,9 +26,12 @@ struct IqnCosArgs {
     float* cost;  // the same block transposed, cost[slot][b][i - 1] (the embedding backward reads it as an MFMA A operand), or nullptr
     unsigned short* cosp;  // the block as MFMA B fragments in three exact bf16 planes: cosp[slot][k-step t][plane][lane (b, h)][8]
                            // = cos feature i = 16 t + 8 h + jj of sample b (k_iqn_embed3), or nullptr
+    unsigned short* cosa;  // ... and as A fragments of cos (rows = features, k = samples): cosa[slot][row tile rt][k-step t][plane]
+                           // [lane (i, h)][8] = feature 32 rt + i of samples 16 t + 8 h + jj (k_iqn_embed_bwd3), or nullptr
     int K, N, B;
 };
 __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
+    __shared__ float ct[IQN_EMBED][33];
     const int slot = blockIdx.x, q = slot % a.N, v = slot / a.N, type = v / a.K, k = v - type * a.K;
     const int b = threadIdx.x & 31;
     const double tau = b < a.B ? (double)a.tau[(((long)k * 3 + type) * a.N + q) * a.B + b] : 0.5;
@@ -40,12 +43,27 @@ __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
         c[jj] = (float)cospi((double)(i + 1) * tau);
         a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = c[jj];
         if (a.cost) a.cost[((long)slot * 32 + b) * IQN_EMBED + i] = c[jj];
+        ct[i][b] = c[jj];
     }
     if (a.cosp) {
         unsigned p0[4], p1[4], p2[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) split3_pk(c[2 * m], c[2 * m + 1], p0[m], p1[m], p2[m]);
         unsigned short* O = a.cosp + (((long)slot * 4 + (g >> 1)) * 3) * 512 + ((g & 1) * 32 + b) * 8;
+        *reinterpret_cast<u32x4*>(O) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+        *reinterpret_cast<u32x4*>(O + 512) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+        *reinterpret_cast<u32x4*>(O + 1024) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+    }
+    if (a.cosa) {  // thread = (row tile rt, k-step t, lane (i, h)): 8 consecutive samples of one feature
+        __syncthreads();
+        const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, rt = threadIdx.x >> 7, t = (threadIdx.x >> 6) & 1;
+        float v8[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v8[jj] = ct[32 * rt + il][16 * t + 8 * hh + jj];
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) split3_pk(v8[2 * m], v8[2 * m + 1], p0[m], p1[m], p2[m]);
+        unsigned short* O = a.cosa + (((long)slot * 4 + rt * 2 + t) * 3) * 512 + lane * 8;
         *reinterpret_cast<u32x4*>(O) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
         *reinterpret_cast<u32x4*>(O + 512) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
         *reinterpret_cast<u32x4*>(O + 1024) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
@@ -512,6 +530,151 @@ __global__ __launch_bounds__(256, 2) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
         if (qi + 1 < nq) EB_STEP(qi + 1, 1)
     }
 #undef EB_STEP
+    if (!live) return;
+    float* DP = a.dpsi + ((long)qg * a.K + k) * a.F * 32;
+    float* G = a.gpart + ((long)qg * a.K + k) * 65 * a.F;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int fl = mfma_row(i, h);
+        DP[(long)(f0 + fl) * 32 + r] = dps[i];
+        float d = dbe[i];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        if (r == 0) G[64L * a.F + f0 + fl] = d;
+        G[(long)mfma_row(i, h) * a.F + f0 + r] = gw0[i];
+        G[(long)(32 + mfma_row(i, h)) * a.F + f0 + r] = gw1[i];
+    }
+}
+
+// The same backward on the bf16 matrix cores: the recomputed embedding from the pre-split planes (k_iqn_we_pack, cosp:
+// 24 products instead of 32 f32 MFMAs of twice the length), dL/dWe from the A-fragment planes of cos (cosa) and dphi split
+// in the kernel after its trip through the per-wave LDS tile (8 split3_pk per lane and fraction): 24 products instead of
+// 32.  Staging, grouping and outputs as k_iqn_embed_bwd.
+struct IqnEmbedBwd3Args {
+    const unsigned short* cosp;  // [V * N][12][512]
+    const unsigned short* cosa;  // [V * N][12][512]
+    const unsigned short* wep;   // [n_packed][F / 32][12][512]  (online nets first)
+    const float* const* wbase;
+    const float* psi;
+    const float* dx;
+    float* dpsi;
+    float* gpart;
+    long be_off;
+    int K, N, F;
+};
+__global__ __launch_bounds__(256, 2) void k_iqn_embed_bwd3(IqnEmbedBwd3Args a) {
+    __shared__ float tile[4][32][33];
+    extern __shared__ __attribute__((aligned(1024))) unsigned short eb3_cs[];  // [buffer 2][cosp | cosa][12 * 512]: 48 KB (dynamic)
+    unsigned short (*cs)[2][12 * 512] = reinterpret_cast<unsigned short (*)[2][12 * 512]>(eb3_cs);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int k = blockIdx.y, qg = blockIdx.z;
+    const int nq = a.N / (int)gridDim.z, q_begin = qg * nq;
+    const bool live = (int)blockIdx.x * 4 + wave < a.F / 32;
+    const int ft = min((int)blockIdx.x * 4 + wave, a.F / 32 - 1);
+    const int f0 = ft * 32;
+    const float* P = a.wbase[k];
+    bf16x8 wf[4][3];
+    {
+        const unsigned short* Wf = a.wep + (((long)k * (a.F / 32) + ft) * 12) * 512 + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(Wf + (t * 3 + p) * 512);
+    }
+    float be[16], ps[16], dps[16], dbe[16];
+    const float* psi = a.psi + (long)k * a.F * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = f0 + mfma_row(i, h);
+        be[i] = P[a.be_off + f];
+        ps[i] = psi[(long)f * 32 + r];
+        dps[i] = 0.f;
+        dbe[i] = 0.f;
+    }
+    f32x16 gw0, gw1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { gw0[i] = 0.f; gw1[i] = 0.f; }
+    const unsigned lds_cs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)&cs[0][0][0];
+    // this wave's quarter of the 24 KB [cosp | cosa] of fraction q -> buffer `buf` (six 1 KB pieces)
+    auto stage = [&](int q, int buf) {
+        const long slot = (long)k * a.N + q;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int piece = wave * 6 + c, which = piece >= 12, off = (piece - 12 * which) * 512;  // shorts
+            const unsigned short* src = (which ? a.cosa : a.cosp) + slot * (12 * 512) + off;
+            dma16((unsigned)lane * 16, (unsigned long)src, lds_cs + (unsigned)(((buf * 2 + which) * 12 * 512 + off) * 2));
+        }
+    };
+    float dxr[2][16];
+    auto fetch_dx = [&](int q, int st) {
+        const float* DX = a.dx + ((long)k * a.N + q) * a.F * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dxr[st][i] = DX[(long)(f0 + mfma_row(i, h)) * 32 + r];
+    };
+    stage(q_begin, 0);
+    fetch_dx(q_begin, 0);
+#define EB3_STEP(qi, st)                                                                                 \
+    {                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                    \
+        if ((qi) + 1 < nq) {                                                                             \
+            stage(q_begin + (qi) + 1, (st) ^ 1);                                                         \
+            fetch_dx(q_begin + (qi) + 1, (st) ^ 1);                                                      \
+        }                                                                                                \
+        const unsigned short* Cb = &cs[st][0][0] + lane * 8;                                             \
+        const unsigned short* Ca = &cs[st][1][0] + lane * 8;                                             \
+        f32x16 acc;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                  \
+            const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(Cb + (t * 3 + 0) * 512);                  \
+            const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(Cb + (t * 3 + 1) * 512);                  \
+            const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(Cb + (t * 3 + 2) * 512);                  \
+            acc = mfma_bf16(wf[t][2], c0, acc);                                                          \
+            acc = mfma_bf16(wf[t][0], c2, acc);                                                          \
+            acc = mfma_bf16(wf[t][1], c1, acc);                                                          \
+            acc = mfma_bf16(wf[t][1], c0, acc);                                                          \
+            acc = mfma_bf16(wf[t][0], c1, acc);                                                          \
+            acc = mfma_bf16(wf[t][0], c0, acc);                                                          \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                 \
+            const int fl = mfma_row(i, h);                                                               \
+            const float e = acc[i] + be[i];                                                              \
+            const float dx = dxr[st][i];                                                                 \
+            dps[i] = fmaf(dx, fmaxf(e, 0.f), dps[i]);                                                    \
+            const float dphi = e > 0.f ? dx * ps[i] : 0.f;                                               \
+            dbe[i] += dphi;                                                                              \
+            tile[wave][fl][r] = dphi;                                                                    \
+        }                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        /* dWe[i][f] += sum_b cos[i][b] dphi[f][b]: A = cosa fragments (row i, k = sample), B = dphi (k = sample 16 t + 8 h + jj, col f = r) */ \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                  \
+            float dv[8];                                                                                 \
+            _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) dv[jj] = tile[wave][r][16 * t + 8 * h + jj]; \
+            unsigned p0[4], p1[4], p2[4];                                                                \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(dv[2 * m], dv[2 * m + 1], p0[m], p1[m], p2[m]); \
+            const bf16x8 d0 = planes8(p0), d1 = planes8(p1), d2 = planes8(p2);                           \
+            _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {                                           \
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ca + ((rt * 2 + t) * 3 + 0) * 512);   \
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ca + ((rt * 2 + t) * 3 + 1) * 512);   \
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(Ca + ((rt * 2 + t) * 3 + 2) * 512);   \
+                f32x16& g = rt ? gw1 : gw0;                                                              \
+                g = mfma_bf16(a2, d0, g);                                                                \
+                g = mfma_bf16(a0, d2, g);                                                                \
+                g = mfma_bf16(a1, d1, g);                                                                \
+                g = mfma_bf16(a1, d0, g);                                                                \
+                g = mfma_bf16(a0, d1, g);                                                                \
+                g = mfma_bf16(a0, d0, g);                                                                \
+            }                                                                                            \
+        }                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    }
+    for (int qi = 0; qi < nq; qi += 2) {
+        EB3_STEP(qi, 0)
+        if (qi + 1 < nq) EB3_STEP(qi + 1, 1)
+    }
+#undef EB3_STEP
     if (!live) return;
     float* DP = a.dpsi + ((long)qg * a.K + k) * a.F * 32;
     float* G = a.gpart + ((long)qg * a.K + k) * 65 * a.F;

@@ -219,6 +219,7 @@ struct IqnWs {
     int N = 0, V = 0, NS = 2;
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
     float* cost = nullptr;  // cosb transposed per slot [V * N][32][64]
+    unsigned short* cosa = nullptr;  // A-fragment planes of the cos blocks [V * N][12][512]
     unsigned short *cosp = nullptr, *wep = nullptr;  // bf16 fragment planes of the cos blocks [V * N][12][512] and of We [2K][F / 32][12][512]
     float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
@@ -576,6 +577,8 @@ int cnn_setup(idqn_handle_s* h) {
             float* tmp = nullptr;  // (alloc_zero counts floats: 12 x 512 bf16 = 3072 floats per block)
             if ((rc = alloc_zero(&tmp, VN * 3072, h, "iqn_cosp"))) return rc;
             w.cosp = (unsigned short*)tmp;
+            if ((rc = alloc_zero(&tmp, VN * 3072, h, "iqn_cosa"))) return rc;
+            w.cosa = (unsigned short*)tmp;
             if ((rc = alloc_zero(&tmp, 2L * K * (h->F / 32) * 3072, h, "iqn_wep"))) return rc;
             w.wep = (unsigned short*)tmp;
         }
@@ -1817,7 +1820,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     IqnCosArgs ca;
     // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
     static const bool embed3 = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
-    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
     IqnEmbedArgs ea;
@@ -1958,6 +1961,16 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     eb.cosb = w.cosb; eb.cost = w.cost; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
     eb.we_off = w.off_we; eb.be_off = w.off_be;
     eb.K = K; eb.N = w.N; eb.F = h->F;
+    static const bool embed3b = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
+    if (embed3b) {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
+        IqnEmbedBwd3Args e3;
+        e3.cosp = w.cosp; e3.cosa = w.cosa; e3.wep = w.wep; e3.wbase = w.wbase_v; e3.psi = h->train.a3; e3.dx = w.dx;
+        e3.dpsi = w.dpsi; e3.gpart = w.gpart; e3.be_off = w.off_be; e3.K = K; e3.N = w.N; e3.F = h->F;
+        const size_t lds = 2 * 2 * 12 * 512 * 2;
+        static LdsAttrMark attr;
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_embed_bwd3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_iqn_embed_bwd3, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), lds, q, e3);
+    } else
     hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), 0, q, eb);
     tl_mark(h, q, "iqn embedding backward");
     {
