@@ -14,6 +14,7 @@
 //   data gradient  dx[k][bb][f][b] = sum over j of W[f][j] * dh[k][bb][j][b]                             (k_iqn_d0_dgrad)
 //   weight gradient g[ks][k][f][j] = sum over the blocks of split ks and b of x[k][bb][f][b] * dh[k][bb][j][b]  (k_iqn_d0_wgrad)
 //                  followed by k_iqn_d0_adam: g = g[0] + g[1] (fixed order), Adam on Dense_0/kernel in one streaming pass
+//   k_iqn_d0_bwd   both gradients in one launch (the default: 2 x 620 workgroups = 4.8 rounds of the chip instead of 3 + 3)
 // The k-steps of a split are taken in the same order and the six products in the same order as in k_dense0_fwd3: the
 // partials are bit-identical to that kernel's.
 #pragma once
