@@ -45,6 +45,7 @@ __device__ __forceinline__ void ig_park(const float (&v)[8], unsigned char* dst)
 template <int D>  // k-steps of operand rows in flight per wave (registers)
 __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    const long long c_entry = a.clk ? __builtin_amdgcn_s_memrealtime() : 0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
     // item = (net, group of 8 blocks, split, 256-column half), net slowest; an XCD walks consecutive items, i.e. the
     // workgroups that stream the same net's kernel share it through one L2
@@ -196,6 +197,13 @@ __global__ __launch_bounds__(512) void k_iqn_d0_fwd(IqnD0FwdArgs a) {
             const int col0 = jh * 256 + (4 * wn + i) * 32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[(long)(col0 + mfma_row(r, h)) * 32] = acc[i][j][r];
+        }
+    }
+    if (a.clk) {  // workgroup entry and the moment this wave's partial stores have left (100 MHz stamps)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            long long* c = a.clk + 1024 + 256 * 16 + (long)blockIdx.x * 2;
+            c[0] = c_entry; c[1] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }

@@ -598,7 +598,7 @@ int cnn_setup(idqn_handle_s* h) {
         w.HG = getenv("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(getenv("IDQN_IQN_DH_GROUPS"))) : 8;
         while (w.HG > 1 && w.N % w.HG != 0) --w.HG;
         if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
-        if (getenv("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2) * 2, h, "iqn_clk"))) return rc;
+        if (getenv("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }

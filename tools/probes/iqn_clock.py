@@ -38,3 +38,11 @@ nk = 242
 print("per k-step, cycles: wait for own LDS writes  median over waves %.0f   in the barrier  median %.0f  (wave 0: %.0f, wave 7: %.0f; p90 %.0f)" % (
     np.median(w[:, :, 0]) / nk, np.median(w[:, :, 1]) / nk, np.median(w[:, 0, 1]) / nk, np.median(w[:, 7, 1]) / nk, np.percentile(w[:, :, 1], 90) / nk))
 print("barrier wait per k-step by wave:", " ".join("%.0f" % (np.median(w[:, i, 1]) / nk) for i in range(8)))
+us = dr[ok] / 100
+print("k loop per workgroup, us: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f;  first start .. last end of the k loops: %.1f us" % (
+    us.min(), np.percentile(us, 10), np.median(us), np.percentile(us, 90), us.max(), (c[ok, 3].max() - c[ok, 1].min()) / 100))
+e = raw[1024 + 4096:1024 + 4096 + 480].reshape(240, 2).astype(np.float64)
+t0 = e[:, 0].min()
+print("kernel timeline, us from the first workgroup's entry: entries %.1f .. %.1f;  k loops start %.1f .. %.1f, end %.1f .. %.1f;  stores done %.1f .. %.1f" % (
+    0.0, (e[:, 0].max() - t0) / 100, (c[:, 1].min() - t0) / 100, (c[:, 1].max() - t0) / 100, (c[:, 3].min() - t0) / 100, (c[:, 3].max() - t0) / 100,
+    (e[:, 1].min() - t0) / 100, (e[:, 1].max() - t0) / 100))
