@@ -183,7 +183,7 @@ from collections import namedtuple
 from slimdqn.networks.iiqn import iIQN
 Batch = namedtuple("Batch", "state action reward next_state is_terminal")
 rng = np.random.default_rng(21)
-obs, A, K, N, B = (20, 20, 4), 4, 2, 16, 32
+obs, A, K, N, B = (20, 20, 4), 4, 2, int(os.environ.get("TEST_IQN_N", "16")), 32
 agent = iIQN(9, obs, A, K, [32, 32, 32, 256], "cnn", 2.5e-4, 0.99, 1, 1, 10**9, 10**9, adam_eps=1e-6, n_quantiles=N)
 b = Batch(rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8), rng.integers(0, A, size=B).astype(np.int32),
           rng.standard_normal(B).astype(np.float32), rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8), rng.random(B) < 0.1)
@@ -206,6 +206,12 @@ def test_iqn_gemm_kernels_match_the_per_block_kernels():
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
 
+    # N = 8: forward and data gradient as GEMMs, the weight gradient on the fused kernel of the plain step (it needs 16 blocks)
+    a8, b8 = run(TEST_IQN_N="8"), run(TEST_IQN_N="8", IDQN_IQN_GEMM="0")
+    assert a8["losses"][0] == b8["losses"][0]
+    np.testing.assert_allclose(np.asarray(a8["losses"]), np.asarray(b8["losses"]), rtol=2e-6, atol=2e-6)
+    for leaf, want in b8["probe"].items():
+        np.testing.assert_allclose(np.asarray(a8["probe"][leaf]), np.asarray(want), rtol=0, atol=3e-6, err_msg=f"N=8 {leaf}")
     a, b = run(), run(IDQN_IQN_GEMM="0")
     assert a["losses"][0] == b["losses"][0]
     np.testing.assert_allclose(np.asarray(a["losses"]), np.asarray(b["losses"]), rtol=2e-6, atol=2e-6)
