@@ -1,4 +1,5 @@
-"""One launcher for the four entry points (``experiments/{atari,lunar_lander}/{dqn,idqn}.py`` of the reference wire
+"""One launcher for the entry points (``experiments/{atari,lunar_lander}/{dqn,idqn}.py`` of the reference, plus
+``experiments/atari/iiqn.py`` for the quantile-head extension: they wire
 the same four objects -- flags, environment, replay buffer, agent -- with per-environment constants; here that wiring
 is a table and a function instead of four near-identical scripts)."""
 import os
@@ -39,6 +40,11 @@ def make_agent(algo, key, obs_dim, n_actions, p, adam_eps):
 
         return iDQN(key, obs_dim, n_actions, n_networks=p["n_networks"],
                     target_sync_frequency=p["target_sync_frequency"], **shared)
+    if algo == "iiqn":  # extension: the quantile heads on the same trunk and chain (slimdqn/networks/iiqn.py)
+        from slimdqn.networks.iiqn import iIQN
+
+        return iIQN(key, obs_dim, n_actions, n_networks=p["n_networks"],
+                    target_sync_frequency=p["target_sync_frequency"], n_quantiles=p["n_quantiles"], **shared)
     from slimdqn.networks.dqn import DQN
 
     return DQN(key, obs_dim, n_actions, **shared)

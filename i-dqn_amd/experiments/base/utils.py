@@ -35,9 +35,11 @@ def base_parser(algo_name: str) -> argparse.ArgumentParser:
     ap.add_argument("-ee", "--epsilon_end", type=float, default=0.01)
     ap.add_argument("-ed", "--epsilon_duration", type=float, default=1_000)
     ap.add_argument("-tuf", "--target_update_frequency", type=int, default=200)
-    if algo_name == "idqn":
+    if algo_name in ("idqn", "iiqn"):
         ap.add_argument("-nn", "--n_networks", type=int, default=3)
         ap.add_argument("-tsf", "--target_sync_frequency", type=int, default=10)
+    if algo_name == "iiqn":  # extension (the reference has no quantile agent): fractions per sample and pass
+        ap.add_argument("-nq", "--n_quantiles", type=int, default=32)
     return ap
 
 

@@ -126,7 +126,8 @@ class DeviceAgent:
     def _dev(x, dtype):
         t = getattr(x, "tensor", x)
         if not isinstance(t, torch.Tensor):
-            t = torch.from_numpy(np.ascontiguousarray(np.asarray(t)))
+            a = np.ascontiguousarray(np.asarray(t))
+            t = torch.from_numpy(a if a.flags.writeable else a.copy())  # (a read-only view, e.g. an environment's state table)
         return t.to(device="cuda", dtype=dtype).contiguous()
 
     # ---- the step ------------------------------------------------------------------------------------

@@ -124,3 +124,22 @@ def test_iqn_step_is_reproducible_bit_for_bit():
     for leaf in runs[0][1]:
         assert np.array_equal(runs[0][1][leaf], runs[1][1][leaf]), leaf
         assert np.array_equal(runs[0][2][leaf], runs[1][2][leaf]), leaf
+
+
+def test_iqn_trainer_entry_point(tmp_path):
+    """experiments/atari/iiqn.py (extension): the reference's trainer loop -- collect, update_online, T-step copy / shift,
+    D-step sync, logs, checkpoint -- with the quantile agent on the synthetic Atari environment."""
+    import pickle
+
+    from experiments.atari.iiqn import run
+
+    argv = ["-en", "t", "-s", "2", "-ne", "1", "-ntspe", "70", "-nis", "40", "-rbc", "100", "-nn", "2", "-nq", "8", "-at", "cnn",
+            "-tuf", "20", "-tsf", "5", "-f", "32", "64", "64", "256", "-horizon", "30", "-bs", "32"]
+    p, agent = run(argv, save_root=str(tmp_path))
+    logs = [r for r in p["wandb"].records if "loss" in r]
+    assert logs and all(np.isfinite(r["loss"]) and f"networks/{agent.n_networks - 1}_loss" in r for r in logs)
+    assert int(agent._count[0].item()) >= 30
+    model = pickle.load(open(os.path.join(p["save_path"], "models", "2"), "rb"))
+    leaves = model["params"]["params"]
+    assert "Embed_0" in leaves and leaves["Embed_0"]["kernel"].shape[-2] == 64
+    assert all(np.isfinite(v).all() for m in leaves.values() for v in m.values())
