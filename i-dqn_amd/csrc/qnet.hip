@@ -1820,7 +1820,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     IqnCosArgs ca;
     // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
     static const bool embed3 = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
-    ca.tau = tau; ca.cosb = w.cosb; ca.cost = w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    ca.tau = tau; ca.cosb = w.cosb; ca.cost = embed3 ? nullptr : w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
     IqnEmbedArgs ea;
