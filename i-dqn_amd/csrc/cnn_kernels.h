@@ -887,7 +887,7 @@ struct SplitFactorsArgs {
 __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     const int slot = blockIdx.y, bb = slot / a.K, k = slot - bb * a.K;
     const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
-    const long na = (long)a.F * 8, nd = (long)a.J * 8;  // float4 per (block, head)
+    const long na = (long)a.F * 4, nd = (long)a.J * 4;  // pairs of float4 per (block, head): 16-byte stores per plane
     long e = (long)blockIdx.x * 256 + threadIdx.x;
     const float* src;
     unsigned short* dst;
@@ -903,13 +903,15 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
         dst = a.dhp + (long)slot * a.J * 32;
         plane = (long)a.nb * a.K * a.J * 32;
     }
-    const float4 v = *reinterpret_cast<const float4*>(src + e * 4);
-    unsigned q0a, q1a, q2a, q0b, q1b, q2b;
-    split3_pk(v.x, v.y, q0a, q1a, q2a);
-    split3_pk(v.z, v.w, q0b, q1b, q2b);
-    *reinterpret_cast<uint2*>(dst + e * 4) = make_uint2(q0a, q0b);
-    *reinterpret_cast<uint2*>(dst + plane + e * 4) = make_uint2(q1a, q1b);
-    *reinterpret_cast<uint2*>(dst + 2 * plane + e * 4) = make_uint2(q2a, q2b);
+    const float4 v = *reinterpret_cast<const float4*>(src + e * 8), w = *reinterpret_cast<const float4*>(src + e * 8 + 4);
+    unsigned q0[4], q1[4], q2[4];
+    split3_pk(v.x, v.y, q0[0], q1[0], q2[0]);
+    split3_pk(v.z, v.w, q0[1], q1[1], q2[1]);
+    split3_pk(w.x, w.y, q0[2], q1[2], q2[2]);
+    split3_pk(w.z, w.w, q0[3], q1[3], q2[3]);
+    *reinterpret_cast<u32x4*>(dst + e * 8) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane + e * 8) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane + e * 8) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
 }
 
 // The fused kernel over FULL 512-column rows (NQ = 4, dense width 512): the workgroup then holds the complete data gradient

@@ -1372,7 +1372,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         sa.dh_outer = dh_outer; sa.dh_head = dh_head; sa.dh_inner = dh_inner;
         sa.K = K; sa.nb = nb_total; sa.nb_inner = nb_inner; sa.F = h->F; sa.J = h->J;
         sa.a3p = h->fact_planes; sa.dhp = h->fact_planes + (long)3 * nb_total * K * h->F * 32;
-        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)(h->F + h->J) * 8, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
+        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)(h->F + h->J) * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
         tl_mark(h, q, "factor planes");
         dw.a3p = sa.a3p; dw.dhp = sa.dhp;
     }
