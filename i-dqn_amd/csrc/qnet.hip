@@ -324,7 +324,6 @@ struct idqn_handle_s {
     // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
     struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
     bool d0_rows = false;  // the last fused Dense_0 launch ran on full rows and finished dL/da3 itself
-    hipEvent_t d0_wait = nullptr;  // experiment hook: the training forward waits for this event in front of its Dense_0 launch
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
@@ -1255,7 +1254,6 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    if (&s == &h->train && h->d0_wait) IDQN_HIP_CHECK(hipStreamWaitEvent(q, h->d0_wait, 0));
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
@@ -2086,13 +2084,6 @@ extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_de
         // every other leaf, from grad_dev; count += 1 and cum_losses += losses ride in the same launch
         return launch_adam(h, 0, h->L.head_stride, h->off_w0, h->off_b0, false, q, h->cfg.arch == IDQN_ARCH_CNN);
     }
-    return IDQN_OK;
-}
-
-// experiment hook (not part of include/idqn_hip.h): see idqn_handle_s::d0_wait
-extern "C" int idqn_x_set_dense0_wait_event(idqn_handle_t h, void* event) {
-    IDQN_REQUIRE(h, "idqn_x_set_dense0_wait_event: null handle");
-    h->d0_wait = (hipEvent_t)event;
     return IDQN_OK;
 }
 

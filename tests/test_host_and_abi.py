@@ -23,6 +23,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.idqn_abi_version() == 2
     for name in declared:
         assert hasattr(lib, name)
+    # ... and nothing else: the dynamic symbol table of the .so, restricted to defined global functions that are not the
+    # toolchain's own (underscore-prefixed), is exactly the declared set -- no undeclared experiment hooks ride along
+    import subprocess
+
+    nm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "llvm-nm")
+    out = subprocess.run([nm if os.path.exists(nm) else "nm", "-D", "--defined-only", _hip.LIB_PATH], check=True,
+                         capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in ("T", "t")}
+    exported = {n for n in exported if not n.startswith("_")}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_layout_matches_the_reference_pytree():

@@ -7,7 +7,9 @@ conv launches planned for IDQN_CUS = 256 - n_b workgroups.  Modes:
   fused     the shipped single-stream step (one C call)
   serial    the split step, all on one stream (what the split itself costs: separate data gradient, slab reduce)
   within    fork after the data gradient, join before the small-leaf Adam (same step)
-  cross     fork after the data gradient, join in front of the NEXT step's Dense_0 forward (idqn_x_set_dense0_wait_event)
+  (round 3 also had `cross`: join in front of the NEXT step's Dense_0 forward through an experiment hook in the library;
+   its figures are in profiles/r3_overlap_cumask_streams.txt, the hook was removed in round 4: the .so exports only what
+   include/idqn_hip.h declares)
 usage: python tools/probes/overlap_cumask.py <n_b> <pattern: low|stride|none> [steps]
 """
 import ctypes as C
@@ -33,8 +35,6 @@ from collections import namedtuple  # noqa: E402
 
 hip = C.CDLL("libamdhip64.so")
 lib = _hip.lib()
-lib.idqn_x_set_dense0_wait_event.argtypes = [C.c_void_p, C.c_void_p]
-lib.idqn_x_set_dense0_wait_event.restype = C.c_int
 for _f, _a in (("hipEventRecord", [C.c_void_p, C.c_void_p]), ("hipStreamWaitEvent", [C.c_void_p, C.c_void_p, C.c_uint]),
                ("hipStreamSynchronize", [C.c_void_p]), ("hipEventSynchronize", [C.c_void_p]),
                ("hipEventElapsedTime", [C.POINTER(C.c_float), C.c_void_p, C.c_void_p])):
@@ -155,10 +155,6 @@ torch.cuda.synchronize()
 print(f"  Dense_0 update alone on stream B: {best:.1f} us = {476.0 / best:.2f} TB/s", flush=True)
 run("split, serial on one stream", lambda i: step_split(i, "serial"))
 run("split, overlap within the step", lambda i: step_split(i, "within"))
-_hip.check(lib.idqn_x_set_dense0_wait_event(agent._handle, e_join), "hook")
-chk(hip.hipEventRecord(e_join, sB), "record")  # (so that the first wait finds a recorded event)
-run("split, overlap across steps", lambda i: step_split(i, "cross"))
-_hip.check(lib.idqn_x_set_dense0_wait_event(agent._handle, None), "hook")
 torch.cuda.synchronize()
 losses = agent._losses.cpu().numpy()
 assert np.isfinite(losses).all(), losses
