@@ -1753,6 +1753,8 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             // bounded: a caller that hands over allocator-recycled buffers would otherwise instantiate a graph per pointer
             // tuple that ever recurs; past 32 keys everything is dropped and the cache starts again
             if (h->step_graphs.size() >= 32 && !h->step_graphs.count(key)) {
+                // the last replay may still be running on the caller's stream: an executable graph is only destroyed idle
+                IDQN_HIP_CHECK(hipStreamSynchronize(q));
                 for (auto& g : h->step_graphs)
                     if (g.second.second) (void)hipGraphExecDestroy(g.second.second);
                 h->step_graphs.clear();
@@ -1882,6 +1884,9 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     IDQN_REQUIRE(h->iqn.N > 0, "idqn_iqn_learn_on_batch: the handle was created without quantile heads (cfg.n_quantiles)");
     IDQN_REQUIRE(batch >= 1 && batch <= 32 && batch <= h->cfg.max_batch, "idqn_iqn_learn_on_batch: batch %d not in [1, 32]", batch);
     IDQN_REQUIRE(!(flags & ~(IDQN_F_PROFILE | IDQN_F_PROFILE_ALL)), "idqn_iqn_learn_on_batch: only the profile flags are supported");
+    // the quantile loss has no importance weights and writes no |TD|: refuse the combination instead of leaving stale priorities
+    IDQN_REQUIRE(!h->is_weight && !h->td_abs,
+                 "idqn_iqn_learn_on_batch: prioritized-replay buffers are set (idqn_set_per_buffers) but the quantile heads do not use them");
     hipStream_t q = (hipStream_t)stream;
     IqnWs& w = h->iqn;
     const int K = h->cfg.n_heads, A = h->cfg.n_actions;

@@ -99,7 +99,8 @@ int idqn_destroy(idqn_handle_t h);
  * One gradient step of K heads on a minibatch of batch <= 32 samples: per head N online fractions, N action-selection
  * fractions and N target fractions per sample, tau_dev = float32 [K][3][N][batch] in (0, 1) (the host draws them);
  * quantile Huber loss (kappa = 1), sum over the online and mean over the target fractions, mean over the batch; Adam on
- * every leaf; count += 1, losses written, cum_losses accumulated -- as idqn_learn_on_batch.  flags: IDQN_F_PROFILE only. */
+ * every leaf; count += 1, losses written, cum_losses accumulated -- as idqn_learn_on_batch.  flags: IDQN_F_PROFILE / IDQN_F_PROFILE_ALL only.
+ * Refused (IDQN_ERR_*) while idqn_set_per_buffers has buffers set: the quantile loss takes no importance weights. */
 int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
                             const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
                             const float* tau_dev, int32_t batch, uint32_t flags, void* stream);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the i-IQN bench line under a list of environment settings ("A=1 B=2" per argument; "" = defaults): step time + the big launches
-cd "${GRAFT_REPO_ROOT:?}"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" && mkdir -p gpurun_out
 i=0
 for e in "$@"; do
   i=$((i+1))
