@@ -69,6 +69,22 @@ struct CFwdArgs {
     CVar var[4];
 };
 
+// ---- hand-offs between the layers of a chained launch (convp_chain.hip) ------------------------------------------
+// One flag word per work item: the producer stores the step's epoch into it once every wave's write-through (sc1)
+// stores of the item have been acknowledged; a consumer item polls the flags of the producer items whose output rows
+// its input rows overlap (one wave, one lane per flag, relaxed agent-scope loads), then ONE agent-scope acquire
+// (cdna_hip_programming.md, Guideline 16 R1).  An item only ever waits on items of an EARLIER layer and every workgroup
+// runs its items layer by layer, all workgroups co-resident (one per CU): no cycle, no deadlock; spins are bounded.
+struct ChainHand {
+    const unsigned* wait_flags;  // producer layer's flags [slot][p_R], or nullptr: the inputs come from an earlier launch
+    unsigned* done_flags;        // this layer's flags [slot][items_per_slot], or nullptr: a LATER launch reads the outputs
+    unsigned* err;               // [0] |= 1 when a bounded spin gave up (the TD kernel then writes NaN losses)
+    int p_OW, p_OH, p_lo_h;      // producer grid (unpadded) and the zero rows in front of it in the buffer
+    int p_R, p_base, p_rem;      // producer ranges per slot: range r = positions [r * base + min(r, rem), ...) (balanced split)
+    int pad0, pad1;
+};
+#define CHAIN_SPIN_LIMIT (1u << 18)
+
 // ---- weight-gradient launch -----------------------------------------------------------------------------------
 struct CWItem {  // one workgroup: positions [p0, p0 + np) of one head, one kernel row (Conv_0: all kernel rows)
     int net, kh, chunk, p0, np, pad0, pad1, pad2;
@@ -117,6 +133,7 @@ struct StageArgs {
     const int32_t* count;
     float* bcinv;
     float b1, b2;
+    unsigned* epoch;        // chained conv launches: += 1 once per step (first pack block), or nullptr
     PackJob job[8];
 };
 
@@ -142,12 +159,18 @@ __device__ __forceinline__ void dma16(unsigned voff, unsigned long sbase, unsign
                  : "memory", "m0");
 }
 
+// 16-byte write-through store (sc1: the line leaves the XCD's L2 for the memory side at once, no release fence needed
+// before the flag).  hipcc does not count an asm store: the publishing wave drains with s_waitcnt vmcnt(0) itself.
+__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // Touch every 64-byte line of the kernel-argument segment with back-to-back scalar loads at kernel entry.  hipcc loads
 // argument fields lazily, next to their first use: a prologue that needs ~60 of them in dependent steps paid 8 scalar
 // round trips (measured ~4000 cycles); after this warm-up they all hit the scalar cache.
 template <int BYTES>
 __device__ __forceinline__ void warm_kernargs() {
-    static_assert(BYTES <= 16 * 64, "kernel arguments longer than 16 cache lines");
+    static_assert(BYTES <= 32 * 64, "kernel arguments longer than 32 cache lines");
     auto kp = (const __attribute__((address_space(4))) u32x4*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int L = (BYTES + 63) / 64;  // lines; all loads of a group are issued before the one wait its asm statement forces
     {
@@ -158,6 +181,16 @@ __device__ __forceinline__ void warm_kernargs() {
     if (L > 8) {
         const u32x4 v0 = kp[32], v1 = kp[L > 9 ? 36 : 32], v2 = kp[L > 10 ? 40 : 32], v3 = kp[L > 11 ? 44 : 32];
         const u32x4 v4 = kp[L > 12 ? 48 : 32], v5 = kp[L > 13 ? 52 : 32], v6 = kp[L > 14 ? 56 : 32], v7 = kp[L > 15 ? 60 : 32];
+        asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+    }
+    if (L > 16) {
+        const u32x4 v0 = kp[64], v1 = kp[L > 17 ? 68 : 64], v2 = kp[L > 18 ? 72 : 64], v3 = kp[L > 19 ? 76 : 64];
+        const u32x4 v4 = kp[L > 20 ? 80 : 64], v5 = kp[L > 21 ? 84 : 64], v6 = kp[L > 22 ? 88 : 64], v7 = kp[L > 23 ? 92 : 64];
+        asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
+    }
+    if (L > 24) {
+        const u32x4 v0 = kp[96], v1 = kp[L > 25 ? 100 : 96], v2 = kp[L > 26 ? 104 : 96], v3 = kp[L > 27 ? 108 : 96];
+        const u32x4 v4 = kp[L > 28 ? 112 : 96], v5 = kp[L > 29 ? 116 : 96], v6 = kp[L > 30 ? 120 : 96], v7 = kp[L > 31 ? 124 : 96];
         asm volatile("" ::"s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(v4), "s"(v5), "s"(v6), "s"(v7));
     }
 }
@@ -197,6 +230,17 @@ int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_
                       const D0Stream* ds = nullptr);
 bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
+// the three forward convs of a net set as ONE launch with per-item hand-offs (convp_chain.hip)
+struct CChainArgs {
+    CFwdArgs a[3];
+    ChainHand hand[3];
+    unsigned stage_bytes[3], mask_off[3];
+    int ring[3], n_items[3];
+    const unsigned* epoch;  // device word, bumped once per step by the staging launch
+    long long* prof[3];
+};
+bool convp_chain_fwd_built(const int NT[3]);
+int convp_launch_chain_fwd(const CChainArgs& c, const int NT[3], int n_wg, size_t lds_bytes, hipStream_t q);
 int convp_fwd_max_nt(int CT);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: the launchers keep one high-water mark per device and

@@ -42,10 +42,30 @@ __device__ __forceinline__ bf16x8 frag_lin(const unsigned char* p) {
     return *(const __attribute__((address_space(3))) bf16x8*)p;
 }
 
-// b = this workgroup's item index (already remapped XCD-contiguously), nblk = items of the launch (or of this role)
-template <int NPA, int CT, int NQ, int NT>
+// One wave waits for producer items [lo, hi] of a chained launch (convp.h, ChainHand): lane i polls flag lo + i with
+// relaxed agent-scope loads until all equal the step's epoch, then ONE agent-scope acquire (buffer_inv sc1: this CU's L1)
+// and the wait for it; the workgroup barrier that follows releases the waves that load the handed-off bytes.
+__device__ __forceinline__ void chain_wait(const unsigned* flags, int lo, int hi, unsigned epoch, unsigned* err) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lo + lane <= hi;
+    bool ok = false;
+    for (unsigned spins = 0; spins < CHAIN_SPIN_LIMIT; ++spins) {
+        const unsigned v = mine ? __hip_atomic_load(flags + lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (!ok && lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// b = this workgroup's item index (already remapped XCD-contiguously), nblk = items of the launch (or of this role).
+// CHAIN: the body is one layer of a chained launch -- `ch` says which producer flags its input rows wait for and which
+// flag it raises once its outputs are written through; the loaders request the (always ready) packed kernels of the first
+// stages BEFORE the wait, the pixels behind it.
+template <int NPA, int CT, int NQ, int NT, bool CHAIN = false>
 __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_bytes, int ring, unsigned mask_off, long long* prof,
-                                          const int b, const int nblk) {
+                                          const int b, const int nblk, const ChainHand* ch = nullptr, const unsigned epoch = 0) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int WB = NQ * CT * 3 * 1024, BLKA = NPA * 1024, NWP = NQ * CT * 3;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
@@ -58,7 +78,7 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     // scheduler otherwise batches at the top, become a chain of dependent round trips)
     const long long pt0 = clock64(), pw0 = wall_clock64();
     CItem it;  // derived from the workgroup index (an XCD walks consecutive items of one net): no dependent load
-    int vi = 0;
+    int vi = 0, item_in_slot = 0;
     {
         // net-major by default: an XCD walks consecutive ranges of one net and shares its packed kernels through L2.
         // Range-major where the nets read the SAME input (Conv_0: K nets per staged minibatch): an XCD then holds a few
@@ -78,6 +98,7 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
         it.net = slot / a.nb;
         it.bb = slot - it.net * a.nb;
         it.var = vi;
+        item_in_slot = rr;
         const int r = rr - a.r_begin[vi], npos_v = a.var[vi].OH * a.var[vi].OW, R = a.r_cnt[vi];
         const int base = npos_v / R, rem = npos_v - base * R;
         it.p0 = r * base + min(r, rem);
@@ -133,10 +154,12 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     const unsigned long wb0 = (unsigned long)a.wq + (unsigned long)it.net * a.wq_stride + (unsigned long)v.w_off;
     const int NSS = a.KH * a.NCC;
 
-    auto stage = [&](int ss, unsigned buf, int first, int step) {
-        const int kh = ss / a.NCC, cc = ss - kh * a.NCC;
+    auto stage_w = [&](int ss, unsigned buf, int first, int step) {  // the packed kernels of superstep ss
         const unsigned long wsrc = wb0 + (unsigned long)ss * WB;
         for (int i = first; i < NWP; i += step) dma16(lane16, wsrc + (unsigned long)i * 1024, buf + i * 1024);
+    };
+    auto stage_x = [&](int ss, unsigned buf, int first, int step) {  // its pixel strips
+        const int kh = ss / a.NCC, cc = ss - kh * a.NCC;
         const unsigned long so_ = (unsigned long)kh * (unsigned long)a.row_bytes + (unsigned long)cc * 1024;
 #pragma unroll
         for (int r = 0; r < CP_MAX_STRIPS; ++r) {
@@ -150,6 +173,11 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
             }
         }
     };
+    auto stage = [&](int ss, unsigned buf, int first, int step) {
+        stage_w(ss, buf, first, step);
+        stage_x(ss, buf, first, step);
+    };
+    const bool waits = CHAIN && ch->wait_flags != nullptr;  // wave-uniform
 
     // epilogue operands that only depend on the item: requested now, used after the loop
     const int co = ct * 32 + cl;
@@ -178,16 +206,26 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
         // Superstep ss + ring - 1 goes into the buffer superstep ss - 1 was read from, right after barrier ss.  Before
         // barrier ss a loader only needs ITS copies of superstep ss to have landed: vmcnt counts in issue order, so it
         // waits until at most the copies of the younger supersteps (cnt per superstep, the same every time) are left.
-        int cnt = (NWP - wave + 3) / 4;
+        int cnt = (NWP - wave + 3) / 4, cnt_x = 0;
 #pragma unroll
-        for (int r = 0; r < CP_MAX_STRIPS; ++r) cnt += ((nx[r] - wave + 3) / 4) * NPA;
+        for (int r = 0; r < CP_MAX_STRIPS; ++r) cnt_x += ((nx[r] - wave + 3) / 4) * NPA;
+        cnt += cnt_x;
         const int ahead = ring - 1;
-        for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
+        if (waits) {
+            // the packed kernels do not depend on the producers: on their way while compute wave 0 polls the flags
+            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_w(s0, lds0 + s0 * stage_bytes, wave, 4);
+            __builtin_amdgcn_s_barrier();  // (B) the acquire behind the poll has completed
+            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_x(s0, lds0 + s0 * stage_bytes, wave, 4);
+        } else {
+            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
+        }
         int nbuf = ahead == 2 ? 2 : 1;  // buffer of superstep ss + ahead
         long long l_wait = 0, l_bar = 0, l_issue = 0;
         for (int ss = 0; ss < NSS; ++ss) {
             const long long c0 = prof ? clock64() : 0;
-            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? cnt : 0);
+            // (issue order behind a hand-off: kernels 0, kernels 1, pixels 0, pixels 1 -- superstep 0 has landed once at most
+            // the pixel copies of superstep 1 are outstanding)
+            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? (waits && ss == 0 ? cnt_x : cnt) : 0);
             const long long c1 = prof ? clock64() : 0;
             __builtin_amdgcn_s_barrier();  // everybody's copies of ss have landed; nobody still reads the buffer re-filled next
             const long long c2 = prof ? clock64() : 0;
@@ -216,6 +254,25 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     // ---- compute waves -------------------------------------------------------------------------------------------
     // Fragment reads of tile-step u + 1 are issued one per gap BETWEEN the MFMAs of tile-step u (the wave issues an MFMA,
     // is free for the ~32 cycles it runs, and blocks at the next, dependent one): sched_barrier pins that order.
+    if (waits && !loader) {
+        if (wave8 == 0) {
+            // producer rows this item reads: padded input rows [first, last] -> unpadded producer rows -> their ranges
+            const int oh_last = (p0 + np - 1) / OW;
+            const int first = oh0 * a.S + v.in_off_h - ch->p_lo_h, last = oh_last * a.S + v.in_off_h + a.KH - 1 - ch->p_lo_h;
+            const int ya = max(first, 0), yb = min(last, ch->p_OH - 1);
+            const int pa = ya * ch->p_OW, pb_ = (yb + 1) * ch->p_OW - 1;
+            const int big = ch->p_rem * (ch->p_base + 1);  // positions covered by the ranges that are one longer
+            const int r_lo = pa < big ? pa / (ch->p_base + 1) : ch->p_rem + (pa - big) / ch->p_base;
+            const int r_hi = pb_ < big ? pb_ / (ch->p_base + 1) : ch->p_rem + (pb_ - big) / ch->p_base;
+            const long long cw0 = prof ? clock64() : 0;
+            chain_wait(ch->wait_flags + (long)in_slot * ch->p_R, r_lo, r_hi, epoch, ch->err);
+            if (prof && t == 0) {  // (the loader row's spare slots: cycles in the poll + acquire, wall clock behind it, flags polled)
+                long long* pr = prof + 8L * 4096 + (long)b * 8;
+                pr[4] = clock64() - cw0; pr[5] = wall_clock64(); pr[6] = r_hi - r_lo + 1;
+            }
+        }
+        __builtin_amdgcn_s_barrier();  // (B)
+    }
     int cbuf = 0;
     for (int ss = 0; ss < NSS && !loader; ++ss) {
         const unsigned cur_off = cbuf * stage_bytes;
@@ -383,8 +440,11 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = *LDS_PTR(const u32x4, R + pl * 2048 + j * 1024 + rsw);
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 x = *LDS_PTR(const u32x4, R + pl * 2048 + j * 1024 + rsw);
+                    if (CHAIN && ch->done_flags) store16_sc1(O + (unsigned long)pl * a.CO * 64 + j * 1024, x);  // handed off in-launch
+                    else *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = x;
+                }
         }
         if (a.out_f32) {
             float* F = a.out_f32 + (long)out_slot * a.f32_slot + (((long)yh * a.f32_W + yw) * a.CO + ct * 32) * 32 + lane * 4;
@@ -393,6 +453,14 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
                 *reinterpret_cast<f32x4*>(F + j * 256) = *LDS_PTR(const f32x4, R + r_f32 + j * 1024 + fsw);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next one overwrites it
+    }
+    if (CHAIN) {
+        // every wave's stores have been acknowledged and nobody still uses the turn-around tiles: the item's flag goes up
+        // (a relaxed agent-scope store; the payload went out write-through), the next layer's body may refill LDS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ch->done_flags && t == 0)
+            __hip_atomic_store(ch->done_flags + (long)out_slot * a.items_per_slot + item_in_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (prof && t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -293,6 +293,9 @@ struct idqn_handle_s {
     std::map<std::tuple<int, int, int, int>, FwdPlan> fwd_plans;  // (role, n_nets, nb, target workgroups)
     std::map<std::tuple<int, int, int>, WgradPlan> wgrad_plans;   // (layer, nb, position chunks)
     int npc_used[3] = {0, 0, 0};  // position chunks (= slabs per head) the weight-gradient launches of THIS step wrote
+    // chained conv launches (convp_chain.hip): [0] the step's epoch (bumped by the staging launch), [32] err, [64...) flags
+    unsigned* chain_ws = nullptr;
+    int n_cus = 256;  // CUs of the device (a chained launch needs every workgroup resident)
     float* cprof = nullptr;  // debug (IDQN_CONV_PROF=role): phase stamps of one plane conv launch
     int cprof_role = -1;
     int npc[3], pos_per_chunk[3];
@@ -462,9 +465,15 @@ int cnn_setup(idqn_handle_s* h) {
     if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
     if (h->planes && getenv("IDQN_CONV_PROF")) {
         h->cprof_role = atoi(getenv("IDQN_CONV_PROF"));
-        if ((rc = alloc_zero(&h->cprof, 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
+        // role 10 = the chained forward launch: one [2][4096][8] block of stamps per layer
+        if ((rc = alloc_zero(&h->cprof, (h->cprof_role == 10 ? 3 : 1) * 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
     }
     if (h->planes) {
+        float* ws = nullptr;
+        if ((rc = alloc_zero(&ws, 64 + 2L * 4096, h, "chain_ws"))) return rc;
+        h->chain_ws = reinterpret_cast<unsigned*>(ws);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
         if ((rc = alloc_zero16(&h->da2p, (long)K * nb * h->gda2.block * 3, h, "da2p"))) return rc;
         if ((rc = alloc_zero16(&h->da1p, (long)K * nb * h->gda1.block * 3, h, "da1p"))) return rc;
@@ -1032,7 +1041,7 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
         }
     }
     a.n_jobs = nj;
-    if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; }
+    if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; a.epoch = h->chain_ws; }
     static const int part = getenv("IDQN_STAGE_PART") ? atoi(getenv("IDQN_STAGE_PART")) : 0;  // timing experiments only
     if (part == 1) return convp_launch_stage(a, a.n_prep_blocks, q);
     if (part == 2) { const int np = a.n_prep_blocks; a.n_prep_blocks = 0; (void)np; return convp_launch_stage(a, (int)blocks, q); }
@@ -1208,6 +1217,57 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
                              pw->lds, q, conv_prof(h, s, role, pf));
 }
 
+// The three forward convs of the training set as ONE chained launch (convp_chain.hip) when the plans allow it;
+// *done = false: nothing was launched, the caller runs the three launches.  Opt-in (IDQN_CONV_CHAIN=1): measured
+// neutral (every consumer item depends on 3-9 producer items that all finish together, so the layers stay
+// in lockstep and the hand-offs cost what the kernel boundaries did), and three launches have no residency condition.
+#define CHAIN_FLAG_WORDS 4096  // per layer
+int planes_chain_fwd(idqn_handle_s* h, NetSet& s, int nb, hipStream_t q, bool* done) {
+    *done = false;
+    static const bool chain_on = getenv("IDQN_CONV_CHAIN") && atoi(getenv("IDQN_CONV_CHAIN")) != 0;
+    if (!chain_on || &s != &h->train || !h->chain_ws) return IDQN_OK;
+    CChainArgs c;
+    memset(&c, 0, sizeof(c));
+    RoleGeom g[3];
+    FwdPlan* pl[3];
+    int NT[3], n_wg = 0, rc;
+    size_t lds = 0;
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = conv_args(h, s, i, nb, cu_budget(), c.a[i], g[i], pl[i]))) return rc;
+        NT[i] = pl[i]->NT;
+        c.stage_bytes[i] = (unsigned)pl[i]->stage; c.ring[i] = pl[i]->ring; c.n_items[i] = pl[i]->n_items;
+        c.mask_off[i] = (unsigned)convp_fwd_mask_off(pl[i]->stage, NT[i], pl[i]->ring, c.a[i].out3 != nullptr, c.a[i].out_f32 != nullptr);
+        c.prof[i] = (h->cprof && h->cprof_role == 10) ? (long long*)h->cprof + (long)i * 2 * 8 * 4096 : conv_prof(h, s, i, pl[i]);
+        n_wg = std::max(n_wg, pl[i]->n_items);
+        lds = std::max(lds, pl[i]->lds);
+        if (g[i].n_var != 1 || pl[i]->n_items > CHAIN_FLAG_WORDS) return IDQN_OK;
+    }
+    // geometry the chain kernel is instantiated for, every workgroup resident at once
+    const bool nature = g[0].NPA == 1 && g[0].CT == 1 && g[0].NQ == 2 && g[1].NPA == 3 && g[1].CT == 2 && g[1].NQ == 4 &&
+                        g[2].NPA == 3 && g[2].CT == 2 && g[2].NQ == 3;
+    if (!nature || !convp_chain_fwd_built(NT) || n_wg > std::min(256, h->n_cus)) return IDQN_OK;
+    const ActGeom* gbuf[3] = {&h->ga1, &h->ga2, &h->ga3};  // output buffer of layer i = input buffer of layer i + 1
+    for (int i = 0; i < 3; ++i) {
+        ChainHand& hd = c.hand[i];
+        hd.err = h->chain_ws + 32;
+        hd.done_flags = i < 2 ? h->chain_ws + 64 + i * CHAIN_FLAG_WORDS : nullptr;
+        if (i == 0) continue;
+        const ConvL& lp = h->conv[i - 1];
+        const int npos = lp.OH * lp.OW, R = pl[i - 1]->r_cnt[0];
+        hd.wait_flags = h->chain_ws + 64 + (i - 1) * CHAIN_FLAG_WORDS;
+        hd.p_OW = lp.OW; hd.p_OH = lp.OH; hd.p_lo_h = gbuf[i - 1]->lo_h;
+        hd.p_R = R; hd.p_base = npos / R; hd.p_rem = npos % R;
+        // one lane per producer flag: an item's input rows may overlap at most 64 producer ranges
+        const ConvL& l = h->conv[i];
+        const int np_max = cdiv(l.OH * l.OW, pl[i]->r_cnt[0]);
+        const int out_rows = (np_max + l.OW - 2) / l.OW + 1, in_rows = (out_rows - 1) * l.S + l.K;
+        if (hd.p_base < 1 || (long)in_rows * lp.OW / hd.p_base + 2 > 64) return IDQN_OK;
+    }
+    c.epoch = h->chain_ws;
+    *done = true;
+    return convp_launch_chain_fwd(c, NT, n_wg, lds, q);
+}
+
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
 int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q, bool with_dense0 = true) {
     const int nb = cdiv(B, 32);
@@ -1216,7 +1276,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         static const char* nm[3] = {"conv0 fwd", "conv1 fwd", "conv2 fwd"};
         int rc = planes_stage(h, s, st, st2, B, nb, q);
         tl_mark(h, q, "stage (pixels + kernel packing)");
-        for (int i = 0; i < 3 && !rc; ++i) { rc = planes_conv(h, s, i, nb, q); tl_mark(h, q, nm[i]); }
+        bool chained = false;
+        if (!rc) rc = planes_chain_fwd(h, s, nb, q, &chained);
+        if (chained) tl_mark(h, q, "conv0-2 fwd (chained)");
+        for (int i = 0; i < 3 && !rc && !chained; ++i) { rc = planes_conv(h, s, i, nb, q); tl_mark(h, q, nm[i]); }
         if (rc) return rc;
     } else {
         PrepArgs pa;
@@ -1462,6 +1525,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
+    ta.chain_err = h->chain_ws ? h->chain_ws + 32 : nullptr;
     static const bool stage_part = getenv("IDQN_STAGE_PART") && atoi(getenv("IDQN_STAGE_PART")) == 1;  // (timing experiment: no packing blocks)
     ta.bcinv_done = (h->planes && !stage_part) ? 1 : 0;
     h->wt_ready = false;

@@ -2,6 +2,8 @@
 (the switches are read once per process) and compared with the default build of the step.
 
   IDQN_STEP_GRAPH=1   the plain step replayed as a hipGraph          -> bit-identical to the eager launches
+  IDQN_CONV_CHAIN=1   the three forward convs as ONE launch with per-item flag hand-offs (csrc/convp_chain.hip)
+                      -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
   IDQN_NO_PAIR=1      conv data / weight gradients as two launches   -> same losses, parameters within fp32 round-off
                       (the weight gradient is cut into a different number of position chunks, i.e. summed in another order)
   IDQN_ACT_POLL=0     acting result by copy + synchronisation        -> same greedy actions as the polled mailbox
@@ -42,7 +44,7 @@ def batch():
                  torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
                  torch.from_numpy((rng.random(32) < 0.1).astype(np.uint8)).cuda())
 bs = [batch(), batch()]  # two buffer sets, used in turn like the replay buffer's staging sets
-losses = [agent._learn(bs[i % 2]).cpu().numpy().astype(np.float64).tolist() for i in range(6)]
+losses = [agent._learn(bs[i % 2]).cpu().numpy().astype(np.float64).tolist() for i in range(int(os.environ.get("SW_STEPS", "6")))]
 state = rng.integers(0, 256, (84, 84, 4), dtype=np.uint8)
 acts = [int(agent._best_action(0, k, state)) for k in range(5)]
 flat = agent._flat(agent._online)
@@ -69,6 +71,17 @@ def test_step_graph_replay_is_bit_identical(default_run):
     got = _run(IDQN_STEP_GRAPH="1")
     assert got["losses"] == default_run["losses"]
     assert got["probe"] == default_run["probe"]
+
+
+def test_chained_forward_convs_are_bit_identical():
+    # 60 steps: every hand-off of every step has to deliver the producer's bytes (a stale or early read changes the bits
+    # of everything downstream); the losses would be NaN had a bounded spin given up (k_td_dh reads the chain's err word)
+    want = _run(SW_STEPS="60")
+    got = _run(SW_STEPS="60", IDQN_CONV_CHAIN="1")
+    assert np.isfinite(np.asarray(got["losses"])).all()
+    assert got["losses"] == want["losses"]
+    assert got["probe"] == want["probe"]
+    assert got["acts"] == want["acts"]
 
 
 def test_unpaired_conv_backward_matches(default_run):
