@@ -55,6 +55,12 @@ SYMBOLS = {
     "idqn_apply_adam": (C.c_int, [_P, _P]),
     "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
     "sumtree_set_one": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]),
+    "sampler_mailbox_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
+    "sampler_mailbox_destroy": (C.c_int, [_P]),
+    "sumtree_query_host": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32), _P]),
+    "sampler_prioritized_add": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double, _P]),
+    "sampler_prioritized_remove": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     "per_sample_leaves": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     "per_importance_weights": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_double, _P, _P]),
     "per_priorities_from_td": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, _P, _P]),

@@ -4,9 +4,16 @@ Drop-in for the reference's ``slimdqn/sample_collection/samplers.py``.  What sta
 exactly what is integer bookkeeping in the reference too: the dense ``index -> key`` array with
 swap-remove (``samplers.py:26-37``) and the ``numpy.random.Generator`` whose stream defines the
 sampled indices (``:17,43,110``) -- keeping numpy's generator IS bit-parity of the index stream.
-Priorities and the inverse-CDF query run on the device (``sum_tree.SumTree``).
+Priorities and the inverse-CDF query run on the device (``sum_tree.SumTree``).  The prioritized sampler also keeps
+``index -> key`` in HBM (written by the same launches that write the priorities), so that ``sample`` is ONE launch and
+ONE host read (leaves -> keys on the device, root and status in the same mailbox) and ``remove`` reads the moved priority
+on the device instead of the host.  The host dict / list stay as the mirror the reference's tests reach into and as the
+argument check of ``remove`` (``samplers.py:27``); ``key -> index`` has no device consumer.
 """
 import numpy as np
+import torch
+
+from slimdqn import _hip
 
 from slimdqn.sample_collection import ReplayItemID, sum_tree
 
@@ -71,13 +78,22 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         self._max_capacity = max_capacity
         self._priority_exponent = priority_exponent
         self._sum_tree = sum_tree.SumTree(self._max_capacity)
+        self._i2k_dev = torch.zeros(self._max_capacity, dtype=torch.int32, device="cuda")  # index -> key, device copy
         super().__init__(seed=seed)
 
     def add(self, key: ReplayItemID, priority: float) -> None:
         index = self._map.add(key)
         if priority is None:
             priority = 0.0
-        self._sum_tree.set(index, 0.0 if priority == 0.0 else priority**self._priority_exponent)
+        value = 0.0 if priority == 0.0 else priority**self._priority_exponent
+        tree = self._sum_tree
+        assert value >= 0.0, "Values must be positive."
+        if not 0 <= index < self._max_capacity:
+            raise IndexError("sum tree index out of range")
+        tree.max_recorded_priority = max(tree.max_recorded_priority, value)
+        # one launch: index_to_key[index] = key and tree.set(index, value)   (samplers.py:62-66)
+        _hip.check(_hip.lib().sampler_prioritized_add(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._i2k_dev), int(index),
+                                                      int(key), float(value), _hip.current_stream()), "sampler_prioritized_add")
 
     def update(self, keys, priorities) -> None:
         if not isinstance(keys, np.ndarray):
@@ -87,19 +103,30 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         self._sum_tree.set(local, shaped)
 
     def remove(self, key: ReplayItemID) -> None:
+        assert key in self._map.key_to_index, ValueError(f"Key {key} not found.")
         hole = self._map.key_to_index[key]
         last = len(self._map) - 1
-        if hole == last:
-            self._sum_tree.set(hole, 0.0)
-        else:  # the last entry's priority moves into the hole, one two-element set (samplers.py:98-102)
-            self._sum_tree.set(np.asarray([hole, last], dtype=np.int32),
-                               np.asarray([self._sum_tree.get(last), 0.0]))
+        # one launch, no host read: the last entry's priority moves into the hole by the two-leaf set
+        # {hole: leaf[last], last: 0} (samplers.py:98-102; hole == last: {hole: 0}), its key in the device map
+        tree = self._sum_tree
+        _hip.check(_hip.lib().sampler_prioritized_remove(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._i2k_dev), int(hole),
+                                                         int(last), _hip.current_stream()), "sampler_prioritized_remove")
         self._map.remove(key)
 
     def sample(self, size: int):
-        root = self._sum_tree.root
+        assert self._map.index_to_key, ValueError("No keys to sample from.")
+        # `Generator.uniform(0.0, root, size)` is 0.0 + root * next_double per element (samplers.py:110): the host draws the
+        # doubles (the PCG64 stream IS the parity), the device multiplies by the root it holds -- no read of the root first
+        before = self._rng_key.bit_generator.state
+        u = self._rng_key.random(size)
+        _, keys, root, status = self._sum_tree.query_host(u, scale_by_root=True, index_to_key=self._i2k_dev)
         if root == 0.0:
-            # the reference's branch here is `super().sample(size).keys` -> AttributeError (samplers.py:106-108)
+            # the reference's branch here is `super().sample(size).keys` -> AttributeError (samplers.py:106-108), after
+            # drawing `integers` from the generator: replay exactly that on the restored stream
+            self._rng_key.bit_generator.state = before
+            super().sample(size)
             raise AttributeError("'numpy.ndarray' object has no attribute 'keys'")
-        targets = self._rng_key.uniform(0.0, root, size=size)
-        return self._map.keys_at(self._sum_tree.query(targets))
+        if status & 1:
+            raise ValueError(f"Targets must be in the interval [0.0, {root}).")
+        assert not (status & 2), "sum tree traversal: target not below its node (sum_tree.py:81)"
+        return keys

@@ -6,6 +6,7 @@ arithmetic -- including the order of the fp64 additions, which the reference inh
 ``np.unique`` + ``np.add.at`` -- runs in ``csrc/sumtree.hip``; this file only validates arguments,
 moves the (tiny) index / value vectors to the device and maps status codes to exceptions.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -14,6 +15,7 @@ import torch
 from slimdqn import _hip
 
 _MAX_SET = 4096
+_MAIL_N = 4096  # targets per query launch through the host mailbox
 
 
 class SumTree:
@@ -27,6 +29,16 @@ class SumTree:
         self._scratch = torch.empty(_MAX_SET * 2, dtype=torch.float64, device="cuda")
         self._status = torch.zeros(1, dtype=torch.int32, device="cuda")
         self.max_recorded_priority = 1.0
+        self._mailbox = None   # host mailbox of query / sample (created on first use)
+        self._pins = None      # pinned staging of `set`: two (indices, values) sets used in turn
+
+    def __del__(self):
+        mb, self._mailbox = getattr(self, "_mailbox", None), None
+        if mb is not None:
+            try:
+                _hip.lib().sampler_mailbox_destroy(mb)
+            except Exception:  # interpreter shutdown
+                pass
 
     # the reference's tests read ``_nodes`` directly (tests/test_sum_tree.py:34-37)
     @property
@@ -34,12 +46,28 @@ class SumTree:
         return self._nodes_dev.cpu().numpy()
 
     def _launch_set(self, idx: np.ndarray, val: np.ndarray) -> None:
-        i_dev = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).cuda()
-        v_dev = torch.from_numpy(np.ascontiguousarray(val, dtype=np.float64)).cuda()
+        # indices and values travel through pinned memory by asynchronous copies (a pageable upload blocks the host for
+        # ~20 us each); a staging set is rewritten only after the event recorded behind the launch that read it
+        if self._pins is None:
+            self._pins = [[torch.empty(_MAX_SET, dtype=torch.int32).pin_memory(), torch.empty(_MAX_SET, dtype=torch.float64).pin_memory(),
+                           torch.empty(_MAX_SET, dtype=torch.int32, device="cuda"), torch.empty(_MAX_SET, dtype=torch.float64, device="cuda"),
+                           None] for _ in range(2)]
+            self._pin_turn = 0
+        pi, pv, i_dev, v_dev, ev = ent = self._pins[self._pin_turn]
+        self._pin_turn ^= 1
+        if ev is not None:
+            ev.synchronize()
+        n = int(idx.size)
+        pi.numpy()[:n] = idx
+        pv.numpy()[:n] = val
+        i_dev[:n].copy_(pi[:n], non_blocking=True)
+        v_dev[:n].copy_(pv[:n], non_blocking=True)
         _hip.check(
             _hip.lib().sumtree_set(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(i_dev), _hip.ptr(v_dev),
                                    int(idx.size), _hip.ptr(self._scratch), _hip.current_stream()),
             "sumtree_set")
+        ent[4] = ent[4] or torch.cuda.Event()
+        ent[4].record()
 
     def set(self, indices, values) -> None:
         if isinstance(indices, (int, np.integer)) and isinstance(values, (int, float, np.floating)):
@@ -96,15 +124,37 @@ class SumTree:
                                             _hip.current_stream()), "sumtree_query")
         return out
 
+    def query_host(self, values: np.ndarray, scale_by_root: bool = False, index_to_key=None):
+        """ONE launch + ONE host read (a polled mailbox in mapped host memory): the leaves of `values` (targets, or --
+        scale_by_root -- uniforms in [0, 1) turned into numpy's ``uniform(0, root)`` on the device), the keys
+        ``index_to_key[leaf]`` when a device map is given, the root and the status bits."""
+        vals = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        lib = _hip.lib()
+        if self._mailbox is None:
+            mb = C.c_void_p()
+            _hip.check(lib.sampler_mailbox_create(_MAIL_N, C.byref(mb)), "sampler_mailbox_create")
+            self._mailbox = mb
+        leaves = np.empty(vals.size, np.int32)
+        keys = np.empty(vals.size, np.int32) if index_to_key is not None else None
+        root, status, st_all = C.c_double(), C.c_int32(), 0
+        for lo in range(0, vals.size, _MAIL_N):
+            n = min(_MAIL_N, vals.size - lo)
+            _hip.check(lib.sumtree_query_host(
+                _hip.ptr(self._nodes_dev), self._depth, C.c_void_p(vals[lo:].ctypes.data), n, 1 if scale_by_root else 0,
+                _hip.ptr(index_to_key), self._mailbox, C.c_void_p(leaves[lo:].ctypes.data),
+                C.c_void_p(keys[lo:].ctypes.data) if keys is not None else None, C.byref(root), C.byref(status),
+                _hip.current_stream()), "sumtree_query_host")
+            st_all |= status.value
+        return leaves, keys, root.value, st_all
+
     def query(self, targets):
         if isinstance(targets, (int, float)):
             targets = np.asarray([targets], np.float64)
         targets = np.asarray(targets)
-        t_dev = torch.from_numpy(np.ascontiguousarray(targets.reshape(-1), dtype=np.float64)).cuda()
-        self._status.zero_()
-        out = self.query_device(t_dev).cpu().numpy().reshape(targets.shape)
-        status = int(self._status.item())
+        if targets.size == 0:
+            return np.empty(targets.shape, np.int32)
+        leaves, _, root, status = self.query_host(targets)
         if status & 1:
-            raise ValueError(f"Targets must be in the interval [0.0, {self.root}).")
+            raise ValueError(f"Targets must be in the interval [0.0, {root}).")
         assert not (status & 2), "sum tree traversal: target not below its node (sum_tree.py:81)"
-        return out
+        return leaves.reshape(targets.shape)

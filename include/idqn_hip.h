@@ -204,6 +204,31 @@ int sumtree_get(const double* nodes_dev, int32_t depth, const int32_t* indices_d
 int sumtree_query(const double* nodes_dev, int32_t depth, const double* targets_dev, int32_t n,
                   int32_t* out_dev, int32_t* status_dev, void* stream);
 
+/* SumTree.query with ONE host read (sum_tree.py:58-102 returns numpy; samplers.py:105-116 `sample` needs root, leaves and
+ * the status of the range check on the host): the n float64 values at values_host are the targets, or -- scale_by_root --
+ * the uniforms u_i of the host's PCG64, turned into numpy's `Generator.uniform(0.0, root)` = 0.0 + root * u_i on the device
+ * (samplers.py:110).  One launch reads them from a mapped host mailbox, descends, maps leaf -> key through
+ * index_to_key_dev (int32 [capacity], NULL: keys = leaves) and writes leaves, keys, root and status back; the host polls
+ * the mailbox's sequence number -- no device->host copy, no stream synchronisation, no separate read of the root.
+ * status: bit 0 a target outside [0, root) (-> ValueError), bit 1 the per-level assert (:81).  root == 0: leaves are 0.  */
+int sampler_mailbox_create(int32_t max_n, void** mailbox_out);
+int sampler_mailbox_destroy(void* mailbox);
+int sumtree_query_host(const double* nodes_dev, int32_t depth, const double* values_host, int32_t n,
+                       int32_t scale_by_root, const int32_t* index_to_key_dev, void* mailbox,
+                       int32_t* leaves_out_host, int32_t* keys_out_host, double* root_out_host,
+                       int32_t* status_out_host, void* stream);
+/* PrioritizedSamplingDistribution.add (samplers.py:62-66): index_to_key[index] = key and tree.set(index, value) for the
+ * new last index, ONE launch.  The inverse map key -> index stays a host dict: its only consumers are host-called
+ * operations whose arguments are host keys (remove, update). */
+int sampler_prioritized_add(double* nodes_dev, int32_t depth, int32_t* index_to_key_dev, int32_t index, int32_t key,
+                            double value, void* stream);
+/* PrioritizedSamplingDistribution.remove (samplers.py:89-103) for hole = key_to_index[key], last = len - 1: the last
+ * entry's priority moves into the hole by the two-leaf set {hole: leaf[last], last: 0.0} (one leaf {hole: 0.0} when
+ * hole == last), its key by index_to_key[hole] = index_to_key[last] (:31-35) -- ONE launch, the moved priority is read on
+ * the device (the reference reads it with tree.get, :99).  index_to_key_dev may be NULL (tree only). */
+int sampler_prioritized_remove(double* nodes_dev, int32_t depth, int32_t* index_to_key_dev, int32_t hole, int32_t last,
+                               void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Prioritized-replay write-back: an EXTENSION with no reference counterpart (the reference's sample() drops the
  * sampled keys, replay_buffer.py:222-230, and its loss has no importance weights, idqn.py:111-112) -- SURVEY 8f-4,

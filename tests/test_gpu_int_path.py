@@ -205,3 +205,65 @@ def test_frame_ring_grows_when_elementless_transitions_pile_up(frame):
     x, y = a.sample(), b.sample()
     np.testing.assert_array_equal(np.asarray(x.state), y.state)
     np.testing.assert_array_equal(np.asarray(x.action), y.action)
+
+
+@pytest.mark.parametrize("capacity,alpha", [(7, 1.0), (64, 0.6), (1000, 1.0), (1 << 17, 0.5)])
+def test_prioritized_sampler_device_paths_match_the_oracle(capacity, alpha):
+    """Round 4: add / remove / sample run as single launches with the index -> key map in HBM (no host read of the moved
+    priority, one mailbox read per sample).  A long random add / remove / update / sample sequence on the product class
+    against the oracle (itself pinned by the reference-captured traces): node arrays bit for bit after every operation on
+    the small trees, sampled keys identical, the device map equal to the host mirror -- holes at both ends, hole == last,
+    zero priorities, duplicate updates."""
+    from oracle.samplers_ref import PrioritizedRef
+
+    Prioritized = _classes()[2]
+    a, b = Prioritized(9, capacity, alpha), PrioritizedRef(9, capacity, alpha)
+    rng = np.random.default_rng(capacity)
+    live, next_key, n_ops = [], 0, 400 if capacity <= 1000 else 150
+    check_every = capacity <= 1000
+    for op in range(n_ops):
+        r = rng.random()
+        if (r < 0.45 and len(live) < capacity) or len(live) < 2:
+            pr = float(rng.choice([0.0, rng.random() * 3, rng.random() * 1e-3, 5.0]))
+            a.add(next_key, priority=pr)
+            b.add(next_key, priority=pr)
+            live.append(next_key)
+            next_key += int(rng.integers(1, 4))
+        elif r < 0.70:
+            k = live.pop(int(rng.choice([0, len(live) - 1, rng.integers(len(live))])))
+            a.remove(k)
+            b.remove(k)
+        elif r < 0.85:
+            ks = np.asarray(rng.choice(live, size=min(len(live), int(rng.integers(1, 6)))), dtype=np.int32)  # may repeat a key
+            ps = np.where(rng.random(ks.size) < 0.2, 0.0, rng.random(ks.size) * 2)
+            a.update(ks, ps)
+            b.update(ks, ps)
+        elif b.tree.root > 0.0:
+            n = int(rng.integers(1, 40))
+            np.testing.assert_array_equal(a.sample(n), b.sample(n))
+        if check_every or op == n_ops - 1:
+            np.testing.assert_array_equal(a._sum_tree._nodes, b.tree.nodes, err_msg=f"op {op}")
+            assert list(a._index_to_key) == list(b.index_to_key)
+            np.testing.assert_array_equal(a._i2k_dev[: len(live)].cpu().numpy(), np.asarray(b.index_to_key, np.int32))
+    with pytest.raises(AssertionError):
+        a.remove(10**8)
+
+
+def test_prioritized_sampler_empty_tree_branch_consumes_the_stream_like_the_reference():
+    """root == 0: the reference falls into `super().sample(size).keys` (AttributeError) AFTER drawing `integers` from the
+    generator (samplers.py:106-108).  The product draws its uniforms before it learns the root, so it has to rewind and
+    replay that draw: the generator states must be equal afterwards."""
+    from oracle.samplers_ref import PrioritizedRef
+
+    Prioritized = _classes()[2]
+    a, b = Prioritized(4, 16, 1.0), PrioritizedRef(4, 16, 1.0)
+    for k in range(3):
+        a.add(k, priority=0.0)
+        b.add(k, priority=0.0)
+    for s in (a, b):
+        with pytest.raises(AttributeError):
+            s.sample(5)
+    assert a._rng_key.bit_generator.state == b.rng.bit_generator.state
+    a.update(np.asarray([1], np.int32), np.asarray([2.0]))
+    b.update(np.asarray([1], np.int32), np.asarray([2.0]))
+    np.testing.assert_array_equal(a.sample(8), b.sample(8))
