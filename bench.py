@@ -164,6 +164,37 @@ def sampling_leg(reps=300):
                                       "sumtree_set"))
         out[f"sumtree_B{B}"] = {"query_us": dq * 1e6, "set_us": ds * 1e6, "leaves": 1 << 20, "depth": depth,
                                 "query_GBps": B * (depth - 1) * 8 / dq / 1e9, "set_GBps": B * depth * 16 / ds / 1e9}
+    # reference protocol on the product class (samplers.py:52-116): host wall clock per call, results on the host
+    import time
+
+    from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution
+
+    ps = PrioritizedSamplingDistribution(0, 1 << 20, 1.0)
+    for k in range(4096):
+        ps.add(k, priority=float(pri[k]))
+    torch.cuda.synchronize()
+
+    def wall(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    nk = [4096]
+
+    def add_remove():
+        ps.remove(nk[0] - 4096)
+        ps.add(nk[0], priority=0.5)
+        nk[0] += 1
+
+    out["prioritized_protocol"] = {"sample_B32_us": wall(lambda: ps.sample(32), 200), "sample_B256_us": wall(lambda: ps.sample(256), 200),
+                                   "remove_plus_add_us": wall(add_remove, 200), "leaves": 1 << 20,
+                                   "what": "PrioritizedSamplingDistribution on a 2^20-leaf HBM tree, host wall clock per call, keys "
+                                           "returned to the host: sample = one launch + one polled mailbox read; remove + add = two "
+                                           "launches, no host read"}
     out["what"] = ("replay_gather_stacked out of a 2^15-frame ring (bytes = frames read + stacks written); sum tree of 2^20 "
                    "leaves: query = B x 20 dependent 8-byte reads, set = B x 21 read-modify-writes; latency-bound, bytes for scale")
     return out

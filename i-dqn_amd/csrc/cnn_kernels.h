@@ -263,6 +263,10 @@ struct DenseFwdArgs {
     int n_nets, nb, NS, n_jt, F, J;
     int net_rot;  // work item n covers net (n + net_rot) % n_nets: the training set runs its target nets first, so that
                   // the online Dense_0 kernel is the most recently streamed 79 MB when the backward pass re-reads it
+    int G;        // k_dense0_fwd3: 4 = the four waves of a workgroup take four CONSECUTIVE splits of one (net, block, column
+                  // tile) and add their accumulators through LDS in split order before anything is written: part holds
+                  // NS / 4 slabs per (net, block) instead of NS (a quarter of the partial traffic, k_hidden adds a quarter
+                  // of the slabs).  1 = one slab per split (NS not a multiple of 4; 64 KB of dynamic LDS not requested).
 };
 
 __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
@@ -334,13 +338,25 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 __device__ __forceinline__ bf16x8 planes8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, (u32x4){p[0], p[1], p[2], p[3]}); }
 
 __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float d3_red[];  // G == 4: [wave][tile q][register r][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
     long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;
-    const int jt = (int)(item % a.n_jt);
-    item /= a.n_jt;
-    const int s = (int)(item % a.NS);
-    item /= a.NS;
+    int jt, s;
+    if (a.G == 4) {  // workgroup = (net, block, group of 4 splits, column tile); wave = split inside the group
+        item = (long)blockIdx.x;
+        if (item * 4 >= a.n_items) return;
+        jt = (int)(item % a.n_jt);
+        item /= a.n_jt;
+        const int nsg = a.NS / 4;
+        s = (int)(item % nsg) * 4 + wave;
+        item /= nsg;
+    } else {
+        if (item >= a.n_items) return;
+        jt = (int)(item % a.n_jt);
+        item /= a.n_jt;
+        s = (int)(item % a.NS);
+        item /= a.NS;
+    }
     const int bb = (int)(item % a.nb);
     const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
     // INTERLEAVED split-K: split s takes the 16-row k-steps s, s + NS, s + 2 NS, ...  The NS workgroups of a net then
@@ -408,6 +424,23 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
 #undef D3_LOAD
 #undef D3_TILE
 #undef D3_MMA
+    if (a.G == 4) {
+        // the four splits of the group meet in LDS; wave w then owns accumulator tile q = w and adds the four splits'
+        // copies of it in split order, ((s0 + s1) + s2) + s3 -- a fixed order, so the step stays bit-reproducible
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d3_red[((wave * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+        __syncthreads();
+        float* P = a.part + ((((long)n * a.nb + bb) * (a.NS / 4) + s / 4) * a.J + jt * 128) * 32 + bl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* x = d3_red + (wave * 16 + r) * 64 + lane;  // tile q = wave of split-wave 0; + 4 * 16 * 64 per split-wave
+            const float v = ((x[0] + x[4 * 16 * 64]) + x[2 * 4 * 16 * 64]) + x[3 * 4 * 16 * 64];
+            P[(4 * mfma_row(r, h) + wave) * 32] = v;
+        }
+        return;
+    }
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -202,6 +202,7 @@ int build_layout(const idqn_config_t& c, Layout& L) {
 struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
     int NS = 0;  // split-K of this set's Dense_0 forward
+    int G = 1;   // splits whose accumulators a workgroup adds through LDS before writing (k_dense0_fwd3): 4 or 1
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -369,6 +370,10 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
+    {
+        static const bool grp = !(getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) == 0);
+        s.G = (grp && h->planes && units_per_split <= 0 && s.NS >= 8 && s.NS % 4 == 0) ? 4 : 1;
+    }
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
         const int units = h->F / 32;
         s.NS = (units + units_per_split - 1) / units_per_split;
@@ -446,6 +451,9 @@ int cnn_setup(idqn_handle_s* h) {
         int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
         if (const char* e = getenv("IDQN_D0_SPLITS")) ns = atoi(e);
         h->NS = std::max(1, std::min(std::min(ns, 64), units));
+        // groups of four splits per workgroup (DenseFwdArgs::G): a multiple of 4 that still keeps <= 256 workgroups busy
+        static const bool grp = !(getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) == 0);
+        if (grp && h->planes && h->NS >= 8) h->NS = h->NS / 4 * 4;
     }
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
@@ -1322,7 +1330,12 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
-    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    d.G = h->planes ? s.G : 1;
+    if (d.G == 4) {
+        static LdsAttrMark attr;
+        if (attr.needs(65536)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    }
+    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 : 0, q, d);
     else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
@@ -1508,7 +1521,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
     // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
     HiddenArgs hi;
-    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS;
+    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS / s.G;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
     hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
     tl_mark(h, q, "hidden");
@@ -1914,7 +1927,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
-    d.net_rot = 0;
+    d.net_rot = 0; d.G = 1;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
     static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
