@@ -12,7 +12,10 @@
 namespace {
 
 __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
-    __shared__ unsigned short tile[64][40];  // [element][sample], 80-byte rows keep the 16-byte reads aligned
+    // [element][sample], 80-byte rows keep the 16-byte reads aligned.  The four 8-sample groups of a row are XOR-swizzled
+    // by (row >> 3) & 3: a wave's transposing 2-byte stores go to 8 rows that are 8 apart (640 bytes = 0 mod 32 banks) --
+    // 8-way conflicts unswizzled (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.81 in round 3), 2-way with the groups spread
+    __shared__ unsigned short tile[64][40];
     const int t = threadIdx.x;
     warm_kernargs<sizeof(StageArgs)>();
     if ((int)blockIdx.x < a.n_prep_blocks) {
@@ -36,7 +39,8 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
                 for (int i = 0; i < 8; ++i) u[i] = (bg < a.B && e8 + i < a.E) ? src[(long)bg * a.E + e8 + i] : 0u;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tile[c8 * 8 + i][s] = (unsigned short)(__float_as_uint((float)u[i]) >> 16);  // exact
+            for (int i = 0; i < 8; ++i)  // row c8 * 8 + i: (row >> 3) & 3 = c8 & 3
+                tile[c8 * 8 + i][(((s >> 3) ^ (c8 & 3)) << 3) | (s & 7)] = (unsigned short)(__float_as_uint((float)u[i]) >> 16);  // exact
         }
         __syncthreads();
         const int row = t >> 2, part = t & 3;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
             const int hh = E32 / WC, r = E32 - hh * WC, w = r / a.C, c = r - w * a.C;
             const long orow = ((long)(hh + a.lo_h) * a.Wp + (w + a.lo_w)) * a.C + c;
             unsigned short* dst = a.x1 + (((long)set * a.nb + bb) * a.Hp * a.Wp * a.C + orow) * 32 + part * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&tile[row][part * 8]);
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&tile[row][(part ^ ((row >> 3) & 3)) * 8]);
         }
         return;
     }

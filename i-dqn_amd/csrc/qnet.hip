@@ -275,6 +275,7 @@ struct idqn_handle_s {
     unsigned* act_seq = nullptr;      // device-side sequence counter
     unsigned act_expected = 0;        // sequence number the next idqn_act_host call waits for
     bool act_use_mail = false;        // set while idqn_act_host issues / captures its launches
+    int act_pending = 0;              // idqn_act_host_begin launched, idqn_act_host_end has not collected yet (1 mailbox, 2 copy)
     // IDQN_STEP_GRAPH=1: the plain cnn step replayed as a hipGraph per (batch buffers, size); value = calls seen, graph
     std::map<std::tuple<const void*, const void*, const void*, const void*, const void*, int, int, const void*, const void*>,
              std::pair<int, hipGraphExec_t>> step_graphs;
@@ -2327,8 +2328,10 @@ extern "C" int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, co
 // reference uploads the state, runs best_action and blocks on `.item()`): upload from pinned memory, the five launches of
 // the single-state path, the action back into pinned memory, one stream synchronisation -- replayed as ONE hipGraph per
 // (net, buffers) after the first call (seven eager API calls cost more host time than the ~35 us of GPU work).
-extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
-                             int32_t* action_host_pinned, void* stream) {
+static int act_host_wait(idqn_handle_t h, int32_t* action_host_pinned, hipStream_t q);
+// wait = false: the launch only (idqn_act_host_begin); the result is collected by act_host_wait (idqn_act_host_end)
+static int act_host_impl(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                         int32_t* action_host_pinned, void* stream, bool wait) {
     IDQN_REQUIRE(h && state_host_pinned && q_out_dev && action_host_pinned, "idqn_act_host: null pointer");
     IDQN_REQUIRE(head >= 0 && head < h->cfg.n_heads && (which == 0 || which == 1), "idqn_act_host: bad head / which");
     hipStream_t q = (hipStream_t)stream;
@@ -2388,6 +2391,15 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
         rc = issue(q);
         if (rc) return rc;
     }
+    h->act_pending = poll ? 1 : 2;  // 1: the mailbox announces the action; 2: a device-to-host copy is queued, synchronise
+    if (!wait) return IDQN_OK;
+    return act_host_wait(h, action_host_pinned, q);
+}
+
+static int act_host_wait(idqn_handle_t h, int32_t* action_host_pinned, hipStream_t q) {
+    IDQN_REQUIRE(h->act_pending != 0, "idqn_act_host_end: no acting launch is pending");
+    const bool poll = h->act_pending == 1;
+    h->act_pending = 0;
     if (poll) {
         const unsigned want = ++h->act_expected;
         volatile int32_t* mail = h->act_mail;
@@ -2410,6 +2422,20 @@ extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const
     }
     IDQN_HIP_CHECK(hipStreamSynchronize(q));
     return IDQN_OK;
+}
+
+extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                             int32_t* action_host_pinned, void* stream) {
+    return act_host_impl(h, which, head, state_host_pinned, q_out_dev, action_host_pinned, stream, true);
+}
+extern "C" int idqn_act_host_begin(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                                   int32_t* action_host_pinned, void* stream) {
+    IDQN_REQUIRE(h && h->act_pending == 0, "idqn_act_host_begin: null handle, or an acting launch is already pending");
+    return act_host_impl(h, which, head, state_host_pinned, q_out_dev, action_host_pinned, stream, false);
+}
+extern "C" int idqn_act_host_end(idqn_handle_t h, int32_t* action_host_pinned, void* stream) {
+    IDQN_REQUIRE(h && action_host_pinned, "idqn_act_host_end: null pointer");
+    return act_host_wait(h, action_host_pinned, (hipStream_t)stream);
 }
 
 extern "C" int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes) {

@@ -61,6 +61,8 @@ class Trainer:
                 stats.open_episode()
             if self.total_steps > self.p["n_initial_samples"]:
                 self._gradient_step()
+        if hasattr(self.rb, "flush_deferred"):
+            self.rb.flush_deferred()  # (a postponed add of the last step: the buffer is complete at every epoch end)
         avg_return, avg_length, n_episodes = stats.summary()
         print(f"\nEpoch {index}: Return {avg_return} averaged on {n_episodes} episodes.\n", flush=True)
         self.p["wandb"].log({"epoch": index, "n_training_steps": self.total_steps, "avg_return": avg_return,

@@ -65,5 +65,11 @@ def launch(env_name, algo, argvs, env=None, save_root=None):
                       update_horizon=p["update_horizon"], gamma=p["gamma"], clipping=consts["clipping"], compress=True)
     rb.reuse_sample_buffers = True  # the loop below consumes every batch before it draws the next (two staging sets in turn)
     agent = make_agent(algo, agent_key, observation_dim(env_name, env), env.n_actions, p, consts["adam_eps"])
+    # host work under the acting launch (slimdqn/sample_collection/utils.py, collect_single_sample); IDQN_LOOP_OVERLAP=0: off.
+    # Only where the launch is long enough to hide something: the conv nets' ~40 us (Atari-shaped loop 6.15 -> 6.5 k env
+    # steps/s); the MLP's ~20 us launch is shorter than what the extra calls cost (7.3 -> 7.0 k), so it stays synchronous.
+    if os.environ.get("IDQN_LOOP_OVERLAP", "1") != "0" and hasattr(agent, "lazy_host_actions") and p["architecture_type"] == "cnn":
+        agent.lazy_host_actions = True
+        p["overlap_replay_add"] = True
     train(train_key, p, agent, env, rb, save_fn=save_data)
     return p, agent

@@ -69,6 +69,8 @@ SYMBOLS = {
     "idqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "idqn_best_action": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     "idqn_act_host": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "idqn_act_host_begin": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "idqn_act_host_end": (C.c_int, [_P, _P, _P]),
     "idqn_debug_buffer": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "idqn_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p]),
     "idqn_profile_table": (C.c_int, [_P, C.c_char_p, C.c_int32]),

@@ -32,7 +32,30 @@ class _HostAction(int):
         return int(self)
 
 
+class _PendingHostAction:
+    """A greedy action whose launch is in flight (``idqn_act_host_begin``): ``.item()`` waits for it.  The trainer's
+    ``collect_single_sample`` runs the replay bookkeeping of the previous transition between the two."""
+
+    __slots__ = ("_agent", "_value")
+
+    def __init__(self, agent):
+        self._agent, self._value = agent, None
+
+    def item(self):
+        if self._value is None:
+            a = self._agent
+            _hip.check(_hip.lib().idqn_act_host_end(a._handle, C.c_void_p(a._act_out.data_ptr()), _hip.current_stream()),
+                       "idqn_act_host_end")
+            self._value = int(a._act_out_np[0])
+            a._act_in_flight = None
+        return self._value
+
+    __int__ = __index__ = item
+
+
 class DeviceAgent:
+    lazy_host_actions = False  # True (the trainer of this build sets it): best_action on a host state returns a pending action
+
     def __init__(self, key, observation_dim, n_actions, n_heads, features, architecture_type, learning_rate, gamma,
                  update_horizon, adam_eps, stacked, init_heads=None):
         self.network = DQNNet(features, architecture_type, n_actions)
@@ -112,6 +135,12 @@ class DeviceAgent:
         self._handle, self._handle_batch = h, max(batch, 32)
 
     def _destroy_handle(self):
+        pending = getattr(self, "_act_in_flight", None)
+        if pending is not None and getattr(self, "_handle", None) is not None:  # collect before the handle goes away
+            try:
+                pending.item()
+            except Exception:
+                self._act_in_flight = None
         if getattr(self, "_handle", None) is not None:
             _hip.lib().idqn_destroy(self._handle)
             self._handle = None
@@ -208,8 +237,17 @@ class DeviceAgent:
                 self._act_out_np = self._act_out.numpy()
             src = np.asarray(getattr(state, "tensor", state))
             assert src.size == self._act_pin_np.size, "best_action takes a single state"
+            pending = getattr(self, "_act_in_flight", None)
+            if pending is not None:  # (a lazy action nobody collected: finish it before the staging buffer is rewritten)
+                pending.item()
             self._act_pin_np[:] = src.reshape(-1)  # casts like the array conversion of the reference's jit would
             self._ensure_handle(32)
+            if self.lazy_host_actions:
+                _hip.check(_hip.lib().idqn_act_host_begin(self._handle, int(which), int(head), C.c_void_p(self._act_pin.data_ptr()),
+                                                          _hip.ptr(self._q_out), C.c_void_p(self._act_out.data_ptr()),
+                                                          _hip.current_stream()), "idqn_act_host_begin")
+                self._act_in_flight = _PendingHostAction(self)
+                return self._act_in_flight
             _hip.check(_hip.lib().idqn_act_host(self._handle, int(which), int(head), C.c_void_p(self._act_pin.data_ptr()),
                                                 _hip.ptr(self._q_out), C.c_void_p(self._act_out.data_ptr()),
                                                 _hip.current_stream()), "idqn_act_host")

@@ -332,7 +332,22 @@ class ReplayBuffer:
         self._flushed = hi
 
     # ---- reference API -----------------------------------------------------------------------------
+    def add_deferred(self, transition: TransitionElement, **kwargs: Any) -> None:
+        """``add`` whose work is postponed to the next ``flush_deferred`` (the trainer calls it while the GPU computes the
+        next action); ``add`` / ``sample`` / ``update`` flush first, so every observable state is the one ``add`` gives.
+        The frame is copied now: the environment may reuse its buffer on the next step or reset."""
+        self.flush_deferred()
+        self._deferred = (transition._replace(observation=np.array(transition.observation, copy=True)), kwargs)
+
+    def flush_deferred(self) -> None:
+        d = getattr(self, "_deferred", None)
+        if d is not None:
+            self._deferred = None
+            self.add(d[0], **d[1])
+
     def add(self, transition: TransitionElement, **kwargs: Any) -> None:
+        if getattr(self, "_deferred", None) is not None:
+            self.flush_deferred()
         t_now = self._upload_frame(transition.observation)
         light = transition._replace(observation=None)  # the window decides positions; pixels stay on the device
         for plan, window_size in self._accumulator.plan(light):
@@ -416,6 +431,7 @@ class ReplayBuffer:
                              is_terminal=DevArray(e.is_terminal.tensor.clone()), episode_end=DevArray(e.episode_end.tensor.clone()))
 
     def sample(self, size=None) -> ReplayElement:
+        self.flush_deferred()
         assert self.add_count, ValueError("No samples in replay buffer!")
         if size is None:
             size = self._batch_size
@@ -423,4 +439,5 @@ class ReplayBuffer:
         return self._gather((np.asarray(keys, np.int64) % self._max_capacity).astype(np.int32))
 
     def update(self, keys, **kwargs: Any) -> None:
+        self.flush_deferred()
         self._sampling_distribution.update(keys, **kwargs)

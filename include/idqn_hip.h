@@ -175,6 +175,12 @@ int idqn_best_action(idqn_handle_t h, int32_t which, int32_t head, const void* s
  * buffers) the whole sequence is replayed as one hipGraph (IDQN_ACT_GRAPH=0: eager).                                   */
 int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
                   int32_t* action_host_pinned, void* stream);
+/* The same in two halves, so that host work that does not depend on the action (the replay-buffer bookkeeping of the
+ * PREVIOUS transition, key splits) runs while the GPU computes it: _begin uploads and launches and returns at once, _end
+ * waits for the action exactly as idqn_act_host does.  One launch may be pending per handle.                         */
+int idqn_act_host_begin(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
+                        int32_t* action_host_pinned, void* stream);
+int idqn_act_host_end(idqn_handle_t h, int32_t* action_host_pinned, void* stream);
 
 /* Test / debug access to internal activation buffers by name (device pointer + byte size).        */
 int idqn_debug_buffer(idqn_handle_t h, const char* name, void** ptr_dev, int64_t* nbytes);

@@ -146,6 +146,22 @@ def test_trainer_loop_with_and_without_step_graph():
     assert a["target"] == b["target"]
 
 
+def test_trainer_loop_with_and_without_overlapped_replay_add():
+    """Round 4: the launcher lets the greedy action's launch return at once (idqn_act_host_begin / _end) and runs the replay
+    bookkeeping of the previous transition under it (ReplayBuffer.add_deferred; IDQN_LOOP_OVERLAP=0 switches both off).  Same
+    transitions in the same order, same samples, same steps: bit-identical parameters at the end."""
+    def run(flag):
+        e = dict(os.environ, IDQN_LOOP_OVERLAP=flag)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + TRAINER_CHILD], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+
+    a, b = run("1"), run("0")
+    assert a["count"] == b["count"] and a["count"] >= 40
+    assert a["probe"] == b["probe"]
+    assert a["target"] == b["target"]
+
+
 FC_CHILD = r"""
 import json, sys, os
 sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
