@@ -267,6 +267,17 @@ struct DenseFwdArgs {
                   // tile) and add their accumulators through LDS in split order before anything is written: part holds
                   // NS / 4 slabs per (net, block) instead of NS (a quarter of the partial traffic, k_hidden adds a quarter
                   // of the slabs).  1 = one slab per split (NS not a multiple of 4; 64 KB of dynamic LDS not requested).
+    // G == 4 and arrive != nullptr: the head's first stage rides in this launch.  Every workgroup of a (net, block, column
+    // tile) group writes its slab write-through and adds to the group's arrival counter; the one whose add comes LAST
+    // (whichever it is: it then adds the slabs in slab order, so the sums do not depend on it) does what k_hidden does for
+    // the tile's 128 hidden units -- bias + ReLU -> hbuf, the Dense_1 chunk partials -> qpart (architectures/dqn.py:67-70)
+    // -- and re-arms the counter.  Bit-identical to d0fwd + k_hidden, one launch and the re-read of the slabs by a second
+    // grid fewer.
+    unsigned* arrive;   // [n_nets * nb * n_jt], zero between launches
+    float* hbuf;        // [n_nets][nb][J][32]
+    float* qpart;       // [n_nets][nb][J / 32][32][32]
+    long b0_off, w1_off;
+    int A;
 };
 
 __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
@@ -425,20 +436,88 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
 #undef D3_TILE
 #undef D3_MMA
     if (a.G == 4) {
-        // the four splits of the group meet in LDS; wave w then owns accumulator tile q = w and adds the four splits'
-        // copies of it in split order, ((s0 + s1) + s2) + s3 -- a fixed order, so the step stays bit-reproducible
+        // the four splits of the group meet in LDS and are added in split order, ((s0 + s1) + s2) + s3 -- a fixed order, so
+        // the step stays bit-reproducible.  Element (tile q, register r, lane) of a wave's accumulators is column
+        // 4 * mfma_row(r, lane >> 5) + q, sample lane & 31: four consecutive lanes are 16 contiguous bytes of the slab.
+        const int t = threadIdx.x, nsg = a.NS / 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d3_red[((wave * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
         __syncthreads();
-        float* P = a.part + ((((long)n * a.nb + bb) * (a.NS / 4) + s / 4) * a.J + jt * 128) * 32 + bl;
+        const long slot = (long)n * a.nb + bb;
+        float* P = a.part + ((slot * nsg + s / 4) * a.J + jt * 128) * 32;
+        const bool fuse = a.arrive != nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* x = d3_red + (wave * 16 + r) * 64 + lane;  // tile q = wave of split-wave 0; + 4 * 16 * 64 per split-wave
-            const float v = ((x[0] + x[4 * 16 * 64]) + x[2 * 4 * 16 * 64]) + x[3 * 4 * 16 * 64];
-            P[(4 * mfma_row(r, h) + wave) * 32] = v;
+        for (int m = 0; m < 4; ++m) {
+            const int f = t + 256 * m;  // float4 index: (q, r) = f / 16, lanes 4 (f % 16) .. + 3
+            const int qr = f >> 4, l4 = (f & 15) * 4, q = qr >> 4, r = qr & 15;
+            const float* x = d3_red + qr * 64 + l4;
+            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(x), v1 = *reinterpret_cast<const f32x4v*>(x + 4 * 16 * 64);
+            const f32x4v v2 = *reinterpret_cast<const f32x4v*>(x + 2 * 4 * 16 * 64), v3 = *reinterpret_cast<const f32x4v*>(x + 3 * 4 * 16 * 64);
+            const f32x4v v = ((v0 + v1) + v2) + v3;
+            float* dst = P + (4 * mfma_row(r, l4 >> 5) + q) * 32 + (l4 & 31);
+            if (fuse) store16_sc1(dst, __builtin_bit_cast(u32x4, v));  // handed to another workgroup inside this launch
+            else *reinterpret_cast<f32x4v*>(dst) = v;
         }
+        if (!fuse) return;
+        // ---- arrival: every storing wave has drained, ONE lane adds; the last arriver takes the tile's head stage --------
+        int* last_flag = reinterpret_cast<int*>(d3_red + 4 * 4 * 16 * 64);  // (behind the 64 KB: a static would shift the dynamic base off 16 bytes)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* ctr = a.arrive + slot * a.n_jt + jt;
+        if (t == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)nsg - 1u;
+            if (last) {
+                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *last_flag = last;
+        }
+        __syncthreads();
+        if (!*last_flag) return;
+        // ---- k_hidden's work for hidden units [jt * 128, jt * 128 + 128) of (net n, block bb) -------------------------------
+        float* hs = d3_red;              // [128][33]
+        float* w1s = d3_red + 128 * 33;  // [128][A]
+        const float* p = a.wbase[n];
+        {
+            const float* w1 = p + a.w1_off + (long)jt * 128 * a.A;
+            for (int e = t; e < 128 * a.A; e += 256) w1s[e] = w1[e];
+        }
+        const float* part = a.part + (slot * nsg * a.J + jt * 128) * 32;
+        const long sstride = (long)a.J * 32;
+        float* hb = a.hbuf + (slot * a.J + jt * 128) * 32;
+        const int jl = t >> 3, l8 = t & 7;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = jl + 32 * it;
+            const float bias = p[a.b0_off + jt * 128 + j];
+            float4 sv = make_float4(bias, bias, bias, bias);
+            const float* pr = part + (long)j * 32 + 4 * l8;
+            for (int sp = 0; sp < nsg; sp += 16) {  // the slabs in slab order, 16 per round in flight (as k_hidden)
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v[u] = sp + u < nsg ? *reinterpret_cast<const float4*>(pr + (sp + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (sp + u < nsg) { sv.x += v[u].x; sv.y += v[u].y; sv.z += v[u].z; sv.w += v[u].w; }
+            }
+            sv.x = fmaxf(sv.x, 0.f); sv.y = fmaxf(sv.y, 0.f); sv.z = fmaxf(sv.z, 0.f); sv.w = fmaxf(sv.w, 0.f);
+            hs[j * 33 + 4 * l8 + 0] = sv.x; hs[j * 33 + 4 * l8 + 1] = sv.y; hs[j * 33 + 4 * l8 + 2] = sv.z; hs[j * 33 + 4 * l8 + 3] = sv.w;
+            *reinterpret_cast<float4*>(hb + (long)j * 32 + 4 * l8) = sv;
+        }
+        __syncthreads();
+        const int b = t & 31, jj = t >> 5;
+        for (int c = 0; c < 4; ++c)
+            for (int ac = jj; ac < a.A; ac += 8) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) s_ = fmaf(hs[(c * 32 + r) * 33 + b], w1s[(c * 32 + r) * a.A + ac], s_);
+                a.qpart[((slot * (a.J / 32) + jt * 4 + c) * 32 + ac) * 32 + b] = s_;
+            }
         return;
     }
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;

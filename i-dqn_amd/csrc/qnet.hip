@@ -203,6 +203,7 @@ struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
     int NS = 0;  // split-K of this set's Dense_0 forward
     int G = 1;   // splits whose accumulators a workgroup adds through LDS before writing (k_dense0_fwd3): 4 or 1
+    bool hidden_fused = false;  // the last Dense_0 forward of this set also ran the head's first stage (no k_hidden launch)
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -479,7 +480,7 @@ int cnn_setup(idqn_handle_s* h) {
     }
     if (h->planes) {
         float* ws = nullptr;
-        if ((rc = alloc_zero(&ws, 64 + 2L * 4096, h, "chain_ws"))) return rc;
+        if ((rc = alloc_zero(&ws, 64 + 3L * 4096, h, "chain_ws"))) return rc;  // (the third block: arrival counters of the Dense_0 forward)
         h->chain_ws = reinterpret_cast<unsigned*>(ws);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
@@ -1332,11 +1333,23 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
     d.G = h->planes ? s.G : 1;
+    d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
+    // IDQN_D0_FUSE_HIDDEN=1: the training set's head stage 1 (k_hidden) rides in this launch (DenseFwdArgs::arrive).  Opt-in:
+    // bit-identical and measured neutral (profiles/r4_d0fwd_group_fuse_ab.txt: the launch grows by the 7 us the head stage,
+    // the write-through drain, the arrival add and the acquire take on the 40 last-arriving workgroups; k_hidden took 5.5 + a
+    // boundary) -- the in-launch split-K seam costs what the launch it replaces did, as on the conv chain.
+    static const bool fuse_hidden = getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0;
+    s.hidden_fused = false;
+    if (d.G == 4 && fuse_hidden && &s == &h->train && h->chain_ws && h->J % 128 == 0 && (long)s.n_nets * nb * d.n_jt <= 4096 &&
+        128 * 33 + 128 * h->cfg.n_actions <= 16384) {
+        d.arrive = h->chain_ws + 64 + 2 * 4096; d.hbuf = h->hbuf; d.qpart = h->qpart;
+        s.hidden_fused = true;
+    }
     if (d.G == 4) {
         static LdsAttrMark attr;
-        if (attr.needs(65536)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        if (attr.needs(65536 + 16)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     }
-    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 : 0, q, d);
+    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
     else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
@@ -1524,8 +1537,10 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     HiddenArgs hi;
     hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS / s.G;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
-    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
-    tl_mark(h, q, "hidden");
+    if (!s.hidden_fused) {
+        hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
+        tl_mark(h, q, "hidden");
+    }
     TdArgs ta;
     ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
     ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K;
@@ -1928,7 +1943,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
-    d.net_rot = 0; d.G = 1;
+    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
     static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
