@@ -88,7 +88,6 @@ def test_chained_forward_convs_are_bit_identical():
 
 def test_dense0_forward_group_and_fused_head_stage(default_run):
     """Round 4: the Dense_0 forward adds four consecutive splits per workgroup through LDS (IDQN_D0_GROUP=0: one slab per
-    split, another association of the same sum -> fp32 round-off) and carries the head's first stage, the last-arriving
     split, another association of the same sum -> fp32 round-off); IDQN_D0_FUSE_HIDDEN=1 lets that launch carry the head's
     first stage, the last-arriving workgroup of a column tile doing what k_hidden does -> bit-identical."""
     got = _run(IDQN_D0_FUSE_HIDDEN="1")
