@@ -1250,12 +1250,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(ConvWgradArgs a) {
 }
 
 // slab reduce for all conv layers in ONE launch: grad[k][off + e] = sum_pc slab[pc][k][e]  (fixed order)
-struct SlabSeg {
-    const float* slab;
-    long slab_stride, w_off, b_off, wsize;
-    int npc, bsize;
-    long first_block;  // blockIdx.x range [first_block, first_block + n_blocks)
-};
+// (SlabSeg: dense0_update.h, shared with the Adam role of the Conv_0 weight-gradient launch)
 struct SlabReduceArgs {
     SlabSeg seg[3];
     float* grad;
@@ -1287,86 +1282,14 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs a) {
 // --------------------------------------------------------------------------------------------
 // Adam over (part of) the arenas (optax.adam, idqn.py:52,106-107) and the step epilogue
 // --------------------------------------------------------------------------------------------
-struct AdamArgs {
-    float *theta, *mu, *nu;
-    const float* grad;
-    const float* bcinv;  // [K][2]
-    AdamConsts ad;
-    long P, begin, end;         // element range inside a head, multiples of 4
-    long skip_begin, skip_end;  // sub-range already updated by a fused kernel (empty when begin==end)
-    long gP, w0_begin, w0_end, g_w0_base;  // gradient arena layout (GradLayout in qnet.hip)
-    int K, n_seg;               // n_seg > 0: the conv leaves' gradients are still per-chunk slabs (fused path):
-    SlabSeg seg[3];             // sum them here (fixed chunk order) instead of a separate reduce launch
-    // step epilogue of the two-phase (data-parallel) step, or nullptr: count += 1 (optax count, idqn.py:53) and
-    // cum_losses += losses in f64 (idqn.py:72), by one thread per head -- this launch reads bcinv, not count
-    int32_t* ep_count;
-    const float* ep_losses;
-    double* ep_cum;
-};
+// (AdamArgs and the per-thread body adam_thread: dense0_update.h)
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int k = blockIdx.y;
     if (a.ep_count && blockIdx.x == 0 && threadIdx.x == 0) {
         a.ep_count[k] += 1;
         a.ep_cum[k] = a.ep_cum[k] + (double)a.ep_losses[k];
     }
-    // FOUR lanes per float4 of parameters: where the gradient is still per-chunk slabs (the conv leaves on the fused path),
-    // each lane sums every fourth chunk, up to 8 loads in flight, and the four partial sums are combined in a
-    // fixed order, ((l0 + l1) + (l2 + l3)) -- one latency round instead of npc / 8 (Conv_0 has 51 chunks).  Lane 0 of the
-    // quad then does the update.  The grid covers [begin, end) minus the skipped range (the fused kernel's
-    // Dense_0/kernel: 98 % of the head), compacted.
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int sub = (int)(gid & 3);
-    long e = a.begin + (gid >> 2) * 4;
-    if (e >= a.skip_begin) e += a.skip_end - a.skip_begin;
-    if (e >= a.end) return;  // whole quads leave together
-    const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
-    const long o = (long)k * a.P + e;
-    const long w0n = a.w0_end - a.w0_begin;
-    const long go = e < a.w0_begin ? (long)k * a.gP + e
-                    : (e < a.w0_end ? a.g_w0_base + (long)k * w0n + (e - a.w0_begin) : (long)k * a.gP + e - w0n);
-    float4 th = make_float4(0.f, 0.f, 0.f, 0.f), m = th, v = th, g = th;
-    if (sub == 0) {  // independent of the gradient assembly below: issue first
-        th = *reinterpret_cast<float4*>(a.theta + o);
-        m = *reinterpret_cast<float4*>(a.mu + o);
-        v = *reinterpret_cast<float4*>(a.nu + o);
-    }
-    bool from_slab = false;
-#pragma unroll
-    for (int si = 0; si < 3; ++si) {
-        if (si >= a.n_seg) break;
-        const SlabSeg& sg = a.seg[si];
-        long se = -1;  // element index inside the slab (weights, then bias); leaves are 4-aligned
-        if (e >= sg.w_off && e < sg.w_off + sg.wsize) se = e - sg.w_off;
-        else if (e >= sg.b_off && e < sg.b_off + sg.bsize) se = sg.wsize + (e - sg.b_off);
-        if (se >= 0) {
-            from_slab = true;
-            const float* sp = sg.slab + (long)k * sg.slab_stride + se;
-            const long pstride = (long)a.K * sg.slab_stride;
-            for (int pc0 = sub; pc0 < sg.npc; pc0 += 32) {  // 8 chunks per lane and round (32 per quad), no load past the last chunk
-                float4 x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (pc0 + 4 * u < sg.npc) x[u] = *reinterpret_cast<const float4*>(sp + (pc0 + 4 * u) * pstride);
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (pc0 + 4 * u < sg.npc) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
-            }
-        }
-    }
-    if (from_slab) {  // quad-uniform: the four lanes share e
-        g.x += __shfl_xor(g.x, 1); g.y += __shfl_xor(g.y, 1); g.z += __shfl_xor(g.z, 1); g.w += __shfl_xor(g.w, 1);
-        g.x += __shfl_xor(g.x, 2); g.y += __shfl_xor(g.y, 2); g.z += __shfl_xor(g.z, 2); g.w += __shfl_xor(g.w, 2);
-    } else if (sub == 0) {
-        g = *reinterpret_cast<const float4*>(a.grad + go);
-    }
-    if (sub != 0) return;
-    adam_elem(a.ad, bc1, bc2, g.x, th.x, m.x, v.x);
-    adam_elem(a.ad, bc1, bc2, g.y, th.y, m.y, v.y);
-    adam_elem(a.ad, bc1, bc2, g.z, th.z, m.z, v.z);
-    adam_elem(a.ad, bc1, bc2, g.w, th.w, m.w, v.w);
-    *reinterpret_cast<float4*>(a.theta + o) = th;
-    *reinterpret_cast<float4*>(a.mu + o) = m;
-    *reinterpret_cast<float4*>(a.nu + o) = v;
+    adam_thread(a, k, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // count += 1 (optax count, idqn.py:53), cum_losses += losses in f64 (idqn.py:72)

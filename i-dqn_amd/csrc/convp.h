@@ -223,6 +223,10 @@ struct D0Stream;  // dense0_update.h: a share of the fused Dense_0 update carrie
 int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q,
                        const D0Stream* ds = nullptr);
 bool convp_wgrad_stream_built(int NPX, int MT, int CT, int PG);
+struct AdamArgs;  // dense0_update.h: the small-leaf Adam update carried by the launch's spare workgroups (convp_wgrad.hip)
+bool convp_wgrad_adam_built(int NPX, int MT, int CT, int PG);
+int convp_launch_wgrad_adam(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const AdamArgs& ad,
+                            long n_threads, int n_role);
 // a data gradient and a weight gradient side by side in one launch (convp_pair.hip); convp_pair_built: is this pair compiled
 bool convp_pair_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
 int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_f, size_t f_stage, int ring, size_t f_lds,

@@ -25,6 +25,34 @@ __global__ __launch_bounds__(512) void k_cwgrad_s(CWgradArgs a, unsigned stage_b
     cwgrad_body<NPX, CT, NTW, PG>(a, stage_bytes, MT, xcd_contiguous_id_n(n_conv));
 }
 
+// The same launch with an ADAM ROLE behind the conv workgroups: blocks [n_conv, gridDim.x) run the small-leaf Adam update
+// (dense0_update.h, adam_thread) over the leaves whose gradients do not depend on this launch -- every leaf but Conv_0's --
+// on the CUs the weight gradient leaves free.  Independent roles, no hand-off: the launch that follows only has Conv_0's
+// 8 k parameters per head left.
+template <int NPX, int CT, int NTW, int PG>
+__global__ __launch_bounds__(512) void k_cwgrad_a(CWgradArgs a, unsigned stage_bytes, int MT, int n_conv, AdamArgs ad, long n_threads) {
+    warm_kernargs<(sizeof(CWgradArgs) + sizeof(AdamArgs) + 48 < 1024 ? sizeof(CWgradArgs) + sizeof(AdamArgs) + 48 : 1024)>();
+    if ((int)blockIdx.x >= n_conv) {
+        const long step = (long)((int)gridDim.x - n_conv) * 512;
+        for (int k = 0; k < ad.K; ++k)
+            for (long gid = (long)((int)blockIdx.x - n_conv) * 512 + threadIdx.x; gid < n_threads; gid += step) adam_thread(ad, k, gid);
+        return;
+    }
+    cwgrad_body<NPX, CT, NTW, PG>(a, stage_bytes, MT, xcd_contiguous_id_n(n_conv));
+}
+
+template <int NPX, int CT, int NTW, int PG>
+int launch_one_a(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipStream_t q, const AdamArgs& ad, long n_threads, int n_role) {
+    static LdsAttrMark attr;  // per instantiation
+    if (attr.needs(lds_bytes + 2048)) {
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cwgrad_a<NPX, CT, NTW, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes + 2048));
+    }
+    hipLaunchKernelGGL((k_cwgrad_a<NPX, CT, NTW, PG>), dim3((unsigned)(n_items + n_role)), dim3(512), lds_bytes + 2048, q, a,
+                       (unsigned)(lds_bytes / 2), MT, n_items, ad, n_threads);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
 template <int NPX, int CT, int NTW, int PG>
 int launch_one_s(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipStream_t q, const D0Stream& ds) {
     const size_t lds = std::max(lds_bytes + 2048, (size_t)65536);
@@ -55,6 +83,16 @@ int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipSt
 bool convp_wgrad_stream_built(int NPX, int MT, int CT, int PG) {  // which weight-gradient kernels carry the stream role
     const int ntw = (MT * CT + 3) / 4;
     return NPX == 1 && ((CT == 1 && ntw == 2 && PG == 4) || (CT == 2 && ntw == 4 && PG == 2));
+}
+
+bool convp_wgrad_adam_built(int NPX, int MT, int CT, int PG) { return NPX == 1 && CT == 1 && (MT * CT + 3) / 4 == 2 && PG == 4; }
+
+int convp_launch_wgrad_adam(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const AdamArgs& ad,
+                            long n_threads, int n_role) {
+    IDQN_REQUIRE(lds_bytes + 2048 <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes + 2048);
+    IDQN_REQUIRE(n_role >= 1 && n_items + n_role <= 256, "plane wgrad: %d + %d workgroups do not fit one per CU", n_items, n_role);
+    IDQN_REQUIRE(convp_wgrad_adam_built(NPX, MT, CT, a.PG), "plane wgrad: no Adam-role kernel for this shape");
+    return launch_one_a<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q, ad, n_threads, n_role);
 }
 
 int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const D0Stream* ds) {

@@ -329,6 +329,7 @@ struct idqn_handle_s {
     // to the stream roles of the Conv_2 pair launch (S2 workgroups x r2 rounds) and of the Conv_0 weight-gradient launch
     // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
     struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
+    long adam_done_from = 0;  // > 0: the last backward's Conv_0 weight-gradient launch already updated the leaves from this element on
     bool d0_rows = false;  // the last fused Dense_0 launch ran on full rows and finished dL/da3 itself
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
@@ -1356,17 +1357,12 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     return IDQN_OK;
 }
 
+void fill_adam_args(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, bool epilogue, AdamArgs& a);
 int launch_adam(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, hipStream_t q, bool epilogue = false) {
     AdamArgs a;
-    a.ep_count = epilogue ? h->count : nullptr; a.ep_losses = h->losses; a.ep_cum = h->cum;
-    a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
-    a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
-    a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
-    a.gP = h->gP; a.w0_begin = h->g_w0_begin; a.w0_end = h->g_w0_end; a.g_w0_base = h->g_w0_base;
-    for (int i = 0; i < 3; ++i) a.seg[i] = h->segs[i];
     IDQN_REQUIRE(skip_b == skip_e || (skip_b >= begin && skip_e <= end && skip_b % 4 == 0 && skip_e % 4 == 0),
                  "launch_adam: bad skip range");
-    if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
+    fill_adam_args(h, begin, end, skip_b, skip_e, from_slabs, epilogue, a);
     hipLaunchKernelGGL(k_adam, dim3(cdiv(end - begin - (skip_e - skip_b), 256), h->cfg.n_heads), dim3(256), 0, q, a);  // 4 lanes per float4
     tl_mark(h, q, "adam (small leaves + slab sums)");
     IDQN_HIP_CHECK(hipGetLastError());
@@ -1434,7 +1430,7 @@ int make_dgrad_args(idqn_handle_s* h, int i, int nb, ConvFwdArgs& a) {
     return IDQN_OK;
 }
 
-int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bool adam_role = false);
 
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
 int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
@@ -1628,11 +1624,36 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    return cnn_backward_rest(h, B, fuse_adam, q);
+    return cnn_backward_rest(h, B, fuse_adam, q, fuse_adam);
 }
 
-int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
+// the slab descriptor of conv layer i (position chunks = what its weight-gradient launch of THIS step wrote)
+void fill_seg(idqn_handle_s* h, int i, SlabSeg& g, long first_block) {
+    const ConvL& l = h->conv[i];
+    g.slab = h->slab + h->slab_off[i]; g.slab_stride = h->slab_stride[i]; g.w_off = l.w_off; g.b_off = l.b_off;
+    g.wsize = (long)l.K * l.K * l.CI * l.CO; g.npc = h->planes ? h->npc_used[i] : h->npc[i]; g.bsize = l.CO;
+    g.first_block = first_block;
+}
+
+void fill_adam_args(idqn_handle_s* h, long begin, long end, long skip_b, long skip_e, bool from_slabs, bool epilogue, AdamArgs& a) {
+    a.ep_count = epilogue ? h->count : nullptr; a.ep_losses = h->losses; a.ep_cum = h->cum;
+    a.theta = h->online; a.mu = h->mu; a.nu = h->nu; a.grad = h->grad; a.bcinv = h->bcinv; a.ad = h->ad;
+    a.P = h->L.head_stride; a.begin = begin; a.end = end; a.skip_begin = skip_b; a.skip_end = skip_e;
+    a.K = h->cfg.n_heads; a.n_seg = from_slabs ? 3 : 0;
+    a.gP = h->gP; a.w0_begin = h->g_w0_begin; a.w0_end = h->g_w0_end; a.g_w0_base = h->g_w0_base;
+    for (int i = 0; i < 3; ++i) a.seg[i] = h->segs[i];
+    if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
+}
+
+// adam_role (the plain fused step only, opt-in: IDQN_ADAM_ROLE=1): the Conv_0 weight-gradient launch, planned for ~160
+// workgroups, carries the Adam update of every small leaf but Conv_0's on the CUs it leaves free (convp_wgrad.hip,
+// k_cwgrad_a) -- two independent roles in one launch; the Adam launch behind it is then left with Conv_0's kernel and bias.
+// Measured SLOWER (profiles/r4_adam_role_ab.txt: step 0.2811-0.2857 -> 0.2884-0.2891 ms): 96 role workgroups walk the 366 k
+// elements in 7-8 dependent passes (25 us for the launch against 14 for the weight gradient alone) where the stand-alone
+// launch spreads them over 1600 workgroups at once; the Adam launch left behind still costs most of what the full one did.
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bool adam_role) {
     const int K = h->cfg.n_heads, nb = cdiv(B, 32);
+    h->adam_done_from = 0;
     NetSet& s = h->train;
     const ConvL* cl[3] = {&h->conv[0], &h->conv[1], &h->conv[2]};
     SlabReduceArgs r;
@@ -1653,6 +1674,26 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
             else if (i == 1) rc = planes_pair(h, i, nb, q, &paired);
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
+            if (!rc && i == 0 && adam_role && !ovl) {
+                static const bool role_on = getenv("IDQN_ADAM_ROLE") && atoi(getenv("IDQN_ADAM_ROLE")) != 0;
+                static const int role_cus = getenv("IDQN_ADAM_ROLE_CUS") ? atoi(getenv("IDQN_ADAM_ROLE_CUS")) : 96;
+                CWgradArgs wa;
+                WgradPlan* pl = nullptr;
+                const int conv_budget = std::max(K, cu_budget() - role_cus);
+                if (role_on && cu_budget() == 256 && (rc = wgrad_args(h, 0, nb, std::max(1, conv_budget / K), wa, pl)) == IDQN_OK &&
+                    convp_wgrad_adam_built(1, pl->MT, cl[0]->CO / 32, pl->PG) && 256 - pl->n_items >= 16) {
+                    h->npc_used[0] = pl->n_chunks;
+                    for (int j = 0; j < 3; ++j) fill_seg(h, j, h->segs[2 - j], 0);
+                    AdamArgs ad;
+                    const long begin = cl[1]->w_off, end = h->L.head_stride;  // leaf order: Conv_0/{kernel, bias} come first
+                    fill_adam_args(h, begin, end, h->off_w0, h->off_b0, true, false, ad);
+                    rc = convp_launch_wgrad_adam(wa, 1, pl->MT, cl[0]->CO / 32, pl->n_items, pl->lds, q, ad,
+                                                 end - begin - (h->off_b0 - h->off_w0), 256 - pl->n_items);
+                    h->adam_done_from = begin;
+                    tl_mark(h, q, "conv0 wgrad | adam (other small leaves)");
+                    continue;
+                }
+            }
             if (!rc) {
                 if (i == 0 && ovl && h->ov.r0) rc = planes_wgrad(h, i, nb, q, 256 - h->ov.S0, h->ov.r0);
                 else rc = planes_wgrad(h, i, nb, q);
@@ -1695,9 +1736,8 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
             else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(256), 0, q, a);
         }
         SlabSeg& g = r.seg[2 - i];
-        g.slab = h->slab + h->slab_off[i]; g.slab_stride = h->slab_stride[i]; g.w_off = l.w_off; g.b_off = l.b_off;
-        g.wsize = (long)l.K * l.K * l.CI * l.CO; g.npc = h->planes ? h->npc_used[i] : h->npc[i]; g.bsize = l.CO;
-        g.first_block = nblk;
+        fill_seg(h, i, g, nblk);
+        (void)l;
         nblk += cdiv(g.wsize + g.bsize, 256);
     }
     for (int i = 0; i < 3; ++i) h->segs[i] = r.seg[i];
@@ -1831,7 +1871,9 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             if (!grads_only) {
                 // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
                 const long w0_b = h->off_w0, w0_e = h->off_b0;
-                if ((r = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, qs))) return r;
+                if (h->adam_done_from > 0) {  // the Conv_0 weight-gradient launch carried the other leaves: Conv_0's are left
+                    if ((r = launch_adam(h, 0, h->adam_done_from, 0, 0, true, qs))) return r;
+                } else if ((r = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, qs))) return r;
             }
             return IDQN_OK;
         };

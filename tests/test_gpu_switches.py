@@ -6,6 +6,8 @@
                       -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
   IDQN_D0_GROUP=0 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward without the in-workgroup split reduction / with the head's
                       first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical
+  IDQN_ADAM_ROLE=1    the Conv_0 weight-gradient launch carries the other small leaves' Adam update  -> bit-identical at
+                      equal chunk counts
   IDQN_NO_PAIR=1      conv data / weight gradients as two launches   -> same losses, parameters within fp32 round-off
                       (the weight gradient is cut into a different number of position chunks, i.e. summed in another order)
   IDQN_ACT_POLL=0     acting result by copy + synchronisation        -> same greedy actions as the polled mailbox
@@ -97,6 +99,21 @@ def test_dense0_forward_group_and_fused_head_stage(default_run):
     np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
     for name, want in default_run["probe"].items():
         np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_adam_role_of_the_conv0_weight_gradient_launch(default_run):
+    """Round 4 (opt-in, measured slower): IDQN_ADAM_ROLE=1 lets the Conv_0 weight-gradient launch carry the Adam update of
+    every other small leaf on the CUs it leaves free (default: one Adam launch for all small leaves behind a whole-chip weight
+    gradient).  The same update arithmetic per element; Conv_0's gradient is cut into another number of position chunks."""
+    got = _run(IDQN_ADAM_ROLE="1")
+    np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
+    for name, want in default_run["probe"].items():
+        if name.startswith("Conv_0"):
+            np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+    # with the same chunk count on both sides everything is bit-identical: the role only moves WHERE the update runs
+    a, b = _run(IDQN_ADAM_ROLE="1"), _run(IDQN_WCHUNKS="32")
+    assert a["losses"] == b["losses"]
+    assert a["probe"] == b["probe"]
 
 
 def test_unpaired_conv_backward_matches(default_run):
