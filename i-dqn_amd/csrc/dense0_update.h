@@ -193,10 +193,16 @@ struct DenseWgradArgs {
 // tiles in LDS and write the 4 KB partial.  k_da3_finalize sums the column tiles' partials and applies the ReLU mask.
 // The LDS tile's columns are rotated by 4 * row: the MFMA reads one column of 32 rows per instruction, which would hit a
 // single bank with a 256-float pitch (rotated: 4-way, 8 cycles per 64-cycle MFMA); float4 accesses stay aligned.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3>  // column tile JT = 128 * NQ (256 when the dense width allows it)
-__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * JT floats (+ 4096 FUSE_DG) */,
+// RT = 2 (with NQ = 1, BF3): the tile is 64 rows x 128 columns instead of 32 x 256 -- the same 8192 elements, the same four
+// 32 x 64 wave tiles (wave w: row half w >> 1, column half w & 1), the same number of workgroups, but (64 + 128) instead of
+// (32 + 256) operand rows per sample block: a third less L2 -> CU operand traffic, which is what the N-block contraction of
+// the factored data-parallel update is bound by (qnet.hip, launch_dense0_wgrad); theta / m / v stream as 512-byte row pieces.
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+__device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
-    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 / RPI;  // lanes/row, rows/iter (256 threads), iters
+    constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
+    static_assert(RT == 1 || (RT == 2 && NQ == 1 && BF3 && !FUSE_DG), "64-row tiles: the bf16-plane update without the fused data gradient");
+    constexpr int NQW = RT == 1 ? NQ : 2;  // 32 x 32 accumulator tiles per wave
     static_assert(!FUSE_DG || (FUSE_ADAM && (NQ == 2 || NQ == 4)), "the fused data gradient rides on the fused 256- / 512-column kernels");
     constexpr bool ROWS = FUSE_DG && NQ == 4;  // whole rows: the data gradient is complete here
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
@@ -208,7 +214,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     item /= a.n_jt;
     const int ft = item % a.n_ft;
     const int k = item / a.n_ft;
-    const int f0 = ft * 32, j0 = jt * JT, jw = wave * (32 * NQ);
+    const int f0 = ft * 32 * RT, j0 = jt * JT, jw = RT == 1 ? wave * (32 * NQ) : (wave & 1) * 64, rw = RT == 1 ? 0 : (wave >> 1) * 32;
     const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
     // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
     const int prow = t / LPR, pcol = (t % LPR) * 4;
@@ -228,16 +234,16 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             vv[d] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
         }
     }
-    f32x16 acc[NQ];
+    f32x16 acc[NQW];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQW; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
             const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
-            const unsigned short* Ap = a.a3p + slot * a.F * 32 + (long)(f0 + bl) * 32 + 16 * h;
+            const unsigned short* Ap = a.a3p + slot * a.F * 32 + (long)(f0 + rw + bl) * 32 + 16 * h;
             const unsigned short* Dp = a.dhp + slot * a.J * 32 + (long)(j0 + jw + bl) * 32 + 16 * h;
             bf16x8 A[3][2];
 #pragma unroll
@@ -245,7 +251,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
                 for (int s = 0; s < 2; ++s) A[pl][s] = *reinterpret_cast<const bf16x8*>(Ap + pl * pa + 8 * s);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < NQW; ++q) {
                 bf16x8 B[3][2];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -282,9 +288,9 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gs[rot(mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
+        for (int r = 0; r < 16; ++r) gs[rot(rw + mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
     __syncthreads();
     if (FUSE_DG && !upd) {  // deferred item: the pre-update theta tile goes to LDS as phase 2 would leave it, nothing is stored
 #pragma unroll

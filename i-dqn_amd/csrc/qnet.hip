@@ -1472,8 +1472,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     static const bool rows_on = getenv("IDQN_D0_ROWS") && atoi(getenv("IDQN_D0_ROWS")) != 0;
     const bool rows = rows_on && fuse_adam && fuse_dg && h->J == 512 && h->ov.n_def == 0;
     h->d0_rows = rows;
-    const int nq = rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
-    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
+    // IDQN_DP_TILE64=1: the bf16-plane update over several sample blocks (factored data-parallel step) on 64 x 128 tiles, a
+    // third less operand traffic per block than 32 x 256 (dense0_update.h).  Opt-in: parity green, measured neutral
+    // (profiles/r4_emulate_ranks_tile64_ab.txt: N = 8 emulated 414.9 against 412.7 us) -- the per-block cost of the contraction
+    // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
+    static const bool tile64_on = getenv("IDQN_DP_TILE64") && atoi(getenv("IDQN_DP_TILE64")) != 0;
+    const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
+    const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
+    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / (tile64 ? 64 : 32); dw.n_jt = h->J / (128 * nq);
     dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1;
     dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
@@ -1512,6 +1518,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, dw);
     } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    else if (tile64) D0W_LAUNCH(true, 1, false, true, 2);
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
