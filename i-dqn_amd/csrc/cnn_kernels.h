@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
 
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 : 0)];
+    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 + 4 : 0)];  // (+ 4: the last-arriver flag)
     dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 

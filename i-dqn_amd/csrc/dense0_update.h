@@ -166,6 +166,13 @@ struct DenseWgradArgs {
     ActGeom g;
     int C;
     float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
+    // FUSE_DG with column tiles (NQ < 4) and fin_ctr != nullptr: no finalize launch -- every workgroup writes its partial
+    // write-through and adds to the arrival counter of its 32 rows ([K * nb][n_ft], zero between launches); the one whose add
+    // comes last adds the column tiles' partials IN TILE ORDER (its own from registers, so the sum does not depend on who is
+    // last), applies the ReLU mask and writes the output forms (da3p / da3f / pb, g, C as for the full-row kernel).  Unlike the
+    // arrival at the end of the Dense_0 forward these arrivals are spread over the whole launch: the CU's other workgroup
+    // streams meanwhile.
+    unsigned* fin_ctr;
     // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
     // dhp[plane][bb][k][J * 32]
     const unsigned short *a3p, *dhp;
@@ -374,10 +381,42 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                     const float4 y = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
                     s4.x += y.x; s4.y += y.y; s4.z += y.z; s4.w += y.w;
                 }
+                bool finish = ROWS;
                 if (!ROWS) {
                     float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
-                    *reinterpret_cast<float4*>(O + t * 4) = s4;
-                } else {
+                    if (a.fin_ctr) {
+                        store16_sc1(O + t * 4, __builtin_bit_cast(u32x4, (f32x4v){s4.x, s4.y, s4.z, s4.w}));  // handed off in-launch
+                        int* flag = reinterpret_cast<int*>(gs + 32 * JT + 4096);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        if (t == 0) {
+                            unsigned* ctr = a.fin_ctr + ((long)k * a.nb + bb) * a.n_ft + ft;
+                            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int last = old == (unsigned)a.n_jt - 1u;
+                            if (last) {
+                                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            }
+                            *flag = last;
+                        }
+                        __syncthreads();
+                        if (*flag) {  // the column tiles' partials in tile order; this tile's from registers
+                            const long tile = (long)a.K * a.nb * a.F * 32;
+                            const float* P0 = a.dpart + ((long)k * a.nb + bb) * a.F * 32 + (long)f0 * 32 + t * 4;
+                            float4 acc4 = jt == 0 ? s4 : *reinterpret_cast<const float4*>(P0);
+                            for (int j = 1; j < a.n_jt; ++j) {
+                                const float4 y = j == jt ? s4 : *reinterpret_cast<const float4*>(P0 + j * tile);
+                                acc4.x += y.x; acc4.y += y.y; acc4.z += y.z; acc4.w += y.w;
+                            }
+                            s4 = acc4;
+                            finish = true;
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(O + t * 4) = s4;
+                    }
+                }
+                if (finish) {
                     // complete rows: ReLU mask of a3 and the three output forms of dL/da3 (as k_da3_finalize: one thread =
                     // 4 samples of one row f, 8 threads a row)
                     const int f = f0 + row, sl4 = (t & 7) * 4;

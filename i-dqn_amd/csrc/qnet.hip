@@ -331,6 +331,8 @@ struct idqn_handle_s {
     struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
     long adam_done_from = 0;  // > 0: the last backward's Conv_0 weight-gradient launch already updated the leaves from this element on
     bool d0_rows = false;  // the last fused Dense_0 launch ran on full rows and finished dL/da3 itself
+    bool d0_fin = false;   // ... on column tiles whose last-arriving workgroup finished dL/da3 (DenseWgradArgs::fin_ctr)
+    unsigned* fin_ctr = nullptr;  // [K * nb_max][F / 32] arrival counters of that hand-off (zero between launches)
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
@@ -485,6 +487,11 @@ int cnn_setup(idqn_handle_s* h) {
         h->chain_ws = reinterpret_cast<unsigned*>(ws);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+        {
+            float* fc = nullptr;
+            if ((rc = alloc_zero(&fc, (long)K * nb * (h->F / 32) + 64, h, "fin_ctr"))) return rc;
+            h->fin_ctr = reinterpret_cast<unsigned*>(fc);
+        }
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
         if ((rc = alloc_zero16(&h->da2p, (long)K * nb * h->gda2.block * 3, h, "da2p"))) return rc;
         if ((rc = alloc_zero16(&h->da1p, (long)K * nb * h->gda1.block * 3, h, "da1p"))) return rc;
@@ -1440,6 +1447,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
     dw.a3p = dw.dhp = nullptr;
+    dw.fin_ctr = nullptr;
     // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
     // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
     static const bool dp_f32 = getenv("IDQN_DP_F32") != nullptr;
@@ -1510,6 +1518,19 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, e0, e1, 0, dw); \
         else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, dw);             \
     } while (0)
+    // IDQN_D0_FIN=1: the column-tile kernel finishes dL/da3 itself -- the workgroup whose partial arrives last adds the tiles in
+    // order, masks and writes the output forms (DenseWgradArgs::fin_ctr), no k_da3_finalize launch.  Opt-in: bit-identical,
+    // measured 1 us SLOWER (profiles/r4_d0_fin_ab.txt): before its arrival add a workgroup has to drain its stores -- vmcnt
+    // counts in order, so that is every theta / m / v store of its streaming phase -- and the fused kernel grows by 7.6 us,
+    // the 5.4 us launch it saves (+ a boundary) notwithstanding.
+    static const bool fin_on = getenv("IDQN_D0_FIN") && atoi(getenv("IDQN_D0_FIN")) != 0;
+    h->d0_fin = false;
+    if (!rows && fuse_adam && nq == 2 && fuse_dg && fin_on && h->fin_ctr && h->planes) {
+        dw.fin_ctr = h->fin_ctr;
+        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
+        h->d0_fin = true;
+        if (h->ov.n_def > 0) h->ov.dw.fin_ctr = nullptr;  // (the deferred update items of the stream roles emit no data gradient)
+    }
     if (rows) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         const size_t lds = (size_t)(32 * 512 + 4096) * 4;
@@ -1619,7 +1640,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
-    if (fuse_dg && !h->d0_rows) {
+    if (fuse_dg && !h->d0_rows && !h->d0_fin) {
         Da3FinalizeArgs fa;
         fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
         fa.n_rows = (long)K * nb * h->F; fa.n_jt = h->J / 256; fa.F = h->F; fa.C = c2->CO; fa.K = K; fa.nb = nb; fa.g = h->gda3;

@@ -6,6 +6,7 @@
                       -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
   IDQN_D0_GROUP=0 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward without the in-workgroup split reduction / with the head's
                       first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical
+  IDQN_D0_FIN=1       the last-arriving column-tile workgroup instead of the k_da3_finalize launch  -> bit-identical
   IDQN_ADAM_ROLE=1    the Conv_0 weight-gradient launch carries the other small leaves' Adam update  -> bit-identical at
                       equal chunk counts
   IDQN_NO_PAIR=1      conv data / weight gradients as two launches   -> same losses, parameters within fp32 round-off
@@ -99,6 +100,16 @@ def test_dense0_forward_group_and_fused_head_stage(default_run):
     np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
     for name, want in default_run["probe"].items():
         np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_dense0_update_finishes_the_data_gradient_itself(default_run):
+    """Round 4 (opt-in, measured slower): IDQN_D0_FIN=1 lets the column-tile workgroup whose partial data gradient arrives
+    last add the tiles in tile order, apply the ReLU mask and write the planes / per-position sums (DenseWgradArgs::fin_ctr)
+    instead of the k_da3_finalize launch.  Same sums in the same order: bit-identical."""
+    got = _run(IDQN_D0_FIN="1")
+    assert got["losses"] == default_run["losses"]
+    assert got["probe"] == default_run["probe"]
+    assert got["acts"] == default_run["acts"]
 
 
 def test_adam_role_of_the_conv0_weight_gradient_launch(default_run):
