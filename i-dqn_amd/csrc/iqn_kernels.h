@@ -221,6 +221,74 @@ __global__ __launch_bounds__(256) void k_iqn_embed3(IqnEmbed3Args a) {
 #undef IE3_STEP
 }
 
+// The same with the cos fragments of a fraction copied ONCE per workgroup into LDS by LDS-DMA (the four waves of a
+// workgroup hold four feature tiles of the same (virtual net, fraction group) and read identical cos fragments: the
+// register version fetched them four times from L2, one step ahead, and waited for them -- 163 us where its 24 MFMAs per
+// 4 KB tile would allow ~45 and the 476 MB of stores ~95).  Two 12 KB buffers; per fraction: counted vmcnt (this wave's
+// three copies of the fraction have landed: only the 16 tile stores issued behind them may be outstanding), one barrier
+// (everybody's copies have landed, nobody still reads the other buffer), the copies of the next fraction, 12 ds_read_b128.
+__global__ __launch_bounds__(256) void k_iqn_embed3l(IqnEmbed3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char e3_lds[];  // [2][12][1024]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int ft = min((int)blockIdx.x * 4 + wave, a.F / 32 - 1);  // (a wave past the last tile repeats it: same barriers)
+    const bool live = (int)blockIdx.x * 4 + wave < a.F / 32;
+    const int v = blockIdx.y, type = v / a.K, k = v - type * a.K;
+    const int nq = a.N / (int)gridDim.z, q0 = blockIdx.z * nq;
+    const int f0 = ft * 32, pv = v < a.n_packed ? v : v - a.K;
+    const unsigned short* Wf = a.wep + (((long)pv * (a.F / 32) + ft) * 12) * 512 + lane * 8;
+    bf16x8 wf[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(Wf + (t * 3 + p) * 512);
+    const unsigned long cos0 = (unsigned long)(a.cosp + ((long)(v * a.N + q0) * 12) * 512);  // 12 KB per fraction
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&e3_lds[0];
+    auto copy = [&](int q, int buf) {  // pieces wave, wave + 4, wave + 8 of fraction q
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            dma16(lane * 16, cos0 + (unsigned long)q * 12288 + (unsigned long)(wave + 4 * i) * 1024, lds0 + buf * 12288 + (wave + 4 * i) * 1024);
+    };
+    copy(0, 0);
+    const float* P = a.wbase[v];
+    const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
+    float be[16], ps[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int f = f0 + mfma_row(i, h);
+        be[i] = P[a.be_off + f];
+        ps[i] = psi[(long)f * 32 + r];
+    }
+    for (int q = 0; q < nq; ++q) {
+        const int buf = q & 1;
+        // this wave's copies of fraction q: issued before the 16 stores of fraction q - 1 (none for q = 0)
+        if (q == 0 || !live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a wave without a tile issues no stores)
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (q + 1 < nq) copy(q + 1, buf ^ 1);
+        const unsigned char* C = e3_lds + buf * 12288 + lane * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 c0 = *LDS_PTR(const bf16x8, C + (t * 3 + 0) * 1024), c1 = *LDS_PTR(const bf16x8, C + (t * 3 + 1) * 1024),
+                         c2 = *LDS_PTR(const bf16x8, C + (t * 3 + 2) * 1024);
+            acc = mfma_bf16(wf[t][2], c0, acc);
+            acc = mfma_bf16(wf[t][0], c2, acc);
+            acc = mfma_bf16(wf[t][1], c1, acc);
+            acc = mfma_bf16(wf[t][1], c0, acc);
+            acc = mfma_bf16(wf[t][0], c1, acc);
+            acc = mfma_bf16(wf[t][0], c0, acc);
+        }
+        float* X = a.x + (long)(v * a.N + q0 + q) * a.F * 32;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_nontemporal_store(fmaxf(acc[i] + be[i], 0.f) * ps[i], X + (long)(f0 + mfma_row(i, h)) * 32 + r);
+        }
+    }
+}
+
 // Z[slot][action][b] = b1[action] + the Dense_1 chunk partials in chunk order: one workgroup per (virtual net, fraction).
 struct IqnZArgs {
     const float* qpart;         // [V * N][J / 32][32 (action)][32]

@@ -2003,7 +2003,10 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
             IqnEmbed3Args e3;
             e3.cosp = w.cosp; e3.wep = w.wep; e3.wbase = wbase_v; e3.psi = psi; e3.x = w.xq; e3.be_off = w.off_be;
             e3.K = K_for_index; e3.N = w.N; e3.F = h->F; e3.n_packed = n_packed;
-            hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
+            // cos fragments through LDS, once per workgroup (IDQN_IQN_EMBED_LDS=0: every wave fetches its own from L2)
+            static const bool e3lds = !(getenv("IDQN_IQN_EMBED_LDS") && atoi(getenv("IDQN_IQN_EMBED_LDS")) == 0);
+            if (e3lds) hipLaunchKernelGGL(k_iqn_embed3l, grid, dim3(256), 2 * 12288, q, e3);
+            else hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
         } else {
             hipLaunchKernelGGL(k_iqn_embed, grid, dim3(256), 0, q, ea);
         }
