@@ -16,13 +16,13 @@ timeout -k 10 400 python bench.py --algo iiqn --steps 30 --warmup 5 --repeats 3 
 rm -rf $O/prof_iiqn; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_iiqn -- python bench.py --algo iiqn --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/prof_iiqn.log 2>&1
 cp $O/prof_iiqn/*/*_kernel_stats.csv $O/iiqn_kernel_stats.csv && echo "iiqn kernel stats ok"
 IDQN_OVERLAP=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_overlap.json 2> $O/bench_overlap.err; echo "overlap rc=$?"
-# round 4: the opt-in launch structures (in-launch hand-offs / roles), each against the default on THIS box
-for sw in IDQN_CONV_CHAIN=1 IDQN_D0_FUSE_HIDDEN=1 IDQN_D0_FIN=1 IDQN_ADAM_ROLE=1 IDQN_D0_GROUP=0; do
+# round 4: the opt-in launch structures (in-launch hand-offs / roles), each against the default on THIS box (IDQN_NONE=1: the default)
+for sw in IDQN_NONE=1 IDQN_CONV_CHAIN=1 IDQN_D0_FUSE_HIDDEN=1 IDQN_D0_FIN=1 IDQN_ADAM_ROLE=1 IDQN_D0_GROUP=0; do
   env $sw timeout -k 10 200 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_$sw.json 2> $O/bench_$sw.err; echo "$sw rc=$?"
 done
 rm -rf $O/prof_chain; IDQN_CONV_CHAIN=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_chain -- python bench.py --steps 100 --warmup 20 --repeats 1 --no-cpu-baseline > $O/prof_chain.log 2>&1
 cp $O/prof_chain/*/*_kernel_stats.csv $O/chain_kernel_stats.csv && echo "chain kernel stats ok"
-timeout -k 10 200 python tools/probes/chain_prof.py > $O/chain_timeline.txt 2>&1; echo "chain timeline rc=$?"
+IDQN_CONV_CHAIN=1 timeout -k 10 200 python tools/probes/chain_prof.py > $O/chain_timeline.txt 2>&1; echo "chain timeline rc=$?"
 timeout -k 10 400 python tools/bench_heads.py > $O/heads.txt 2> $O/heads.err; echo "heads rc=$?"; cat $O/heads.txt
 timeout -k 10 300 python tools/bench_loop.py > $O/loop_all.log 2>&1; grep -E "us per|env steps" $O/loop_all.log > $O/loop.txt
 timeout -k 10 200 python tools/bench_fc.py 2>/dev/null | grep -E "^fc " >> $O/loop.txt; cat $O/loop.txt
@@ -36,7 +36,7 @@ print("BENCH %.1f steps/s  %.4f ms/step  dominant %.1f us %.0f GB/s frac %.3f  s
 for k in d["kernels"]: print("  %-36s %7.1f us" % (k["launch"], k["us"]))
 print("sampling", json.dumps(d.get("sampling"))[:600])
 for f in ("bench_a18","bench_dp1_factored","bench_dp1_allreduce","bench_hp8","bench_emulate1","bench_emulate2","bench_emulate4","bench_emulate8","bench_iiqn","bench_overlap",
-          "bench_IDQN_CONV_CHAIN=1","bench_IDQN_D0_FUSE_HIDDEN=1","bench_IDQN_D0_FIN=1","bench_IDQN_ADAM_ROLE=1","bench_IDQN_D0_GROUP=0"):
+          "bench_IDQN_NONE=1","bench_IDQN_CONV_CHAIN=1","bench_IDQN_D0_FUSE_HIDDEN=1","bench_IDQN_D0_FIN=1","bench_IDQN_ADAM_ROLE=1","bench_IDQN_D0_GROUP=0"):
     try:
         x=json.load(open("gpurun_out/final/%s.json"%f)); print(f, "%.1f %s  %.4f ms/step" % (x["value"], x["unit"], x["ms_per_step"]))
     except Exception as e: print(f, "failed", e)

@@ -6,6 +6,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
 os.environ["IDQN_CONV_PROF"] = "10"
+os.environ["IDQN_CONV_CHAIN"] = "1"  # (the chained launch is opt-in)
 import numpy as np
 import torch
 from collections import namedtuple
