@@ -376,7 +376,8 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
     {
-        static const bool grp = !(getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) == 0);
+        static const bool grp = (getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) != 0) ||
+                                (getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0);
         s.G = (grp && h->planes && units_per_split <= 0 && s.NS >= 8 && s.NS % 4 == 0) ? 4 : 1;
     }
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
@@ -456,8 +457,12 @@ int cnn_setup(idqn_handle_s* h) {
         int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
         if (const char* e = getenv("IDQN_D0_SPLITS")) ns = atoi(e);
         h->NS = std::max(1, std::min(std::min(ns, 64), units));
-        // groups of four splits per workgroup (DenseFwdArgs::G): a multiple of 4 that still keeps <= 256 workgroups busy
-        static const bool grp = !(getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) == 0);
+        // IDQN_D0_GROUP=1 (implied by IDQN_D0_FUSE_HIDDEN=1): groups of four splits per workgroup (DenseFwdArgs::G), NS a
+        // multiple of 4 that still keeps <= 256 workgroups busy.  Opt-in: a quarter of the partial slabs (-12 MB, k_hidden
+        // 5.5 -> 4.9 us) against +2.4 us in the forward itself (240 instead of 250 workgroups, the LDS reduce; rocprofv3),
+        // step +-1 us depending on the box (profiles/r4_d0fwd_group_fuse_ab.txt).
+        static const bool grp = (getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) != 0) ||
+                                (getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0);
         if (grp && h->planes && h->NS >= 8) h->NS = h->NS / 4 * 4;
     }
     const int K = c.n_heads, nb = h->nb_max;

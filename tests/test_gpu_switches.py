@@ -4,8 +4,8 @@
   IDQN_STEP_GRAPH=1   the plain step replayed as a hipGraph          -> bit-identical to the eager launches
   IDQN_CONV_CHAIN=1   the three forward convs as ONE launch with per-item flag hand-offs (csrc/convp_chain.hip)
                       -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
-  IDQN_D0_GROUP=0 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward without the in-workgroup split reduction / with the head's
-                      first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical
+  IDQN_D0_GROUP=1 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward with the in-workgroup split reduction / also with the head's
+                      first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical to the grouped one
   IDQN_D0_FIN=1       the last-arriving column-tile workgroup instead of the k_da3_finalize launch  -> bit-identical
   IDQN_ADAM_ROLE=1    the Conv_0 weight-gradient launch carries the other small leaves' Adam update  -> bit-identical at
                       equal chunk counts
@@ -90,13 +90,14 @@ def test_chained_forward_convs_are_bit_identical():
 
 
 def test_dense0_forward_group_and_fused_head_stage(default_run):
-    """Round 4: the Dense_0 forward adds four consecutive splits per workgroup through LDS (IDQN_D0_GROUP=0: one slab per
-    split, another association of the same sum -> fp32 round-off); IDQN_D0_FUSE_HIDDEN=1 lets that launch carry the head's
-    first stage, the last-arriving workgroup of a column tile doing what k_hidden does -> bit-identical."""
-    got = _run(IDQN_D0_FUSE_HIDDEN="1")
-    assert got["losses"] == default_run["losses"]
-    assert got["probe"] == default_run["probe"]
-    got = _run(IDQN_D0_GROUP="0")
+    """Round 4 (both opt-in, measured neutral): IDQN_D0_GROUP=1 lets the Dense_0 forward add four consecutive splits per
+    workgroup through LDS (a quarter of the partial slabs; another association of the same sum -> fp32 round-off);
+    IDQN_D0_FUSE_HIDDEN=1 additionally lets that launch carry the head's first stage, the last-arriving workgroup of a
+    column tile doing what k_hidden does -> bit-identical to the grouped forward + k_hidden."""
+    got = _run(IDQN_D0_GROUP="1")
+    fused = _run(IDQN_D0_FUSE_HIDDEN="1")
+    assert fused["losses"] == got["losses"]
+    assert fused["probe"] == got["probe"]
     np.testing.assert_allclose(np.asarray(got["losses"]), np.asarray(default_run["losses"]), rtol=0, atol=1e-6)
     for name, want in default_run["probe"].items():
         np.testing.assert_allclose(np.asarray(got["probe"][name]), np.asarray(want), rtol=0, atol=2e-6, err_msg=name)
