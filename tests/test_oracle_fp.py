@@ -37,6 +37,34 @@ def test_numpy_and_autograd_restatements_agree(arch, obs, feats, A, K, B):
             assert np.abs(g1[n] - g2[n]).max() <= 1e-9 * (np.abs(g2[n]).max() + 1e-30), n
 
 
+@pytest.mark.parametrize("arch,obs,feats,A,K,B", CASES[:2])
+def test_gradients_match_central_differences(arch, obs, feats, A, K, B):
+    """A third angle on the fp oracle that needs no automatic differentiation at all: the analytic gradients of
+    `loss_and_grads` (the hand-written backward the HIP kernels are pinned to) against central differences of ITS OWN fp64
+    loss in random coordinates of every leaf.  A backward pass that agreed with torch's autograd only because both shared a
+    misreading of the forward (padding, flatten order, the target's stop-gradient) would still have to be the derivative of
+    the loss the forward computes."""
+    p, pt, batch = _setup(arch, obs, feats, A, K, B)
+    rng = np.random.default_rng(17)
+    k = 0
+    hp = {n: v.astype(np.float64) for n, v in Q.head(p, k).items()}
+    ht = {n: v.astype(np.float64) for n, v in Q.head(pt, k).items()}
+    _, g, _ = Q.loss_and_grads(hp, ht, batch, arch, 0.99)
+    for n, leaf in hp.items():
+        flat = leaf.reshape(-1)
+        for i in rng.choice(flat.size, size=min(6, flat.size), replace=False):
+            old, eps = flat[i], 1e-5 * max(1.0, abs(flat[i]))
+            flat[i] = old + eps
+            lp = Q.loss_and_grads(hp, ht, batch, arch, 0.99)[0]
+            flat[i] = old - eps
+            lm = Q.loss_and_grads(hp, ht, batch, arch, 0.99)[0]
+            flat[i] = old
+            num, ana = (lp - lm) / (2 * eps), g[n].reshape(-1)[i]
+            # (ReLU kinks: a unit that flips inside +-eps breaks the difference quotient, not the gradient -- allow 1e-4 relative
+            # of the leaf's largest gradient, far above fp64 noise and far below any structural error)
+            assert abs(num - ana) <= 1e-4 * (np.abs(g[n]).max() + 1e-12) + 1e-9, (n, int(i), num, ana)
+
+
 def test_same_padding_geometry():
     # architectures/dqn.py:43-51 with flax's default padding="SAME": 84 -> 21 -> 11 -> 11, flatten 7744
     assert Q.same_pad(84, 8, 4) == (21, 2, 2)
