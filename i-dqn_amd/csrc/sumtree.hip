@@ -445,6 +445,31 @@ extern "C" int sampler_prioritized_remove(double* nodes_dev, int32_t depth, int3
     return IDQN_OK;
 }
 
+// UniformSamplingDistribution's map on the device (samplers.py:26-49): add writes index_to_key[len] = key, remove writes the
+// moved last key into the hole -- both are ONE int32 store, passed by value (the host map knows index and key); sample maps
+// the host generator's indices to keys with a gather.  Only a sampler that opts in pays for it (the reference protocol hands
+// host keys to host code; the device copy serves callers that keep the sampled keys on the device).
+__global__ void k_sampler_map_set(int32_t* __restrict__ index_to_key, int index, int key) { index_to_key[index] = key; }
+__global__ void k_sampler_map_indices(const int32_t* __restrict__ index_to_key, const int32_t* __restrict__ indices, int n,
+                                      int32_t* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = index_to_key[indices[i]];
+}
+extern "C" int sampler_map_set(int32_t* index_to_key_dev, int32_t index, int32_t key, void* stream) {
+    IDQN_REQUIRE(index_to_key_dev && index >= 0, "sampler_map_set: bad arguments");
+    hipLaunchKernelGGL(k_sampler_map_set, dim3(1), dim3(1), 0, (hipStream_t)stream, index_to_key_dev, index, key);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+extern "C" int sampler_map_indices(const int32_t* index_to_key_dev, const int32_t* indices_dev, int32_t n, int32_t* keys_out_dev,
+                                   void* stream) {
+    IDQN_REQUIRE(index_to_key_dev && indices_dev && keys_out_dev && n >= 1, "sampler_map_indices: bad arguments");
+    hipLaunchKernelGGL(k_sampler_map_indices, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, index_to_key_dev, indices_dev, n,
+                       keys_out_dev);
+    IDQN_HIP_CHECK(hipGetLastError());
+    return IDQN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // One host read per query / sample (reference protocol: SumTree.query returns numpy, sum_tree.py:58-102;
 // PrioritizedSamplingDistribution.sample returns host keys, samplers.py:105-116).  The n targets (or the n uniforms the

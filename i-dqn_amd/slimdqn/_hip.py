@@ -59,6 +59,8 @@ SYMBOLS = {
     "sampler_mailbox_destroy": (C.c_int, [_P]),
     "sumtree_query_host": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), _P]),
+    "sampler_map_set": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "sampler_map_indices": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "sampler_prioritized_add": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_double, _P]),
     "sampler_prioritized_remove": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     "per_sample_leaves": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),

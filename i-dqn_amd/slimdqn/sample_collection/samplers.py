@@ -8,7 +8,9 @@ Priorities and the inverse-CDF query run on the device (``sum_tree.SumTree``).  
 ``index -> key`` in HBM (written by the same launches that write the priorities), so that ``sample`` is ONE launch and
 ONE host read (leaves -> keys on the device, root and status in the same mailbox) and ``remove`` reads the moved priority
 on the device instead of the host.  The host dict / list stay as the mirror the reference's tests reach into and as the
-argument check of ``remove`` (``samplers.py:27``); ``key -> index`` has no device consumer.
+argument check of ``remove`` (``samplers.py:27``); ``key -> index`` has no device consumer.  The uniform sampler is host-only
+by default (a host generator feeding host arithmetic); ``enable_device_map`` gives it the same device copy of ``index -> key``
+(``sampler_map_set`` per add / remove) and ``sample_device`` hands out the sampled keys as a device tensor.
 """
 import numpy as np
 import torch
@@ -60,15 +62,39 @@ class UniformSamplingDistribution:
     _key_to_index = property(lambda self: self._map.key_to_index)
     _index_to_key = property(lambda self: self._map.index_to_key)
 
+    _i2k_dev = None  # optional device copy of index -> key (enable_device_map)
+
+    def enable_device_map(self, capacity: int) -> None:
+        """Keeps a copy of ``index -> key`` in HBM (``sampler_map_set`` on every add / remove) so that ``sample_device``
+        can hand out the sampled keys as a device tensor.  Not part of the reference's protocol: opt-in."""
+        self._i2k_dev = torch.zeros(int(capacity), dtype=torch.int32, device="cuda")
+        for i, k in enumerate(self._map.index_to_key):
+            _hip.check(_hip.lib().sampler_map_set(_hip.ptr(self._i2k_dev), i, int(k), _hip.current_stream()), "sampler_map_set")
+
     def add(self, key: ReplayItemID) -> None:
-        self._map.add(key)
+        index = self._map.add(key)
+        if self._i2k_dev is not None:
+            _hip.check(_hip.lib().sampler_map_set(_hip.ptr(self._i2k_dev), index, int(key), _hip.current_stream()), "sampler_map_set")
 
     def remove(self, key: ReplayItemID) -> None:
-        self._map.remove(key)
+        hole, last = self._map.remove(key)
+        if self._i2k_dev is not None and hole != last:  # the last entry moved into the hole (samplers.py:31-35)
+            _hip.check(_hip.lib().sampler_map_set(_hip.ptr(self._i2k_dev), hole, int(self._map.index_to_key[hole]),
+                                                  _hip.current_stream()), "sampler_map_set")
 
     def sample(self, size: int):
         assert self._map.index_to_key, ValueError("No keys to sample from.")
         return self._map.keys_at(self._rng_key.integers(len(self._map), size=size))
+
+    def sample_device(self, size: int):
+        """``sample`` with the keys left on the device (int32 tensor): the same generator draw, mapped by ``sampler_map_indices``."""
+        assert self._i2k_dev is not None, "enable_device_map first"
+        assert self._map.index_to_key, ValueError("No keys to sample from.")
+        idx = torch.from_numpy(self._rng_key.integers(len(self._map), size=size).astype(np.int32)).cuda()
+        out = torch.empty(int(idx.numel()), dtype=torch.int32, device="cuda")
+        _hip.check(_hip.lib().sampler_map_indices(_hip.ptr(self._i2k_dev), _hip.ptr(idx), int(idx.numel()), _hip.ptr(out),
+                                                  _hip.current_stream()), "sampler_map_indices")
+        return out
 
 
 class PrioritizedSamplingDistribution(UniformSamplingDistribution):
@@ -129,4 +155,22 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         if status & 1:
             raise ValueError(f"Targets must be in the interval [0.0, {root}).")
         assert not (status & 2), "sum tree traversal: target not below its node (sum_tree.py:81)"
+        return keys
+
+    def enable_device_map(self, capacity: int) -> None:
+        pass  # (always on: add / remove write the map in the launches that write the priorities)
+
+    def sample_device(self, size: int):
+        """``sample`` with the keys left on the device and no host read at all: the same generator draw, targets ``u * root``
+        made on the device (clamped below the root where the reference would raise), leaves mapped by ``sampler_map_indices``."""
+        assert self._map.index_to_key, ValueError("No keys to sample from.")
+        tree = self._sum_tree
+        u = torch.from_numpy(self._rng_key.random(size)).cuda()
+        leaves = torch.empty(int(u.numel()), dtype=torch.int32, device="cuda")
+        keys = torch.empty_like(leaves)
+        lib, q = _hip.lib(), _hip.current_stream()
+        _hip.check(lib.per_sample_leaves(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(u), int(u.numel()), 0, _hip.ptr(leaves), q),
+                   "per_sample_leaves")
+        _hip.check(lib.sampler_map_indices(_hip.ptr(self._i2k_dev), _hip.ptr(leaves), int(u.numel()), _hip.ptr(keys), q),
+                   "sampler_map_indices")
         return keys

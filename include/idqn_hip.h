@@ -223,6 +223,12 @@ int sumtree_query_host(const double* nodes_dev, int32_t depth, const double* val
                        int32_t scale_by_root, const int32_t* index_to_key_dev, void* mailbox,
                        int32_t* leaves_out_host, int32_t* keys_out_host, double* root_out_host,
                        int32_t* status_out_host, void* stream);
+/* UniformSamplingDistribution's index -> key map on the device (samplers.py:26-49), for callers that keep sampled keys on
+ * the device: add = sampler_map_set(map, len, key); remove = sampler_map_set(map, hole, moved last key) (:31-35: the host
+ * map knows both); sample = sampler_map_indices over the int32 indices the host generator drew (:43-49). */
+int sampler_map_set(int32_t* index_to_key_dev, int32_t index, int32_t key, void* stream);
+int sampler_map_indices(const int32_t* index_to_key_dev, const int32_t* indices_dev, int32_t n, int32_t* keys_out_dev,
+                        void* stream);
 /* PrioritizedSamplingDistribution.add (samplers.py:62-66): index_to_key[index] = key and tree.set(index, value) for the
  * new last index, ONE launch.  The inverse map key -> index stays a host dict: its only consumers are host-called
  * operations whose arguments are host keys (remove, update). */

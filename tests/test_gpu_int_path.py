@@ -267,3 +267,35 @@ def test_prioritized_sampler_empty_tree_branch_consumes_the_stream_like_the_refe
     a.update(np.asarray([1], np.int32), np.asarray([2.0]))
     b.update(np.asarray([1], np.int32), np.asarray([2.0]))
     np.testing.assert_array_equal(a.sample(8), b.sample(8))
+
+
+def test_uniform_sampler_device_map_and_device_samples():
+    """SURVEY 8b lists the samplers' index <-> key maps among the device state.  The uniform sampler keeps its map on the host
+    by default (its output feeds host code); with `enable_device_map` every add / remove also writes the HBM copy
+    (sampler_map_set) and `sample_device` maps the generator's indices on the device (sampler_map_indices): after a random
+    add / remove sequence the device map equals the host list and twin samplers return the same keys either way.  Likewise
+    the prioritized sampler's all-device `sample_device` against its host-returning `sample`."""
+    _, Uniform, Prioritized, _, _ = _classes()
+    a, b = Uniform(5), Uniform(5)
+    a.enable_device_map(256)
+    rng = np.random.default_rng(3)
+    live, nxt = [], 0
+    for _ in range(300):
+        if len(live) < 2 or (rng.random() < 0.6 and len(live) < 256):
+            a.add(nxt); b.add(nxt); live.append(nxt); nxt += 1
+        else:
+            k = live.pop(int(rng.integers(len(live))))
+            a.remove(k); b.remove(k)
+    np.testing.assert_array_equal(a._i2k_dev[: len(live)].cpu().numpy(), np.asarray(b._index_to_key, np.int32))
+    for n in (1, 7, 64):
+        np.testing.assert_array_equal(a.sample_device(n).cpu().numpy(), b.sample(n))
+    a.enable_device_map(256)  # (re-enabling rebuilds the copy from the host list)
+    np.testing.assert_array_equal(a._i2k_dev[: len(live)].cpu().numpy(), np.asarray(b._index_to_key, np.int32))
+    pa, pb = Prioritized(8, 128, 0.7), Prioritized(8, 128, 0.7)
+    for k in range(90):
+        pr = float(rng.random() * 2)
+        pa.add(k, priority=pr); pb.add(k, priority=pr)
+    for k in (0, 89, 40, 41):
+        pa.remove(k); pb.remove(k)
+    for n in (1, 32, 100):
+        np.testing.assert_array_equal(pa.sample_device(n).cpu().numpy(), pb.sample(n))
