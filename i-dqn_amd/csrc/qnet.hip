@@ -2519,6 +2519,7 @@ static int act_host_wait(idqn_handle_t h, int32_t* action_host_pinned, hipStream
 
 extern "C" int idqn_act_host(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
                              int32_t* action_host_pinned, void* stream) {
+    IDQN_REQUIRE(h && h->act_pending == 0, "idqn_act_host: null handle, or an idqn_act_host_begin is still waiting for its _end");
     return act_host_impl(h, which, head, state_host_pinned, q_out_dev, action_host_pinned, stream, true);
 }
 extern "C" int idqn_act_host_begin(idqn_handle_t h, int32_t which, int32_t head, const void* state_host_pinned, float* q_out_dev,
