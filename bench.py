@@ -493,7 +493,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes},
+                         "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes,
+                         # context, not the contract's `frac`: what a pure non-temporal copy reaches on this chip
+                         # (profiles/r4_ldsdma_copy_probe.txt: 6.1-6.25 TB/s read + write; MI355X_MICROARCH.md: 6.29)
+                         "copy_ceiling": 6200.0, "frac_of_copy_ceiling": achieved / 6200.0},
             # the whole step against its two floors (per GPU: every rank does one 32-sample step per global step)
             "step_roofline": {"flops": step_flops, "bytes": step_bytes,
                               "floor_us_mfma_f32": step_flops / MFMA_F32_PEAK * 1e6, "floor_us_hbm": step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6,
