@@ -1037,10 +1037,10 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
     dense0_wgrad_body<true, 4, true, false>(a, (int)blockIdx.x + a.item0, gs_dyn, (int)threadIdx.x);
 }
 
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1>
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1, bool FIN = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 + 4 : 0)];  // (+ 4: the last-arriver flag)
-    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 : 0) + (FIN ? 4 : 0)];  // (+ 4: the last-arriver flag)
+    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

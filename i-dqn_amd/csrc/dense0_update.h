@@ -204,7 +204,9 @@ struct DenseWgradArgs {
 // 32 x 64 wave tiles (wave w: row half w >> 1, column half w & 1), the same number of workgroups, but (64 + 128) instead of
 // (32 + 256) operand rows per sample block: a third less L2 -> CU operand traffic, which is what the N-block contraction of
 // the factored data-parallel update is bound by (qnet.hip, launch_dense0_wgrad); theta / m / v stream as 512-byte row pieces.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+// FIN (with FUSE_DG on column tiles): the last-arriving column-tile workgroup finishes dL/da3 (DenseWgradArgs::fin_ctr).  A
+// template parameter, not a run-time branch: as a branch it cost the DEFAULT instantiation 32 bytes of scratch per lane.
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
@@ -384,7 +386,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                 bool finish = ROWS;
                 if (!ROWS) {
                     float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
-                    if (a.fin_ctr) {
+                    if constexpr (FIN) {
                         store16_sc1(O + t * 4, __builtin_bit_cast(u32x4, (f32x4v){s4.x, s4.y, s4.z, s4.w}));  // handed off in-launch
                         int* flag = reinterpret_cast<int*>(gs + 32 * JT + 4096);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,6 +418,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                         *reinterpret_cast<float4*>(O + t * 4) = s4;
                     }
                 }
+                if constexpr (ROWS || FIN)
                 if (finish) {
                     // complete rows: ReLU mask of a3 and the three output forms of dL/da3 (as k_da3_finalize: one thread =
                     // 4 samples of one row f, 8 threads a row)

@@ -1543,7 +1543,8 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, dw);
-    } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    } else if (fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
+    else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (tile64) D0W_LAUNCH(true, 1, false, true, 2);
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
