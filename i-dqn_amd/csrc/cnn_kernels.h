@@ -1040,7 +1040,15 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1, bool FIN = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 : 0) + (FIN ? 4 : 0)];  // (+ 4: the last-arriver flag)
+    d0_stagger(a.stagger);
     dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+}
+// The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
+// 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
+__global__ __launch_bounds__(256) void k_dense0_wgrad_alds(DenseWgradArgs a) {
+    __shared__ __attribute__((aligned(1024))) float gs[32 * 256 + 4096];
+    d0_stagger(a.stagger);
+    dense0_wgrad_body<true, 2, false, true, 1, false, true>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

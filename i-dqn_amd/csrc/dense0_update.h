@@ -157,6 +157,7 @@ struct DenseWgradArgs {
     // sample block bb of head k: base + (bb / nb_inner) * outer + k * head + (bb % nb_inner) * inner   (floats)
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
+    int stagger;   // > 0: workgroup b < 3 * 256 of the stand-alone kernel waits (b / 256) * stagger ticks of the 100 MHz clock first (d0_stagger)
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
     int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
     // NQ = 4 (full 512-column rows) with FUSE_DG: the workgroup finishes dL/da3 itself -- what k_da3_finalize does otherwise
@@ -178,6 +179,18 @@ struct DenseWgradArgs {
     const unsigned short *a3p, *dhp;
 };
 
+
+// De-phasing experiment (IDQN_D0_STAGGER=<ticks of 10 ns>): the first 768 workgroups -- one per residency slot, three per CU --
+// start together and every tile costs the same, so the whole chip alternates between its MFMA phases and its streaming phase;
+// delaying the second and third slot of every CU by one and two thirds of a workgroup's lifetime lets one workgroup of a CU
+// contract while the other two stream.
+__device__ __forceinline__ void d0_stagger(const int ticks) {
+    const int slot = (int)blockIdx.x >> 8;
+    if (ticks > 0 && slot > 0 && slot < 3) {
+        const long long t0 = __builtin_amdgcn_s_memrealtime(), d = (long long)slot * ticks;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
+}
 
 // Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
 // on the MFMA (2 accumulators, k = the 32 samples per batch block) and parks it in LDS.  Phase 2: all 256
@@ -206,13 +219,20 @@ struct DenseWgradArgs {
 // the factored data-parallel update is bound by (qnet.hip, launch_dense0_wgrad); theta / m / v stream as 512-byte row pieces.
 // FIN (with FUSE_DG on column tiles): the last-arriving column-tile workgroup finishes dL/da3 (DenseWgradArgs::fin_ctr).  A
 // template parameter, not a run-time branch: as a branch it cost the DEFAULT instantiation 32 bytes of scratch per lane.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+// ALDS (with BF3, RT = 1, NQ = 2): the contraction over the N sample blocks of the factored data-parallel update was one
+// DEPENDENT round trip per block -- a tile's a3 planes are read exactly twice (once per column tile), i.e. they come from HBM,
+// and the 18 fragments of a block leave no registers for a second block in flight (7.7 us per extra block).  Here the tile's a3
+// fragments of up to 8 blocks (6 KB each) are copied up front by LDS-DMA, in fragment order, into the LDS the gradient tile is
+// parked in afterwards (+ 16 KB): ONE HBM round trip per tile; the dh fragments (L2-resident: 0.8 MB per head) stay in registers,
+// one block ahead.
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false, bool ALDS = false>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
     static_assert(RT == 1 || (RT == 2 && NQ == 1 && BF3 && !FUSE_DG), "64-row tiles: the bf16-plane update without the fused data gradient");
     constexpr int NQW = RT == 1 ? NQ : 2;  // 32 x 32 accumulator tiles per wave
     static_assert(!FUSE_DG || (FUSE_ADAM && (NQ == 2 || NQ == 4)), "the fused data gradient rides on the fused 256- / 512-column kernels");
+    static_assert(!ALDS || (BF3 && RT == 1 && NQ == 2), "a3 fragments through LDS: the 32 x 256 bf16-plane update");
     constexpr bool ROWS = FUSE_DG && NQ == 4;  // whole rows: the data gradient is complete here
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     // FUSE_DG with upd_end >= 0: items from upd_end on are DEFERRED -- their update runs later, in the stream role of a conv
@@ -234,7 +254,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     // (the full-row kernel has two workgroups per CU instead of three: deeper, to keep as many bytes in flight per CU)
     constexpr int DEPTH = (FUSE_DG && NQ == 4) ? D0W_DEPTH_ROWS : D0W_DEPTH;
     float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
-    if (FUSE_ADAM && upd) {
+    auto prefetch = [&]() {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const long on = o0 + (long)(RPI * d) * a.J;
@@ -242,12 +262,88 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             mm[d] = ld4<(D0_WG_NT & 1) != 0>(a.mu + on);
             vv[d] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
         }
-    }
+    };
+#ifndef D0W_ABL
+#define D0W_ABL 0
+#endif
+#ifndef D0W_ALDS_PRE
+#define D0W_ALDS_PRE 0  // 0: the ALDS variant requests its first row groups only after the contraction (48 registers less in the block loop)
+#endif
+    constexpr bool PRE_EARLY = !ALDS || D0W_ALDS_PRE;
+    if (FUSE_ADAM && upd && PRE_EARLY) prefetch();
     f32x16 acc[NQW];
 #pragma unroll
     for (int q = 0; q < NQW; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    if constexpr (ALDS) {
+        constexpr int CH = 8;  // sample blocks staged at once: CH * 3 planes * 2 KB = 48 KB
+        const long pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
+        const unsigned lds0 = (unsigned)(uintptr_t)gs;  // low half of a generic LDS address = the LDS byte address
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        // fragment order: piece (chunk c = block * 3 + plane, step s) is 1 KB = lane (h, bl)'s 16 bytes: row f0 + bl, samples 16 h + 8 s ..
+        const unsigned voff = (unsigned)(bl * 64 + 32 * h);
+        // dh fragments: wave-uniform base (scalar registers) + the lane's 32-bit byte offset, the same one as the a3 copies
+        const unsigned short* Dp0 = a.dhp + (long)(j0 + wv * 64) * 32;
+        auto load_b = [&](int bb, int q, bf16x8 (&Bq)[3][2]) {
+            const unsigned char* Dp = reinterpret_cast<const unsigned char*>(Dp0 + ((long)bb * a.K + k) * a.J * 32 + (long)q * 32 * 32);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) Bq[pl][s2] = *reinterpret_cast<const bf16x8*>(Dp + (pl * pd + 8 * s2) * 2 + voff);
+        };
+        for (int c0 = 0; c0 < a.nb; c0 += CH) {
+            const int nc = a.nb - c0 < CH ? a.nb - c0 : CH;
+            if (c0 > 0) __syncthreads();  // every wave has read the previous chunk's fragments
+            for (int pc = wv; pc < nc * 6; pc += 4) {  // 1 KB pieces, dealt to the four waves
+                const int c = pc >> 1, s2 = pc & 1, bbl = c / 3, pl = c - 3 * bbl;
+                const unsigned short* src = a.a3p + pl * pa + ((long)(c0 + bbl) * a.K + k) * a.F * 32 + (long)f0 * 32 + 8 * s2;
+                dma16(voff, (unsigned long)src, lds0 + (unsigned)pc * 1024);
+            }
+            bf16x8 B[4][3][2];  // ring of four (block parity, q) units: a unit is re-filled two blocks ahead once its 12 products are issued
+            load_b(c0, 0, B[0]);
+            load_b(c0, 1, B[1]);
+            if (nc > 1) {
+                load_b(c0 + 1, 0, B[2]);
+                load_b(c0 + 1, 1, B[3]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned char* lA = reinterpret_cast<const unsigned char*>(gs) + lane * 16;
+#pragma unroll 1
+            for (int bb2 = 0; bb2 < nc; bb2 += 2) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int bbl = bb2 + par;
+                    if (bbl < nc) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {  // the product order of the register version
+                                bf16x8 A[3];
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl) A[pl] = *reinterpret_cast<const bf16x8*>(lA + ((bbl * 3 + pl) * 2 + s2) * 1024);
+                                acc[q] = mfma_bf16(A[2], B[2 * par + q][0][s2], acc[q]);
+                                acc[q] = mfma_bf16(A[0], B[2 * par + q][2][s2], acc[q]);
+                                acc[q] = mfma_bf16(A[1], B[2 * par + q][1][s2], acc[q]);
+#if D0W_ABL != 1  // ablation 1: half the products (wrong results)
+                                acc[q] = mfma_bf16(A[1], B[2 * par + q][0][s2], acc[q]);
+                                acc[q] = mfma_bf16(A[0], B[2 * par + q][1][s2], acc[q]);
+                                acc[q] = mfma_bf16(A[0], B[2 * par + q][0][s2], acc[q]);
+#endif
+                            }
+#if D0W_ABL == 2  // ablation: the dh fragments of the first two blocks serve every block (wrong results): no operand wait in the loop
+                            if (false)
+#endif
+                            if (bbl + 2 < nc) load_b(c0 + bbl + 2, q, B[2 * par + q]);
+                        }
+                    }
+                }
+            }
+        }
+        if (!PRE_EARLY) prefetch();
+        __syncthreads();  // the gradient tile is parked over the fragments
+    } else
     for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first

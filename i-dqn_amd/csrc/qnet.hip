@@ -1452,6 +1452,8 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
     dw.a3p = dw.dhp = nullptr;
+    static const int stagger = getenv("IDQN_D0_STAGGER") ? atoi(getenv("IDQN_D0_STAGGER")) : 0;
+    dw.stagger = stagger;
     dw.fin_ctr = nullptr;
     // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
     // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
@@ -1490,6 +1492,8 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // (profiles/r4_emulate_ranks_tile64_ab.txt: N = 8 emulated 414.9 against 412.7 us) -- the per-block cost of the contraction
     // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
     static const bool tile64_on = getenv("IDQN_DP_TILE64") && atoi(getenv("IDQN_DP_TILE64")) != 0;
+    // IDQN_DP_ALDS=0: the register version of the contraction (one dependent HBM round trip per sample block)
+    static const bool alds = !(getenv("IDQN_DP_ALDS") && atoi(getenv("IDQN_DP_ALDS")) == 0);
     const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
     const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / (tile64 ? 64 : 32); dw.n_jt = h->J / (128 * nq);
@@ -1546,6 +1550,10 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     } else if (fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
     else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (tile64) D0W_LAUNCH(true, 1, false, true, 2);
+    else if (bf3 && alds) {
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_alds, wgrid, dim3(256), 0, q, dw);
+    }
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);

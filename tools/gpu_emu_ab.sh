@@ -1,0 +1,13 @@
+mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+run() { # label, env..., N
+  lbl="$1"; n="$2"; shift 2
+  env "$@" timeout -k 10 200 python bench.py --emulate-ranks $n --steps 200 --warmup 50 --no-cpu-baseline > gpurun_out/emu_tmp.json 2> gpurun_out/emu_tmp.err || { echo "[$lbl N=$n] failed"; tail -5 gpurun_out/emu_tmp.err; return 1; }
+  python - "$lbl" "$n" <<PY
+import json, sys
+d = json.load(open("gpurun_out/emu_tmp.json"))
+print("%-28s N=%s  %.1f us/step  losses %s" % (sys.argv[1], sys.argv[2], d["ms_per_step"] * 1e3, d["final_losses"]))
+PY
+}
+for n in 8 4 2; do
+  run "register (ALDS=0)" $n IDQN_DP_ALDS=0 && run "alds late-prefetch" $n IDQN_NONE=1 && run "register (ALDS=0)" $n IDQN_DP_ALDS=0 && run "alds late-prefetch" $n IDQN_NONE=1 || exit 1
+done
