@@ -4,6 +4,8 @@
 // fewer CUs carries a share of the update on the CUs it leaves free (qnet.hip, overlap modes).
 // Reference: optax.adam on Dense_0/kernel inside iDQN.learn_on_batch (slimdqn/networks/idqn.py:105-107).
 #pragma once
+#include <type_traits>
+
 #include "convp.h"
 
 // Cache policy of the Dense_0 streams (tools/probes/mall_policy_probe.hip, profiles/r3_mall_policy_probe.txt): a
@@ -397,6 +399,25 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
         for (int r = 0; r < 16; ++r) gs[rot(rw + mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
     __syncthreads();
+    // phase 3's dh values of the first sample block (L2-resident) are requested HERE, in front of the streaming phase: behind it
+    // they queued after the tile's last loads and stores and every workgroup opened phase 3 with a full round trip (32 registers,
+    // the kernel stays at three waves per SIMD)
+    constexpr int NCH3 = FUSE_DG ? 2 * NQ : 1;  // chunks of 8 MFMA steps (16 columns each) over this wave's 32 * NQ columns
+#ifndef D0W_PF3
+#define D0W_PF3 2  // chunks requested in front of the streaming phase; the others at the start of phase 3, behind them
+#endif
+    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN) ? D0W_PF3 : 0;
+    float dv[NCH3][8];
+    auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
+        const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
+        // A operand: dh^T, lane (b = bl, k = h) reads dh[j0 + jw + 2 t + h][b]
+        const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + h) * 32 + bl;
+#pragma unroll
+        for (int c = c_lo; c < c_hi; ++c)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[c][u] = Dp[(long)(16 * c + 2 * u) * 32];
+    };
+    if constexpr (PF3 > 0) load_dv(0, std::integral_constant<int, 0>{}, std::integral_constant<int, PF3>{});
     if (FUSE_DG && !upd) {  // deferred item: the pre-update theta tile goes to LDS as phase 2 would leave it, nothing is stored
 #pragma unroll
         for (int i0 = 0; i0 < NIT; i0 += 8) {
@@ -443,26 +464,19 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
         float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
         for (int bb = 0; bb < a.nb; ++bb) {
-            const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
-            // A operand: dh^T, lane (b = bl, k = h) reads dh[j0 + jw + 2 t + h][b]; B operand: theta_old[f = bl][j = jw + 2 t + h]
-            const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + h) * 32 + bl;
+            // A operand: dh^T (dv); B operand: theta_old[f = bl][j = jw + 2 t + h]
+            [[maybe_unused]] const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
+            if (bb > 0) load_dv(bb, std::integral_constant<int, 0>{}, std::integral_constant<int, NCH3>{});
+            else load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            float dv[2][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[0][u] = Dp[(long)(2 * u) * 32];
-            constexpr int NCH = 2 * NQ;  // chunks of 8 MFMA steps (16 columns each) over this wave's 32 * NQ columns
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c + 1 < NCH) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dv[(c + 1) & 1][u] = Dp[(long)(16 * (c + 1) + 2 * u) * 32];
-                }
+            for (int c = 0; c < NCH3; ++c) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int col = jw + 16 * c + 2 * u + h;
-                    d = mfma32(dv[c & 1][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
+                    d = mfma32(dv[c][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
                 }
             }
             // this wave's tile -> LDS: lane = row f (bl), 4 x 4 consecutive samples per register quad
