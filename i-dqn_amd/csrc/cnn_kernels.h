@@ -1045,10 +1045,11 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
 }
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
+template <int RT>  // 32 * RT rows x 256 columns
 __global__ __launch_bounds__(256) void k_dense0_wgrad_alds(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(1024))) float gs[32 * 256 + 4096];
+    __shared__ __attribute__((aligned(1024))) float gs[RT == 1 ? 32 * 256 + 4096 : 64 * 256];
     d0_stagger(a.stagger);
-    dense0_wgrad_body<true, 2, false, true, 1, false, true>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+    dense0_wgrad_body<true, 2, false, true, RT, false, true>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

@@ -226,15 +226,17 @@ __device__ __forceinline__ void d0_stagger(const int ticks) {
 // and the 18 fragments of a block leave no registers for a second block in flight (7.7 us per extra block).  Here the tile's a3
 // fragments of up to 8 blocks (6 KB each) are copied up front by LDS-DMA, in fragment order, into the LDS the gradient tile is
 // parked in afterwards (+ 16 KB): ONE HBM round trip per tile; the dh fragments (L2-resident: 0.8 MB per head) stay in registers,
-// one block ahead.
+// two blocks ahead.  RT = 2 with ALDS: a 64 x 256 tile -- the two row tiles share every dh fragment (half the L2 -> CU operand
+// traffic, twice the products behind every fragment wait), 64 accumulator registers, two workgroups per CU.
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false, bool ALDS = false>  // column tile JT = 128 * NQ (256 when the dense width allows it)
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
-    static_assert(RT == 1 || (RT == 2 && NQ == 1 && BF3 && !FUSE_DG), "64-row tiles: the bf16-plane update without the fused data gradient");
-    constexpr int NQW = RT == 1 ? NQ : 2;  // 32 x 32 accumulator tiles per wave
+    static_assert(RT == 1 || (RT == 2 && (NQ == 1 || ALDS) && BF3 && !FUSE_DG), "64-row tiles: the bf16-plane update without the fused data gradient");
+    constexpr bool TALL = ALDS && RT == 2;  // 64 x 256 tile: every wave keeps 64 columns of BOTH row halves (two tiles share the dh fragments)
+    constexpr int NQW = TALL ? 4 : RT == 1 ? NQ : 2;  // 32 x 32 accumulator tiles per wave
     static_assert(!FUSE_DG || (FUSE_ADAM && (NQ == 2 || NQ == 4)), "the fused data gradient rides on the fused 256- / 512-column kernels");
-    static_assert(!ALDS || (BF3 && RT == 1 && NQ == 2), "a3 fragments through LDS: the 32 x 256 bf16-plane update");
+    static_assert(!ALDS || (BF3 && NQ == 2), "a3 fragments through LDS: the 32 x 256 / 64 x 256 bf16-plane update");
     constexpr bool ROWS = FUSE_DG && NQ == 4;  // whole rows: the data gradient is complete here
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     // FUSE_DG with upd_end >= 0: items from upd_end on are DEFERRED -- their update runs later, in the stream role of a conv
@@ -245,7 +247,8 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     item /= a.n_jt;
     const int ft = item % a.n_ft;
     const int k = item / a.n_ft;
-    const int f0 = ft * 32 * RT, j0 = jt * JT, jw = RT == 1 ? wave * (32 * NQ) : (wave & 1) * 64, rw = RT == 1 ? 0 : (wave >> 1) * 32;
+    const int f0 = ft * 32 * RT, j0 = jt * JT, jw = (RT == 1 || TALL) ? wave * (32 * NQ) : (wave & 1) * 64,
+              rw = (RT == 1 || TALL) ? 0 : (wave >> 1) * 32;
     const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
     // phase-2 addressing: iteration i, this thread: row RPI * i + prow, columns pcol .. pcol + 3
     const int prow = t / LPR, pcol = (t % LPR) * 4;
@@ -279,11 +282,12 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     if constexpr (ALDS) {
-        constexpr int CH = 8;  // sample blocks staged at once: CH * 3 planes * 2 KB = 48 KB
+        constexpr int CH = 8 / RT;  // sample blocks staged at once: CH * RT row tiles * 3 planes * 2 KB = 48 KB
         const long pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
         const unsigned lds0 = (unsigned)(uintptr_t)gs;  // low half of a generic LDS address = the LDS byte address
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        // fragment order: piece (chunk c = block * 3 + plane, step s) is 1 KB = lane (h, bl)'s 16 bytes: row f0 + bl, samples 16 h + 8 s ..
+        // fragment order: piece ((block * RT + row tile) * 3 + plane, step s) is 1 KB = lane (h, bl)'s 16 bytes: row f0 + 32 rt + bl,
+        // samples 16 h + 8 s ..
         const unsigned voff = (unsigned)(bl * 64 + 32 * h);
         // dh fragments: wave-uniform base (scalar registers) + the lane's 32-bit byte offset, the same one as the a3 copies
         const unsigned short* Dp0 = a.dhp + (long)(j0 + wv * 64) * 32;
@@ -297,12 +301,12 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         for (int c0 = 0; c0 < a.nb; c0 += CH) {
             const int nc = a.nb - c0 < CH ? a.nb - c0 : CH;
             if (c0 > 0) __syncthreads();  // every wave has read the previous chunk's fragments
-            for (int pc = wv; pc < nc * 6; pc += 4) {  // 1 KB pieces, dealt to the four waves
-                const int c = pc >> 1, s2 = pc & 1, bbl = c / 3, pl = c - 3 * bbl;
-                const unsigned short* src = a.a3p + pl * pa + ((long)(c0 + bbl) * a.K + k) * a.F * 32 + (long)f0 * 32 + 8 * s2;
+            for (int pc = wv; pc < nc * 6 * RT; pc += 4) {  // 1 KB pieces, dealt to the four waves
+                const int c = pc >> 1, s2 = pc & 1, br = c / 3, pl = c - 3 * br, bbl = br / RT, rt = br - RT * bbl;
+                const unsigned short* src = a.a3p + pl * pa + ((long)(c0 + bbl) * a.K + k) * a.F * 32 + (long)(f0 + 32 * rt) * 32 + 8 * s2;
                 dma16(voff, (unsigned long)src, lds0 + (unsigned)pc * 1024);
             }
-            bf16x8 B[4][3][2];  // ring of four (block parity, q) units: a unit is re-filled two blocks ahead once its 12 products are issued
+            bf16x8 B[4][3][2];  // ring of four (block parity, q) units: a unit is re-filled two blocks ahead once its products are issued
             load_b(c0, 0, B[0]);
             load_b(c0, 1, B[1]);
             if (nc > 1) {
@@ -321,18 +325,23 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {  // the product order of the register version
-                                bf16x8 A[3];
+                            for (int s2 = 0; s2 < 2; ++s2) {  // per accumulator the product order of the register version
 #pragma unroll
-                                for (int pl = 0; pl < 3; ++pl) A[pl] = *reinterpret_cast<const bf16x8*>(lA + ((bbl * 3 + pl) * 2 + s2) * 1024);
-                                acc[q] = mfma_bf16(A[2], B[2 * par + q][0][s2], acc[q]);
-                                acc[q] = mfma_bf16(A[0], B[2 * par + q][2][s2], acc[q]);
-                                acc[q] = mfma_bf16(A[1], B[2 * par + q][1][s2], acc[q]);
+                                for (int rt = 0; rt < RT; ++rt) {
+                                    bf16x8 A[3];
+#pragma unroll
+                                    for (int pl = 0; pl < 3; ++pl)
+                                        A[pl] = *reinterpret_cast<const bf16x8*>(lA + (((bbl * RT + rt) * 3 + pl) * 2 + s2) * 1024);
+                                    f32x16& d = acc[2 * rt + q];
+                                    d = mfma_bf16(A[2], B[2 * par + q][0][s2], d);
+                                    d = mfma_bf16(A[0], B[2 * par + q][2][s2], d);
+                                    d = mfma_bf16(A[1], B[2 * par + q][1][s2], d);
 #if D0W_ABL != 1  // ablation 1: half the products (wrong results)
-                                acc[q] = mfma_bf16(A[1], B[2 * par + q][0][s2], acc[q]);
-                                acc[q] = mfma_bf16(A[0], B[2 * par + q][1][s2], acc[q]);
-                                acc[q] = mfma_bf16(A[0], B[2 * par + q][0][s2], acc[q]);
+                                    d = mfma_bf16(A[1], B[2 * par + q][0][s2], d);
+                                    d = mfma_bf16(A[0], B[2 * par + q][1][s2], d);
+                                    d = mfma_bf16(A[0], B[2 * par + q][0][s2], d);
 #endif
+                                }
                             }
 #if D0W_ABL == 2  // ablation: the dh fragments of the first two blocks serve every block (wrong results): no operand wait in the loop
                             if (false)
@@ -397,7 +406,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #pragma unroll
     for (int q = 0; q < NQW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gs[rot(rw + mfma_row(r, h), jw + 32 * q + bl)] = acc[q][r];
+        for (int r = 0; r < 16; ++r) gs[rot(rw + (TALL ? 32 * (q >> 1) : 0) + mfma_row(r, h), jw + 32 * (TALL ? q & 1 : q) + bl)] = acc[q][r];
     __syncthreads();
     // phase 3's dh values of the first sample block (L2-resident) are requested HERE, in front of the streaming phase: behind it
     // they queued after the tile's last loads and stores and every workgroup opened phase 3 with a full round trip (32 registers,

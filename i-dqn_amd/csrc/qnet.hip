@@ -1493,10 +1493,12 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
     static const bool tile64_on = getenv("IDQN_DP_TILE64") && atoi(getenv("IDQN_DP_TILE64")) != 0;
     // IDQN_DP_ALDS=0: the register version of the contraction (one dependent HBM round trip per sample block)
-    static const bool alds = !(getenv("IDQN_DP_ALDS") && atoi(getenv("IDQN_DP_ALDS")) == 0);
+    //   =2: the same on 64 x 256 tiles (two row tiles share every dh fragment; two workgroups per CU)
+    static const int alds_mode = getenv("IDQN_DP_ALDS") ? atoi(getenv("IDQN_DP_ALDS")) : 1;
     const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
+    const bool alds = alds_mode != 0 && !tile64, tall = alds && alds_mode == 2 && h->F % 64 == 0;
     const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
-    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / (tile64 ? 64 : 32); dw.n_jt = h->J / (128 * nq);
+    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / ((tile64 || (bf3 && tall)) ? 64 : 32); dw.n_jt = h->J / (128 * nq);
     dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1;
     dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
@@ -1550,9 +1552,12 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     } else if (fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
     else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (tile64) D0W_LAUNCH(true, 1, false, true, 2);
-    else if (bf3 && alds) {
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_alds, wgrid, dim3(256), 0, q, dw);
+    else if (bf3 && alds && tall) {
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, dw);
+    } else if (bf3 && alds) {
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, dw);
     }
     else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);

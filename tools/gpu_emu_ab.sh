@@ -1,5 +1,7 @@
+# A/B of the factored data-parallel update's contraction on ONE box: bench.py --emulate-ranks N under IDQN_DP_ALDS = 0 (registers),
+# 1 (a3 fragments through LDS, 32 x 256 tiles), 2 (the same on 64 x 256 tiles); prints step time and final losses (bit-identical)
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-run() { # label, env..., N
+run() { # label, N, env...
   lbl="$1"; n="$2"; shift 2
   env "$@" timeout -k 10 200 python bench.py --emulate-ranks $n --steps 200 --warmup 50 --no-cpu-baseline > gpurun_out/emu_tmp.json 2> gpurun_out/emu_tmp.err || { echo "[$lbl N=$n] failed"; tail -5 gpurun_out/emu_tmp.err; return 1; }
   python - "$lbl" "$n" <<PY
@@ -8,6 +10,8 @@ d = json.load(open("gpurun_out/emu_tmp.json"))
 print("%-28s N=%s  %.1f us/step  losses %s" % (sys.argv[1], sys.argv[2], d["ms_per_step"] * 1e3, d["final_losses"]))
 PY
 }
-for n in 8 4 2; do
-  run "register (ALDS=0)" $n IDQN_DP_ALDS=0 && run "alds late-prefetch" $n IDQN_NONE=1 && run "register (ALDS=0)" $n IDQN_DP_ALDS=0 && run "alds late-prefetch" $n IDQN_NONE=1 || exit 1
+for n in ${@:-8 4 2}; do
+  for rep in 1 2; do
+    run "register (ALDS=0)" $n IDQN_DP_ALDS=0 && run "alds 32 x 256" $n IDQN_DP_ALDS=1 && run "alds 64 x 256" $n IDQN_DP_ALDS=2 || exit 1
+  done
 done
