@@ -302,6 +302,10 @@ def main():
                     help="ONE GPU: the compute side of rank 0 of an N-rank factored data-parallel step (the fused Dense_0 update "
                          "runs over N sample blocks: this rank's factors N times), no collective; a regression guard for the "
                          "part of weak scaling that does not depend on xGMI")
+    ap.add_argument("--emulate-copies", choices=["serial", "side"], default="serial",
+                    help="--emulate-ranks: the N factor-block copies that stand in for the all-gather run on the compute stream "
+                         "(serial: the tracked figure) or on a second stream under the conv backward, where the product path runs "
+                         "its all-gather (side)")
     ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
                     help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
                          "has no quantile code), one GPU, its own JSON line")
@@ -672,14 +676,23 @@ def emulate_ranks_bench(args, json_fd, Batch):
     send = torch.zeros(n_a3 + n_dh, dtype=torch.float32, device="cuda")
     gathered = torch.zeros(N * (n_a3 + n_dh), dtype=torch.float32, device="cuda")
     it = [0]
+    side = torch.cuda.Stream() if args.emulate_copies == "side" else None
 
     def step():
         agent._learn(batches[it[0] % 8], flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD, mean_divisor=32 * N)
         it[0] += 1
         _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()), "export")
-        for r in range(N):  # (stands for the all-gather: every slot holds this rank's factors)
-            gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
+        if side is None:
+            for r in range(N):  # (stands for the all-gather: every slot holds this rank's factors)
+                gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
+        else:  # as the product path runs its all-gather: on a second stream, under the conv backward
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for r in range(N):
+                    gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
         _hip.check(lib.idqn_backward_rest(agent._handle, q()), "rest")
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         fa = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), N, 1, n_a3 + n_dh, X, X, n_a3 + n_dh, Y, Y)
         _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_DENSE0, q()), "finish")
         _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_REST, q()), "finish")
@@ -698,8 +711,10 @@ def emulate_ranks_bench(args, json_fd, Batch):
     out = {"metric": "compute side of one rank of an N-rank factored i-DQN step (no collective), steps/s", "emulated_ranks": N,
            "value": args.steps / elapsed, "unit": "rank-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-           "note": f"includes {N} device copies of the 5.3 MB factor block standing in for the all-gather; the Dense_0 update "
-                   f"contracts {N} sample blocks per head",
+           "copies": args.emulate_copies,
+           "note": f"includes {N} device copies of the 5.3 MB factor block standing in for the all-gather "
+                   f"({'on the compute stream' if side is None else 'on a second stream under the conv backward, as the all-gather runs'}); "
+                   f"the Dense_0 update contracts {N} sample blocks per head",
            "final_losses": [float(x) for x in agent._losses.cpu().numpy()]}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 

@@ -531,6 +531,103 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
     }
 }
 
+// k_dense0_fwd3 with the weight stream through LDS-DMA (IDQN_D0_FWD_DMA=1; G = 1 form only).  The register version is bound by how
+// fast a CU streams through global_load_dwordx4 (its loads-only ablation takes the same time); the stand-alone probe
+// (tools/probes/ldsdma_stream_probe.hip) moves the same 158.6 MB at 6.0 - 6.3 TB/s through an LDS-DMA ring against 5.3 TB/s through
+// registers at this kernel's one workgroup per CU.  Every wave owns a ring of four 8 KB slots (one 16-row k-step of its 128
+// columns): eight 1 KB copies per k-step, lane (h, bl) -> 16 bytes at [jj][h][bl], i.e. exactly the float4 the register version
+// held in wv[jj] -- read back with eight conflict-free ds_read_b128.  The k-step's 2 KB of activations (16 rows x 32 samples,
+// contiguous) take the same way (two copies, a 2 KB slot per wave and ring position), so that ONE counted s_waitcnt (10 copies
+// per k-step, three k-steps ahead: vmcnt(30)) orders everything and no register is written behind hipcc's back.  160 KB of LDS,
+// one workgroup per CU as before.  Same k order, same splits, same product order: bit-identical partials.
+__device__ __forceinline__ void dma16_nt(unsigned voff, unsigned long sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__global__ __launch_bounds__(256) void k_dense0_fwd3d(DenseFwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char d3d_lds[];  // W [wave][slot 0..3][jj 0..7][64 lanes][16 B], then X [wave][slot][16 rows][32]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
+    long item = (long)blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;  // wave-uniform; no barrier below
+    const int jt = (int)(item % a.n_jt);
+    item /= a.n_jt;
+    const int s = (int)(item % a.NS);
+    item /= a.NS;
+    const int bb = (int)(item % a.nb);
+    const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
+    const int NU = a.F / 16, NC = (NU - s + a.NS - 1) / a.NS;  // k-steps of this split (interleaved split-K, as k_dense0_fwd3)
+    const unsigned long step_w = 16UL * a.NS * a.J * 4, step_x = 16UL * a.NS * 32 * 4, row_w = (unsigned long)a.J * 4;  // bytes
+    const unsigned long Wb = (unsigned long)(a.wbase[n] + a.w_off + (long)(16 * s) * a.J + jt * 128);
+    const unsigned long Xb = (unsigned long)(a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(16 * s) * 32);
+    const unsigned voff_w = (unsigned)((8 * h * a.J + 4 * bl) * 4), voff_x = (unsigned)lane * 16;
+    // LDS: per wave four 8 KB weight slots, then (behind the 128 KB of all waves) four 2 KB activation slots
+    const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&d3d_lds[0];
+    const unsigned lds0 = ldsb + (unsigned)wave * 4 * 8192, ldx0 = ldsb + 4 * 4 * 8192 + (unsigned)wave * 4 * 2048;
+    const unsigned char* lw = d3d_lds + wave * 4 * 8192 + lane * 16;
+    const float* lx = reinterpret_cast<const float*>(d3d_lds + 4 * 4 * 8192 + wave * 4 * 2048) + 8 * h * 32 + bl;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#define D3D_LOAD(c, sl)                                                                                              \
+    {                                                                                                                \
+        const unsigned long wsrc = Wb + (unsigned long)(c) * step_w, xsrc = Xb + (unsigned long)(c) * step_x;        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slot's earlier ds_reads have returned */           \
+        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) dma16_nt(voff_w, wsrc + jj * row_w, lds0 + (sl) * 8192 + jj * 1024); \
+        dma16(voff_x, xsrc, ldx0 + (sl) * 2048);                                                                     \
+        dma16(voff_x, xsrc + 1024, ldx0 + (sl) * 2048 + 1024);                                                       \
+    }
+#define D3D_TILE(q, comp)                                                                      \
+    {                                                                                          \
+        unsigned p0[4], p1[4], p2[4];                                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(wv[2 * m].comp, wv[2 * m + 1].comp, p0[m], p1[m], p2[m]); \
+        const bf16x8 w0 = planes8(p0), w1 = planes8(p1), w2 = planes8(p2);                     \
+        acc[q] = mfma_bf16(w2, x0, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x2, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w1, x1, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w1, x0, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x1, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x0, acc[q]);                                                    \
+    }
+#define D3D_MMA(sl)                                                                            \
+    {                                                                                          \
+        float4 wv[8];                                                                          \
+        float xv[8];                                                                           \
+        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) wv[jj] = *reinterpret_cast<const float4*>(lw + (sl) * 8192 + jj * 1024); \
+        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xv[jj] = lx[(sl) * 512 + jj * 32];    \
+        unsigned q0[4], q1[4], q2[4];                                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xv[2 * m], xv[2 * m + 1], q0[m], q1[m], q2[m]); \
+        const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
+        D3D_TILE(0, x) D3D_TILE(1, y) D3D_TILE(2, z) D3D_TILE(3, w)                            \
+    }
+    // every k-step issues exactly 10 copies (the clamped tail re-requests the last k-step, as the register version does):
+    // with three k-steps requested behind it a k-step's data has arrived at vmcnt(30)
+#define D3D_STEP(u)                                                                            \
+    D3D_LOAD(min(c + (u) + 3, NC - 1), ((u) + 3) & 3)                                          \
+    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");                                          \
+    if (c + (u) < NC) D3D_MMA(u)
+    D3D_LOAD(0, 0)
+    D3D_LOAD(min(1, NC - 1), 1)
+    D3D_LOAD(min(2, NC - 1), 2)
+    for (int c = 0; c < NC; c += 4) {
+        D3D_STEP(0) D3D_STEP(1) D3D_STEP(2) D3D_STEP(3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail's copies land before the wave may end
+#undef D3D_STEP
+#undef D3D_MMA
+#undef D3D_TILE
+#undef D3D_LOAD
+    float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = mfma_row(r, h);
+        P[(4 * i + 0) * 32] = acc[0][r];
+        P[(4 * i + 1) * 32] = acc[1][r];
+        P[(4 * i + 2) * 32] = acc[2][r];
+        P[(4 * i + 3) * 32] = acc[3][r];
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Head, stage 1 (all 2K nets in parallel): split-K reduce + bias + ReLU -> h, and the per-chunk partial
 // products of Dense_1.  grid = (J / 32 chunks, net * batch block).   architectures/dqn.py:67-70

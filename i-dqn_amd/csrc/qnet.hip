@@ -1362,7 +1362,14 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         static LdsAttrMark attr;
         if (attr.needs(65536 + 16)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     }
-    if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
+    // IDQN_D0_FWD_DMA=1: the weight stream through a per-wave LDS-DMA ring (k_dense0_fwd3d, bit-identical partials)
+    static const bool fwd_dma = getenv("IDQN_D0_FWD_DMA") && atoi(getenv("IDQN_D0_FWD_DMA")) != 0;
+    if (h->planes && fwd_dma && d.G == 1 && d.F / 16 >= d.NS && (long)h->J * 32 * 4 < (1L << 31)) {
+        static LdsAttrMark attr;
+        constexpr int lds = 4 * 4 * (8192 + 2048);  // all of the CU's 160 KB
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3d, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_dense0_fwd3d, dim3(cdiv(d.n_items, 4)), dim3(256), lds, q, d);
+    } else if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
     else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
