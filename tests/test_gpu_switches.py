@@ -6,6 +6,9 @@
                       -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
   IDQN_D0_GROUP=1 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward with the in-workgroup split reduction / also with the head's
                       first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical to the grouped one
+  IDQN_D0_FWD_DMA=1   the Dense_0 forward fed by per-wave LDS-DMA rings instead of vector registers  -> bit-identical
+  IDQN_DP_ALDS=0/1/2  the factored data-parallel update's contraction: registers / a3 fragments through LDS / the same on
+                      64 x 256 tiles  -> bit-identical
   IDQN_D0_FIN=1       the last-arriving column-tile workgroup instead of the k_da3_finalize launch  -> bit-identical
   IDQN_ADAM_ROLE=1    the Conv_0 weight-gradient launch carries the other small leaves' Adam update  -> bit-identical at
                       equal chunk counts
@@ -111,6 +114,77 @@ def test_dense0_update_finishes_the_data_gradient_itself(default_run):
     assert got["losses"] == default_run["losses"]
     assert got["probe"] == default_run["probe"]
     assert got["acts"] == default_run["acts"]
+
+
+def test_dense0_forward_through_lds_dma_is_bit_identical(default_run):
+    """Round 4 (opt-in, measured neutral): IDQN_D0_FWD_DMA=1 sends the Dense_0 forward's weight stream and activations through
+    per-wave LDS-DMA rings (k_dense0_fwd3d) instead of vector registers.  Same k order, splits and product order: bit-identical."""
+    got = _run(IDQN_D0_FWD_DMA="1")
+    assert got["losses"] == default_run["losses"]
+    assert got["probe"] == default_run["probe"]
+    assert got["acts"] == default_run["acts"]
+
+
+CHILD_DP = r"""
+import json, sys, os
+sys.path[:0] = [ROOT, os.path.join(ROOT, "i-dqn_amd")]
+import numpy as np, torch
+from collections import namedtuple
+from slimdqn import _hip
+from slimdqn.networks.idqn import iDQN
+Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+rng = np.random.default_rng(11)
+N = int(os.environ["SW_RANKS"])
+agent = iDQN(3, (84, 84, 4), 6, 5, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+def batch():
+    return Batch(torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy(rng.integers(0, 6, 32).astype(np.int32)).cuda(),
+                 torch.from_numpy(rng.standard_normal(32).astype(np.float32)).cuda(),
+                 torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy((rng.random(32) < 0.1).astype(np.uint8)).cuda())
+bs = [batch(), batch()]
+lib, q, K = _hip.lib(), _hip.current_stream, agent._K
+F, J = next(shape for name, _, shape in agent._leaves if name == "Dense_0/kernel")
+X, Y = F * 32, J * 32
+n_a3, n_dh = K * X, K * Y
+send = torch.zeros(n_a3 + n_dh, dtype=torch.float32, device="cuda")
+gathered = torch.zeros(N * (n_a3 + n_dh), dtype=torch.float32, device="cuda")
+losses = []
+for i in range(4):  # rank 0's calls of an N-rank factored step (slimdqn/networks/parallel.py); every slot holds this rank's factors
+    agent._learn(bs[i % 2], flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD, mean_divisor=32 * N)
+    _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()), "export")
+    for r in range(N):
+        gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
+    _hip.check(lib.idqn_backward_rest(agent._handle, q()), "rest")
+    fa = (agent._handle, _hip.ptr(gathered), _hip.ptr(gathered[n_a3:]), N, 1, n_a3 + n_dh, X, X, n_a3 + n_dh, Y, Y)
+    _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_DENSE0, q()), "finish")
+    _hip.check(lib.idqn_finish_step_factored(*fa, _hip.FACTORED_REST, q()), "finish")
+    losses.append(agent._losses.cpu().numpy().astype(np.float64).tolist())
+flat = agent._flat(agent._online)
+probe = {name: v.reshape(5, -1)[:, :: max(1, v[0].size // 997)].astype(np.float64).tolist() for name, v in flat.items()}
+print("RESULT" + json.dumps({"losses": losses, "probe": probe}))
+"""
+
+
+@pytest.mark.parametrize("ranks", [3, 9])
+def test_factored_update_contraction_variants_are_bit_identical(ranks):
+    """Round 4: the factored data-parallel update contracts N sample blocks per head.  Default (IDQN_DP_ALDS=1): the tile's a3
+    fragments are staged once by LDS-DMA (chunks of 8 blocks: N = 9 takes two), the dh fragments run in a register ring;
+    IDQN_DP_ALDS=2 the same on 64 x 256 tiles (chunks of 4 blocks); IDQN_DP_ALDS=0 the register version.  Every accumulator
+    takes the same products in the same order: bit-identical parameters after 4 emulated N-rank steps."""
+    def run(**env):
+        e = dict(os.environ, SW_RANKS=str(ranks))
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD_DP], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+        return json.loads(line[len("RESULT"):])
+    ref = run(IDQN_DP_ALDS="0")
+    assert np.isfinite(np.asarray(ref["losses"])).all()
+    for mode in ("1", "2"):
+        got = run(IDQN_DP_ALDS=mode)
+        assert got["losses"] == ref["losses"], mode
+        assert got["probe"] == ref["probe"], mode
 
 
 def test_adam_role_of_the_conv0_weight_gradient_launch(default_run):
