@@ -274,7 +274,11 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_ALDS_PRE
 #define D0W_ALDS_PRE 0  // 0: the ALDS variant requests its first row groups only after the contraction (48 registers less in the block loop)
 #endif
-    constexpr bool PRE_EARLY = !ALDS || D0W_ALDS_PRE;
+#ifndef D0W_PRE_OPS
+#define D0W_PRE_OPS 1  // the f32 contraction's operand loads go out in FRONT of the first row groups' (an in-order wait for the
+#endif                 // operands then does not include the twelve HBM loads of the prefetch)
+    constexpr bool PRE_OPS = D0W_PRE_OPS && FUSE_ADAM && !BF3 && !ALDS;
+    constexpr bool PRE_EARLY = (!ALDS || D0W_ALDS_PRE) && !PRE_OPS;
     if (FUSE_ADAM && upd && PRE_EARLY) prefetch();
     f32x16 acc[NQW];
 #pragma unroll
@@ -355,7 +359,11 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         if (!PRE_EARLY) prefetch();
         __syncthreads();  // the gradient tile is parked over the fragments
     } else
+#if D0W_ABL == 3 || D0W_ABL == 5  // ablation: no phase 1 (zero gradient tile; wrong results)
+    for (int bb = 0; bb < 0; ++bb) {
+#else
     for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
+#endif
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
             const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
@@ -392,13 +400,22 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         const float av[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w,
                               x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
         const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + bl) * 32 + 16 * h;
+        float4 y[NQ][4];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const float* dq = Dp + (long)q * 32 * 32;  // columns jw + 32 q + bl
-            float4 y0 = *reinterpret_cast<const float4*>(dq), y1 = *reinterpret_cast<const float4*>(dq + 4);
-            float4 y2 = *reinterpret_cast<const float4*>(dq + 8), y3 = *reinterpret_cast<const float4*>(dq + 12);
-            const float bv[16] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w,
-                                  y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[q][u] = *reinterpret_cast<const float4*>(dq + 4 * u);
+        }
+        if (PRE_OPS && bb == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float bv[16] = {y[q][0].x, y[q][0].y, y[q][0].z, y[q][0].w, y[q][1].x, y[q][1].y, y[q][1].z, y[q][1].w,
+                                  y[q][2].x, y[q][2].y, y[q][2].z, y[q][2].w, y[q][3].x, y[q][3].y, y[q][3].z, y[q][3].w};
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc[q] = mfma32(av[u], bv[u], acc[q]);
         }
@@ -415,7 +432,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_PF3
 #define D0W_PF3 2  // chunks requested in front of the streaming phase; the others at the start of phase 3, behind them
 #endif
-    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN) ? D0W_PF3 : 0;
+    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN && D0W_ABL != 4 && D0W_ABL != 5) ? D0W_PF3 : 0;
     float dv[NCH3][8];
     auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
         const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
@@ -469,7 +486,11 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             *reinterpret_cast<float4*>(a.grad + g0 + (long)(RPI * i) * a.J) =
                 *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
+#if D0W_ABL == 4 || D0W_ABL == 5  // ablation: no phase 3 (no data-gradient partials; wrong results)
+    if (false) {
+#else
     if (FUSE_DG) {
+#endif
         __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
         float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
         for (int bb = 0; bb < a.nb; ++bb) {
