@@ -432,6 +432,9 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_PF3
 #define D0W_PF3 2  // chunks requested in front of the streaming phase; the others at the start of phase 3, behind them
 #endif
+#ifndef D0W_PF3_MID
+#define D0W_PF3_MID 1
+#endif
     constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN && D0W_ABL != 4 && D0W_ABL != 5) ? D0W_PF3 : 0;
     float dv[NCH3][8];
     auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
@@ -463,6 +466,14 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             float* gp = &gs[rot(RPI * i + prow, pcol)];
             const float4 g = *reinterpret_cast<const float4*>(gp);
             float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
+            if constexpr (PF3 > 0 && D0W_PF3_MID) {  // the other chunks go out in the last iterations, into the registers of ring slots
+                if (i >= NIT - 3 && PF3 + i - (NIT - 3) < NCH3 && i < NIT - 1) {  // that are not re-filled any more: phase 3 then
+                    const int c3 = PF3 + i - (NIT - 3);                            // waits for no store of the last iterations
+                    const float* Dp = a.dh + k * a.dh_head + (long)(j0 + jw + h) * 32 + bl;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dv[c3][u] = Dp[(long)(16 * c3 + 2 * u) * 32];
+                }
+            }
             if (FUSE_DG) *reinterpret_cast<float4*>(gp) = t4;  // theta BEFORE the update takes the consumed gradient's place
             if (i + DEPTH < NIT) {  // the slot just read is re-filled DEPTH row groups ahead, before the (may-alias) stores
                 const long on = o0 + (long)(RPI * (i + DEPTH)) * a.J;
@@ -497,7 +508,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             // A operand: dh^T (dv); B operand: theta_old[f = bl][j = jw + 2 t + h]
             [[maybe_unused]] const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
             if (bb > 0) load_dv(bb, std::integral_constant<int, 0>{}, std::integral_constant<int, NCH3>{});
-            else load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
+            else if (!(PF3 > 0 && D0W_PF3_MID && upd && NCH3 - PF3 <= 2)) load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
