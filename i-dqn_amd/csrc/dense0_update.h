@@ -277,7 +277,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_PRE_OPS
 #define D0W_PRE_OPS 1  // the f32 contraction's operand loads go out in FRONT of the first row groups' (an in-order wait for the
 #endif                 // operands then does not include the twelve HBM loads of the prefetch)
-    constexpr bool PRE_OPS = D0W_PRE_OPS && FUSE_ADAM && !BF3 && !ALDS;
+    constexpr bool PRE_OPS = D0W_PRE_OPS && FUSE_ADAM && !BF3 && !ALDS && NQ <= 2;  // (the full-row kernel has no registers for it)
     constexpr bool PRE_EARLY = (!ALDS || D0W_ALDS_PRE) && !PRE_OPS;
     if (FUSE_ADAM && upd && PRE_EARLY) prefetch();
     f32x16 acc[NQW];
@@ -360,6 +360,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         __syncthreads();  // the gradient tile is parked over the fragments
     } else
 #if D0W_ABL == 3 || D0W_ABL == 5  // ablation: no phase 1 (zero gradient tile; wrong results)
+    if (PRE_OPS && upd) prefetch();
     for (int bb = 0; bb < 0; ++bb) {
 #else
     for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
@@ -436,7 +437,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #define D0W_PF3_MID 1
 #endif
     constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN && D0W_ABL != 4 && D0W_ABL != 5) ? D0W_PF3 : 0;
-    float dv[NCH3][8];
+    float dv[PF3 > 0 ? NCH3 : 1][8];
     auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
         const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
         // A operand: dh^T, lane (b = bl, k = h) reads dh[j0 + jw + 2 t + h][b]
@@ -507,17 +508,38 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         for (int bb = 0; bb < a.nb; ++bb) {
             // A operand: dh^T (dv); B operand: theta_old[f = bl][j = jw + 2 t + h]
             [[maybe_unused]] const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
-            if (bb > 0) load_dv(bb, std::integral_constant<int, 0>{}, std::integral_constant<int, NCH3>{});
-            else if (!(PF3 > 0 && D0W_PF3_MID && upd && NCH3 - PF3 <= 2)) load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
+            if constexpr (PF3 > 0) {
+                if (bb > 0) load_dv(bb, std::integral_constant<int, 0>{}, std::integral_constant<int, NCH3>{});
+                else if (!(D0W_PF3_MID && upd && NCH3 - PF3 <= 2)) load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
+            }
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            if constexpr (PF3 > 0) {
 #pragma unroll
-            for (int c = 0; c < NCH3; ++c) {
+                for (int c = 0; c < NCH3; ++c) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int col = jw + 16 * c + 2 * u + h;
-                    d = mfma32(dv[c][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
+                    for (int u = 0; u < 8; ++u) {
+                        const int col = jw + 16 * c + 2 * u + h;
+                        d = mfma32(dv[c][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
+                    }
+                }
+            } else {  // nothing requested ahead (the full-row kernel, the last-arriver variant): chunk c + 1 under chunk c's products
+                const float* Dp = a.dh + bo * a.dh_outer + k * a.dh_head + bi * a.dh_inner + (long)(j0 + jw + h) * 32 + bl;
+                float db[2][8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) db[0][u] = Dp[(long)(2 * u) * 32];
+#pragma unroll
+                for (int c = 0; c < NCH3; ++c) {
+                    if (c + 1 < NCH3) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) db[(c + 1) & 1][u] = Dp[(long)(16 * (c + 1) + 2 * u) * 32];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int col = jw + 16 * c + 2 * u + h;
+                        d = mfma32(db[c & 1][u], gs[bl * JT + ((col + 4 * bl) & (JT - 1))], d);
+                    }
                 }
             }
             // this wave's tile -> LDS: lane = row f (bl), 4 x 4 consecutive samples per register quad
