@@ -1369,8 +1369,13 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         constexpr int lds = 4 * 4 * (8192 + 2048);  // all of the CU's 160 KB
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3d, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(k_dense0_fwd3d, dim3(cdiv(d.n_items, 4)), dim3(256), lds, q, d);
-    } else if (h->planes) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
-    else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    } else if (h->planes) {
+        hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
+        // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
+        // the previous launches leave the memory system in
+        static const bool twice = getenv("IDQN_D0_FWD_TWICE") && atoi(getenv("IDQN_D0_FWD_TWICE")) != 0;
+        if (twice && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+    } else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
