@@ -243,10 +243,17 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     // launch; here such a workgroup only produces its share of the data gradient (theta rows -> LDS -> phase 3), because
     // the conv backward needs dL/da3 of every row before it can start.  Workgroup-uniform.
     const bool upd = !FUSE_DG || a.upd_end < 0 || item < a.upd_end;
+#if D0W_JT_SLOW  // locality experiment: the two column tiles of a row range far apart in dispatch order (jt slowest)
+    const int ft = item % a.n_ft;
+    item /= a.n_ft;
+    const int k = item % a.K;
+    const int jt = item / a.K;
+#else
     const int jt = item % a.n_jt;
     item /= a.n_jt;
     const int ft = item % a.n_ft;
     const int k = item / a.n_ft;
+#endif
     const int f0 = ft * 32 * RT, j0 = jt * JT, jw = (RT == 1 || TALL) ? wave * (32 * NQ) : (wave & 1) * 64,
               rw = (RT == 1 || TALL) ? 0 : (wave >> 1) * 32;
     const long base = (long)k * a.P + a.w_off + (long)f0 * a.J + j0;
@@ -270,6 +277,9 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     };
 #ifndef D0W_ABL
 #define D0W_ABL 0
+#endif
+#ifndef D0W_JT_SLOW
+#define D0W_JT_SLOW 0
 #endif
 #ifndef D0W_ALDS_PRE
 #define D0W_ALDS_PRE 0  // 0: the ALDS variant requests its first row groups only after the contraction (48 registers less in the block loop)
@@ -622,6 +632,197 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                 }
             }
             __syncthreads();  // red is reused by the next batch block
+        }
+    }
+}
+
+// ---- the fused update on PAIRS of column tiles (round 4; one sample block, J = 512) ----------------------------------------
+// One workgroup takes BOTH 32 x 256 column tiles of its 32 rows, one after the other.  Per tile the three phases of
+// dense0_wgrad_body (f32 contraction -> gradient tile in LDS; streaming Adam that leaves theta_old in LDS; data-gradient
+// products from LDS), in the same arithmetic and the same order, so every parameter and every partial sum is bit-identical.
+// What the pairing buys (the ablations of DESIGN 3.5c put 9 us of this kernel on workgroups that are not streaming):
+//  * the second tile's contraction operands are requested before the first tile's phase 3 and its first four row groups right
+//    after that phase's products, into registers the first tile has released -- its phase 1 starts with the operands there
+//    and its stream never runs dry across the two MFMA phases in between;
+//  * the workgroup holds both column tiles' partial data gradients: it adds them (tile 0 + tile 1, the order k_da3_finalize
+//    uses), applies the ReLU mask and writes the output forms itself.  No partials in HBM, no finalize launch, and -- unlike the
+//    last-arriver variant -- no hand-off either.
+// Same registers (vmcnt is in order: operands in front of prefetches, phase-3 operands in front of / inside the stream).
+__device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
+    constexpr int JT = 256, RPI = 4, NIT = 8, DEPTH = 4;
+    const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
+    const int ft = item % a.n_ft, k = item / a.n_ft, f0 = ft * 32, jw = wave * 64;
+    const int prow = t >> 6, pcol = (t & 63) * 4;
+    auto rot = [&](int row, int col) { return row * JT + ((col + 4 * row) & (JT - 1)); };
+    const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
+    const float* const A3 = a.a3 + k * a.a3_head;  // (uniform bases + 32-bit byte offsets, as for theta / m / v below)
+    const float* const Dh = a.dh + k * a.dh_head;
+    const unsigned a_off = (unsigned)((f0 + bl) * 32 + 16 * h) * 4;
+    float4 x[4], y[2][4];
+    float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
+    float dv[4][8];
+    auto load_ops = [&](int jt) {
+        const unsigned d_off = (unsigned)((jt * JT + jw + bl) * 32 + 16 * h) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A3) + (a_off + 16 * u));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                y[q][u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Dh) + (d_off + (unsigned)(q * 32 * 32 * 4 + 16 * u)));
+    };
+    // theta / m / v: workgroup-uniform bases (scalar registers) + 32-bit element offsets, so that the sixteen row-group
+    // addresses of the two tiles are adds on ONE register each, not 64-bit pointers held for the whole kernel
+    const float* const Th = a.theta + (long)k * a.P + a.w_off;
+    const float* const Mu = a.mu + (long)k * a.P + a.w_off;
+    const float* const Nu = a.nu + (long)k * a.P + a.w_off;
+    const unsigned rowJ = (unsigned)(RPI * a.J) * 4;  // BYTE offsets: a zero-extended 32-bit byte offset is what the scalar-base form takes
+    auto at = [](const float* b, unsigned boff) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + boff); };
+    auto atw = [](const float* b, unsigned boff) { return reinterpret_cast<float*>(const_cast<char*>(reinterpret_cast<const char*>(b)) + boff); };
+    auto prefetch = [&](unsigned o0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const unsigned on = o0 + (unsigned)d * rowJ;
+            th[d] = ld4<(D0_WG_NT & 1) != 0>(at(Th, on));
+            mm[d] = ld4<(D0_WG_NT & 1) != 0>(at(Mu, on));
+            vv[d] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
+        }
+    };
+    const unsigned base0 = (unsigned)((f0 + prow) * a.J + pcol) * 4;
+    load_ops(0);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch(base0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const unsigned o0 = base0 + jt * JT * 4;
+        // (the 2 x 32 LDS addresses of the park and of phase 3 are the same in both tiles: kept alive across the whole kernel
+        // they cost 64 registers -- an opaque copy of the lane indices per tile makes hipcc recompute them)
+        int blx = bl, hx = h;
+        asm volatile("" : "+v"(blx), "+v"(hx));
+        // phase 3, A operand: lane (b = bl, k = h) reads dh[j0 + jw + 2 u + h][b]
+        const float* D3 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Dh) + (unsigned)((jt * JT + jw + h) * 32 + bl) * 4);
+        // ---- phase 1: G = a3^T dh (f32 MFMA, k = the 32 samples in order) -> LDS, columns rotated by 4 * row
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+            const float av[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w,
+                                  x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float bv[16] = {y[q][0].x, y[q][0].y, y[q][0].z, y[q][0].w, y[q][1].x, y[q][1].y, y[q][1].z, y[q][1].w,
+                                      y[q][2].x, y[q][2].y, y[q][2].z, y[q][2].w, y[q][3].x, y[q][3].y, y[q][3].z, y[q][3].w};
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[q] = mfma32(av[u], bv[u], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gs[rot(mfma_row(r, hx), jw + 32 * q + blx)] = acc[q][r];
+        }
+        __syncthreads();
+        // phase 3's first operand chunk goes out in front of the stream, the other three in its last iterations (into the
+        // registers of ring slots that are not re-filled any more)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dv[0][u] = D3[(long)(2 * u) * 32];
+        // ---- phase 2: streaming Adam, theta_old takes the consumed gradient's place in LDS
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int s = i % DEPTH;
+            float* gp = &gs[rot(RPI * i + prow, pcol)];
+            const float4 g = *reinterpret_cast<const float4*>(gp);
+            float4 t4 = th[s], m4 = mm[s], v4 = vv[s];
+            if (i >= NIT - 3) {
+                const int c3 = 1 + i - (NIT - 3);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dv[c3][u] = D3[(long)(16 * c3 + 2 * u) * 32];
+            }
+            *reinterpret_cast<float4*>(gp) = t4;
+            if (i + DEPTH < NIT) {
+                const unsigned on = o0 + (unsigned)(i + DEPTH) * rowJ;
+                th[s] = ld4<(D0_WG_NT & 1) != 0>(at(Th, on));
+                mm[s] = ld4<(D0_WG_NT & 1) != 0>(at(Mu, on));
+                vv[s] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
+            }
+            adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
+            adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
+            adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
+            adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
+            const unsigned o = o0 + (unsigned)i * rowJ;
+            st4<(D0_WG_NT & 2) != 0>(atw(Th, o), t4);
+            st4<(D0_WG_NT & 2) != 0>(atw(Mu, o), m4);
+            st4<(D0_WG_NT & 2) != 0>(atw(Nu, o), v4);
+        }
+        __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
+        if (jt == 0) {    // the second tile's contraction operands, in front of everything else it will request
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- phase 3: this wave's 64 columns of dL/da3[f][b] = sum_j theta_old[f][j] dh[j][b]
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int col = jw + 16 * c + 2 * u + hx;
+                d = mfma32(dv[c][u], gs[blx * JT + ((col + 4 * blx) & (JT - 1))], d);
+            }
+        if (jt == 0) {    // ... and its first four row groups, into the registers the phase-3 operands have left
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(base0 + JT * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(&red[wave * 1024 + bl * 32 + (((2 * g + h) ^ (bl & 7)) * 4)]) =
+                make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+        __syncthreads();
+        const int row = t >> 3, slot = ((t & 7) ^ (row & 7)) * 4;
+        float4 s4 = *reinterpret_cast<const float4*>(&red[row * 32 + slot]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 yv = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
+            s4.x += yv.x; s4.y += yv.y; s4.z += yv.z; s4.w += yv.w;
+        }
+        if (jt == 0) {
+            *reinterpret_cast<float4*>(&gs[32 * JT + 4096 + 4 * t]) = s4;  // kept in LDS (4 KB behind red) until the second tile's sum
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            const float4 part0 = *reinterpret_cast<const float4*>(&gs[32 * JT + 4096 + 4 * t]);
+            // complete rows: tile 0 + tile 1, ReLU mask of a3, the three output forms of dL/da3 (as k_da3_finalize: one thread =
+            // 4 samples of one row f, 8 threads a row)
+            s4.x = part0.x + s4.x; s4.y = part0.y + s4.y; s4.z = part0.z + s4.z; s4.w = part0.w + s4.w;
+            const int f = f0 + row, sl4 = (t & 7) * 4;
+            const float4 m = *reinterpret_cast<const float4*>(a.a3 + k * a.a3_head + (long)f * 32 + sl4);
+            s4.x = m.x > 0.f ? s4.x : 0.f; s4.y = m.y > 0.f ? s4.y : 0.f; s4.z = m.z > 0.f ? s4.z : 0.f; s4.w = m.w > 0.f ? s4.w : 0.f;
+            const long sl = (long)k;
+            const int pos = f / a.C, c = f - pos * a.C;
+            const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
+            const long pix = (long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w);
+            if (a.da3f) *reinterpret_cast<float4*>(a.da3f + sl * a.g.block + (pix * a.C + c) * 32 + sl4) = s4;
+            if (a.da3p) {
+                unsigned short* O = a.da3p + sl * a.g.block * 3 + pix * (3L * a.C * 32) + (long)c * 32 + sl4;
+                unsigned q0a, q1a, q2a, q0b, q1b, q2b;
+                split3_pk(s4.x, s4.y, q0a, q1a, q2a);
+                split3_pk(s4.z, s4.w, q0b, q1b, q2b);
+                *reinterpret_cast<uint2*>(O) = make_uint2(q0a, q0b);
+                *reinterpret_cast<uint2*>(O + (long)a.C * 32) = make_uint2(q1a, q1b);
+                *reinterpret_cast<uint2*>(O + 2L * a.C * 32) = make_uint2(q2a, q2b);
+            }
+            if (a.pb) {
+                float r = (s4.x + s4.y) + (s4.z + s4.w);
+                r += __shfl_xor(r, 1);
+                r += __shfl_xor(r, 2);
+                r += __shfl_xor(r, 4);
+                if ((t & 7) == 0) a.pb[(sl * (a.g.H * a.g.W) + pos) * a.C + c] = r;
+            }
         }
     }
 }

@@ -1554,7 +1554,21 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         h->d0_fin = true;
         if (h->ov.n_def > 0) h->ov.dw.fin_ctr = nullptr;  // (the deferred update items of the stream roles emit no data gradient)
     }
-    if (rows) {
+    // IDQN_D0_PAIR=1 (one sample block, J = 512, nothing deferred): one workgroup per PAIR of column tiles (dense0_pair_body) --
+    // the second tile's requests go out under the first tile's last phase, and the workgroup finishes dL/da3 itself (it holds
+    // both partials): no partials in HBM, no k_da3_finalize launch, no hand-off.  Bit-identical.  Opt-in: measured neutral
+    // (profiles/r4_d0_pair_ab.txt) -- the kernel takes what the tile kernel AND the finalize launch took (99.9 against 94.6 + 5.3
+    // us), because a row's two 1 KB halves are now streamed 12 us apart instead of side by side by sibling workgroups.
+    static const bool pair_on = getenv("IDQN_D0_PAIR") && atoi(getenv("IDQN_D0_PAIR")) != 0;
+    const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
+                      h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
+    if (pair) {
+        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
+        h->d0_rows = true;  // (dL/da3 is finished by the launch)
+        const dim3 pgrid((unsigned)(K * dw.n_ft));
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_pair, pgrid, dim3(256), 0, q, dw);
+    } else if (rows) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         const size_t lds = (size_t)(32 * 512 + 4096) * 4;
         static LdsAttrMark attr;
