@@ -1141,9 +1141,10 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 // The fused update on pairs of column tiles (dense0_update.h, dense0_pair_body): one workgroup per (head, 32 rows)
+template <bool ROWPAIR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_dense0_wgrad_pair(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
-    dense0_pair_body(a, (int)blockIdx.x, gs, (int)threadIdx.x);
+    dense0_pair_body<ROWPAIR>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
 }
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).

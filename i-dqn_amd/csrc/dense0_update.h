@@ -648,21 +648,30 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 //    uses), applies the ReLU mask and writes the output forms itself.  No partials in HBM, no finalize launch, and -- unlike the
 //    last-arriver variant -- no hand-off either.
 // Same registers (vmcnt is in order: operands in front of prefetches, phase-3 operands in front of / inside the stream).
-__device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
+// ROWPAIR: the pair is two ROW tiles (f0, f0 + 32) of ONE column tile instead -- the sibling workgroup (other column tile, adjacent
+// in dispatch order) streams the other halves of the same rows at the same time, as in the tile kernel; the partial data
+// gradients go to HBM and k_da3_finalize runs as before.
+template <bool ROWPAIR>
+__device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
     constexpr int JT = 256, RPI = 4, NIT = 8, DEPTH = 4;
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    const int ft = item % a.n_ft, k = item / a.n_ft, f0 = ft * 32, jw = wave * 64;
+    int jt_fixed = 0;
+    if (ROWPAIR) { jt_fixed = item & 1; item >>= 1; }
+    const int nfp = ROWPAIR ? a.n_ft / 2 : a.n_ft;
+    const int ft = (item % nfp) * (ROWPAIR ? 2 : 1), k = item / nfp, f0 = ft * 32, jw = wave * 64;
     const int prow = t >> 6, pcol = (t & 63) * 4;
     auto rot = [&](int row, int col) { return row * JT + ((col + 4 * row) & (JT - 1)); };
     const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
     const float* const A3 = a.a3 + k * a.a3_head;  // (uniform bases + 32-bit byte offsets, as for theta / m / v below)
     const float* const Dh = a.dh + k * a.dh_head;
-    const unsigned a_off = (unsigned)((f0 + bl) * 32 + 16 * h) * 4;
+    auto tile_f0 = [&](int tt) { return ROWPAIR ? f0 + 32 * tt : f0; };
+    auto tile_jt = [&](int tt) { return ROWPAIR ? jt_fixed : tt; };
     float4 x[4], y[2][4];
     float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
     float dv[4][8];
-    auto load_ops = [&](int jt) {
-        const unsigned d_off = (unsigned)((jt * JT + jw + bl) * 32 + 16 * h) * 4;
+    auto load_ops = [&](int tt) {
+        const unsigned a_off = (unsigned)((tile_f0(tt) + bl) * 32 + 16 * h) * 4;
+        const unsigned d_off = (unsigned)((tile_jt(tt) * JT + jw + bl) * 32 + 16 * h) * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A3) + (a_off + 16 * u));
 #pragma unroll
@@ -688,14 +697,15 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const 
             vv[d] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
         }
     };
-    const unsigned base0 = (unsigned)((f0 + prow) * a.J + pcol) * 4;
+    auto tile_base = [&](int tt) { return (unsigned)((tile_f0(tt) + prow) * a.J + tile_jt(tt) * JT + pcol) * 4; };
     load_ops(0);
     __builtin_amdgcn_sched_barrier(0);
-    prefetch(base0);
+    prefetch(tile_base(0));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const unsigned o0 = base0 + jt * JT * 4;
+    for (int tt = 0; tt < 2; ++tt) {
+        const int jt = tile_jt(tt);
+        const unsigned o0 = tile_base(tt);
         // (the 2 x 32 LDS addresses of the park and of phase 3 are the same in both tiles: kept alive across the whole kernel
         // they cost 64 registers -- an opaque copy of the lane indices per tile makes hipcc recompute them)
         int blx = bl, hx = h;
@@ -757,7 +767,7 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const 
             st4<(D0_WG_NT & 2) != 0>(atw(Nu, o), v4);
         }
         __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
-        if (jt == 0) {    // the second tile's contraction operands, in front of everything else it will request
+        if (tt == 0) {    // the second tile's contraction operands, in front of everything else it will request
             __builtin_amdgcn_sched_barrier(0);
             load_ops(1);
             __builtin_amdgcn_sched_barrier(0);
@@ -773,9 +783,9 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const 
                 const int col = jw + 16 * c + 2 * u + hx;
                 d = mfma32(dv[c][u], gs[blx * JT + ((col + 4 * blx) & (JT - 1))], d);
             }
-        if (jt == 0) {    // ... and its first four row groups, into the registers the phase-3 operands have left
+        if (tt == 0) {    // ... and its first four row groups, into the registers the phase-3 operands have left
             __builtin_amdgcn_sched_barrier(0);
-            prefetch(base0 + JT * 4);
+            prefetch(tile_base(1));
             __builtin_amdgcn_sched_barrier(0);
         }
         float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
@@ -791,7 +801,10 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, const 
             const float4 yv = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
             s4.x += yv.x; s4.y += yv.y; s4.z += yv.z; s4.w += yv.w;
         }
-        if (jt == 0) {
+        if (ROWPAIR) {
+            *reinterpret_cast<float4*>(a.dpart + ((long)jt * a.K + k) * a.F * 32 + (long)tile_f0(tt) * 32 + t * 4) = s4;
+            if (tt == 0) __builtin_amdgcn_sched_barrier(0);
+        } else if (tt == 0) {
             *reinterpret_cast<float4*>(&gs[32 * JT + 4096 + 4 * t]) = s4;  // kept in LDS (4 KB behind red) until the second tile's sum
             __builtin_amdgcn_sched_barrier(0);
         } else {

@@ -1554,20 +1554,29 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         h->d0_fin = true;
         if (h->ov.n_def > 0) h->ov.dw.fin_ctr = nullptr;  // (the deferred update items of the stream roles emit no data gradient)
     }
-    // IDQN_D0_PAIR=1 (one sample block, J = 512, nothing deferred): one workgroup per PAIR of column tiles (dense0_pair_body) --
-    // the second tile's requests go out under the first tile's last phase, and the workgroup finishes dL/da3 itself (it holds
-    // both partials): no partials in HBM, no k_da3_finalize launch, no hand-off.  Bit-identical.  Opt-in: measured neutral
-    // (profiles/r4_d0_pair_ab.txt) -- the kernel takes what the tile kernel AND the finalize launch took (99.9 against 94.6 + 5.3
-    // us), because a row's two 1 KB halves are now streamed 12 us apart instead of side by side by sibling workgroups.
-    static const bool pair_on = getenv("IDQN_D0_PAIR") && atoi(getenv("IDQN_D0_PAIR")) != 0;
+    // Default where it applies (one sample block, J = 512, nothing deferred): one workgroup per PAIR of column tiles
+    // (dense0_pair_body) -- the second tile's requests go out under the first tile's last phase, and the workgroup finishes
+    // dL/da3 itself (it holds both partials): no partials in HBM, no k_da3_finalize launch, no hand-off.  Bit-identical.
+    // Measured on three boxes against two workgroups + finalize (profiles/r4_d0_pair_ab.txt): step -0.7 / -3 / -5 us; the kernel
+    // itself takes 2 - 5 us more than the tile kernel (a row's two 1 KB halves are streamed 12 us apart instead of side by side by
+    // sibling workgroups), the finalize launch it replaces took 5.3 us + a boundary.
+    //   IDQN_D0_PAIR=0: the tile kernel + k_da3_finalize.
+    //   =2: the pair is two ROW tiles of one column tile (siblings keep streaming a row's halves side by side; partials +
+    //   k_da3_finalize): 3.5 us SLOWER than the tile kernel -- what pays in the pair is the finished data gradient, not the pairing.
+    static const int pair_mode = getenv("IDQN_D0_PAIR") ? atoi(getenv("IDQN_D0_PAIR")) : 1;
+    const bool pair_on = pair_mode == 1 || (pair_mode == 2 && dw.n_ft % 2 == 0);
     const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
                       h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
-    if (pair) {
+    if (pair && pair_mode == 2) {
+        const dim3 pgrid((unsigned)(K * dw.n_ft));  // K * (n_ft / 2) * 2 column tiles
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, dw);
+    } else if (pair) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         h->d0_rows = true;  // (dL/da3 is finished by the launch)
         const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_pair, pgrid, dim3(256), 0, q, dw);
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, dw);
     } else if (rows) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         const size_t lds = (size_t)(32 * 512 + 4096) * 4;

@@ -6,7 +6,8 @@
                       -> bit-identical over 60 steps (flags only, no sum changes its order), no spin gave up (finite losses)
   IDQN_D0_GROUP=1 / IDQN_D0_FUSE_HIDDEN=1   the Dense_0 forward with the in-workgroup split reduction / also with the head's
                       first stage riding in it (last-arriver hand-off)  -> fp32 round-off / bit-identical to the grouped one
-  IDQN_D0_PAIR=1      the fused Dense_0 update on pairs of column tiles, dL/da3 finished in the kernel  -> bit-identical
+  IDQN_D0_PAIR=0 / 2  the fused Dense_0 update on single tiles + k_da3_finalize / on pairs of row tiles + finalize instead of
+                      pairs of column tiles with dL/da3 finished in the kernel (default)  -> bit-identical
   IDQN_D0_FWD_DMA=1   the Dense_0 forward fed by per-wave LDS-DMA rings instead of vector registers  -> bit-identical
   IDQN_DP_ALDS=0/1/2  the factored data-parallel update's contraction: registers / a3 fragments through LDS / the same on
                       64 x 256 tiles  -> bit-identical
@@ -118,13 +119,15 @@ def test_dense0_update_finishes_the_data_gradient_itself(default_run):
 
 
 def test_dense0_update_on_pairs_of_column_tiles_is_bit_identical(default_run):
-    """Round 4 (opt-in, measured neutral): IDQN_D0_PAIR=1 gives one workgroup both column tiles of its 32 rows, one after the
-    other; it adds the two partial data gradients itself (tile 0 + tile 1, k_da3_finalize's order), masks and writes the output
-    forms -- no partials in HBM, no finalize launch.  Same arithmetic in the same order: bit-identical."""
-    got = _run(IDQN_D0_PAIR="1")
-    assert got["losses"] == default_run["losses"]
-    assert got["probe"] == default_run["probe"]
-    assert got["acts"] == default_run["acts"]
+    """Round 4 (default): one workgroup takes both column tiles of its 32 rows, one after the other; it adds the two partial data
+    gradients itself (tile 0 + tile 1, k_da3_finalize's order), masks and writes the output forms -- no partials in HBM, no
+    finalize launch.  IDQN_D0_PAIR=0 is the tile kernel + k_da3_finalize, =2 pairs of row tiles + finalize.  Same arithmetic in
+    the same order everywhere: bit-identical."""
+    for mode in ("0", "2"):
+        got = _run(IDQN_D0_PAIR=mode)
+        assert got["losses"] == default_run["losses"], mode
+        assert got["probe"] == default_run["probe"], mode
+        assert got["acts"] == default_run["acts"], mode
 
 
 def test_dense0_forward_through_lds_dma_is_bit_identical(default_run):
