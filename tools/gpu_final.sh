@@ -17,7 +17,7 @@ rm -rf $O/prof_iiqn; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output
 cp $O/prof_iiqn/*/*_kernel_stats.csv $O/iiqn_kernel_stats.csv && echo "iiqn kernel stats ok"
 IDQN_OVERLAP=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_overlap.json 2> $O/bench_overlap.err; echo "overlap rc=$?"
 # round 4: the opt-in launch structures (in-launch hand-offs / roles), each against the default on THIS box (IDQN_NONE=1: the default)
-for sw in IDQN_NONE=1 IDQN_CONV_CHAIN=1 IDQN_D0_FUSE_HIDDEN=1 IDQN_D0_FIN=1 IDQN_ADAM_ROLE=1 IDQN_D0_GROUP=1; do
+for sw in IDQN_NONE=1 IDQN_D0_PAIR=0 IDQN_CONV_CHAIN=1 IDQN_D0_FUSE_HIDDEN=1 IDQN_D0_FIN=1 IDQN_ADAM_ROLE=1 IDQN_D0_GROUP=1 IDQN_D0_FWD_DMA=1; do
   env $sw timeout -k 10 200 python bench.py --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_$sw.json 2> $O/bench_$sw.err; echo "$sw rc=$?"
 done
 rm -rf $O/prof_chain; IDQN_CONV_CHAIN=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_chain -- python bench.py --steps 100 --warmup 20 --repeats 1 --no-cpu-baseline > $O/prof_chain.log 2>&1
@@ -36,7 +36,7 @@ print("BENCH %.1f steps/s  %.4f ms/step  dominant %.1f us %.0f GB/s frac %.3f  s
 for k in d["kernels"]: print("  %-36s %7.1f us" % (k["launch"], k["us"]))
 print("sampling", json.dumps(d.get("sampling"))[:600])
 for f in ("bench_a18","bench_dp1_factored","bench_dp1_allreduce","bench_hp8","bench_emulate1","bench_emulate2","bench_emulate4","bench_emulate8","bench_iiqn","bench_overlap",
-          "bench_IDQN_NONE=1","bench_IDQN_CONV_CHAIN=1","bench_IDQN_D0_FUSE_HIDDEN=1","bench_IDQN_D0_FIN=1","bench_IDQN_ADAM_ROLE=1","bench_IDQN_D0_GROUP=1"):
+          "bench_IDQN_NONE=1","bench_IDQN_D0_PAIR=0","bench_IDQN_D0_FWD_DMA=1","bench_IDQN_CONV_CHAIN=1","bench_IDQN_D0_FUSE_HIDDEN=1","bench_IDQN_D0_FIN=1","bench_IDQN_ADAM_ROLE=1","bench_IDQN_D0_GROUP=1"):
     try:
         x=json.load(open("gpurun_out/final/%s.json"%f)); print(f, "%.1f %s  %.4f ms/step" % (x["value"], x["unit"], x["ms_per_step"]))
     except Exception as e: print(f, "failed", e)

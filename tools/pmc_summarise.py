@@ -38,7 +38,7 @@ for k, c in agg.items():
         e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     out[k] = e
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
-dom = [k for k in out if "k_dense0_wgrad_rows" in k] or [k for k in out if "k_dense0_wgrad<true" in k]
+dom = [k for k in out if "k_dense0_wgrad_pair" in k] or [k for k in out if "k_dense0_wgrad_rows" in k] or [k for k in out if "k_dense0_wgrad<true" in k]
 if dom:
     import subprocess
     git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
