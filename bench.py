@@ -34,6 +34,7 @@ for _p in (ROOT, os.path.join(ROOT, "i-dqn_amd")):
 import numpy as np  # noqa: E402
 
 K_HEADS, BATCH, N_ACTIONS, OBS, FEATURES = 5, 32, 6, (84, 84, 4), [32, 64, 64, 512]
+PROFILE_EVERY = 4  # every 4th step of a timed region carries the hipEvent bracket of the dominant kernel (roofline.achieved)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK = 2.5e15  # dense bf16 MFMA (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12  # f32-input MFMA / f32 vector rate; the step's FLOPs are f32 FLOPs whatever the matrix cores run
@@ -413,8 +414,11 @@ def main():
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(_hip.F_PROFILE)
+        for i in range(args.steps):
+            # the dominant kernel is bracketed with hipEvents on every PROFILE_EVERY-th step of the region only: a bracketed
+            # launch cannot overlap its neighbours' launch / tail phases, which costs the step 4.5 - 5 us (measured: the fifth
+            # 500-step region of the earlier all-steps scheme ran past the 2048-event buffer and was that much faster)
+            step(_hip.F_PROFILE if i % PROFILE_EVERY == 0 else 0)
         barrier()
         elapsed = time.perf_counter() - t0
         if dp:
@@ -497,7 +501,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name.value.decode() + ("<fused Adam>" if fused else "<grad only>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "launch_ms": mean_ms.value, "launches_timed": n_l.value, "algorithmic_bytes": alg_bytes,
+                         "launch_ms": mean_ms.value, "launches_timed": n_l.value, "timed_every": PROFILE_EVERY, "algorithmic_bytes": alg_bytes,
                          # context, not the contract's `frac`: what a pure non-temporal copy reaches on this chip
                          # (profiles/r4_ldsdma_copy_probe.txt: 6.1-6.25 TB/s read + write; MI355X_MICROARCH.md: 6.29)
                          "copy_ceiling": 6200.0, "frac_of_copy_ceiling": achieved / 6200.0},
