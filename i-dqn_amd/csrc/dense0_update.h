@@ -669,6 +669,7 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
     float4 x[4], y[2][4];
     float4 th[DEPTH], mm[DEPTH], vv[DEPTH];
     float dv[4][8];
+    float4 mask4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_ops = [&](int tt) {
         const unsigned a_off = (unsigned)((tile_f0(tt) + bl) * 32 + 16 * h) * 4;
         const unsigned d_off = (unsigned)((tile_jt(tt) * JT + jw + bl) * 32 + 16 * h) * 4;
@@ -738,6 +739,10 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
         // registers of ring slots that are not re-filled any more)
 #pragma unroll
         for (int u = 0; u < 8; ++u) dv[0][u] = D3[(long)(2 * u) * 32];
+        if (!ROWPAIR && tt == 1) {  // ... and so does the ReLU mask the finished rows need at the very end (else a round trip on its own)
+            mask4 = *reinterpret_cast<const float4*>(A3 + (long)(f0 + (t >> 3)) * 32 + (t & 7) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- phase 2: streaming Adam, theta_old takes the consumed gradient's place in LDS
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -813,7 +818,7 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
             // 4 samples of one row f, 8 threads a row)
             s4.x = part0.x + s4.x; s4.y = part0.y + s4.y; s4.z = part0.z + s4.z; s4.w = part0.w + s4.w;
             const int f = f0 + row, sl4 = (t & 7) * 4;
-            const float4 m = *reinterpret_cast<const float4*>(a.a3 + k * a.a3_head + (long)f * 32 + sl4);
+            const float4 m = mask4;
             s4.x = m.x > 0.f ? s4.x : 0.f; s4.y = m.y > 0.f ? s4.y : 0.f; s4.z = m.z > 0.f ? s4.z : 0.f; s4.w = m.w > 0.f ? s4.w : 0.f;
             const long sl = (long)k;
             const int pos = f / a.C, c = f - pos * a.C;
