@@ -1146,6 +1146,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
     dense0_pair_body<ROWPAIR>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
 }
+// ... with whole tiles in flight and cross-tile refills (dense0_pair_body<.., 8>): two waves per SIMD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_dense0_wgrad_pair8(DenseWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
+    dense0_pair_body<false, 8>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
+}
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
 template <int RT>  // 32 * RT rows x 256 columns

@@ -651,9 +651,13 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 // ROWPAIR: the pair is two ROW tiles (f0, f0 + 32) of ONE column tile instead -- the sibling workgroup (other column tile, adjacent
 // in dispatch order) streams the other halves of the same rows at the same time, as in the tile kernel; the partial data
 // gradients go to HBM and k_da3_finalize runs as before.
-template <bool ROWPAIR>
+// DEPTH = 8 (= every row group of a tile; two waves per SIMD): the whole tile is requested at once, and every ring slot the first
+// tile's stream has consumed is re-filled with the SECOND tile's row group at once -- the workgroup's requests never stop across
+// the two MFMA phases between the tiles.
+template <bool ROWPAIR, int DEPTH = 4>
 __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
-    constexpr int JT = 256, RPI = 4, NIT = 8, DEPTH = 4;
+    constexpr int JT = 256, RPI = 4, NIT = 8;
+    constexpr bool XT = DEPTH == NIT;  // cross-tile refills
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
     int jt_fixed = 0;
     if (ROWPAIR) { jt_fixed = item & 1; item >>= 1; }
@@ -756,8 +760,8 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
                 for (int u = 0; u < 8; ++u) dv[c3][u] = D3[(long)(16 * c3 + 2 * u) * 32];
             }
             *reinterpret_cast<float4*>(gp) = t4;
-            if (i + DEPTH < NIT) {
-                const unsigned on = o0 + (unsigned)(i + DEPTH) * rowJ;
+            if (XT ? tt == 0 : i + DEPTH < NIT) {
+                const unsigned on = XT ? tile_base(1) + (unsigned)i * rowJ : o0 + (unsigned)(i + DEPTH) * rowJ;
                 th[s] = ld4<(D0_WG_NT & 1) != 0>(at(Th, on));
                 mm[s] = ld4<(D0_WG_NT & 1) != 0>(at(Mu, on));
                 vv[s] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
@@ -788,7 +792,7 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
                 const int col = jw + 16 * c + 2 * u + hx;
                 d = mfma32(dv[c][u], gs[blx * JT + ((col + 4 * blx) & (JT - 1))], d);
             }
-        if (tt == 0) {    // ... and its first four row groups, into the registers the phase-3 operands have left
+        if (tt == 0 && !XT) {  // ... and its first four row groups, into the registers the phase-3 operands have left
             __builtin_amdgcn_sched_barrier(0);
             prefetch(tile_base(1));
             __builtin_amdgcn_sched_barrier(0);

@@ -1563,8 +1563,10 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     //   IDQN_D0_PAIR=0: the tile kernel + k_da3_finalize.
     //   =2: the pair is two ROW tiles of one column tile (siblings keep streaming a row's halves side by side; partials +
     //   k_da3_finalize): 3.5 us SLOWER than the tile kernel -- what pays in the pair is the finished data gradient, not the pairing.
+    //   =3: the pair kernel with whole tiles in flight and cross-tile refills at two waves per SIMD (k_dense0_wgrad_pair8): the same
+    //   time to 0.4 us.
     static const int pair_mode = getenv("IDQN_D0_PAIR") ? atoi(getenv("IDQN_D0_PAIR")) : 1;
-    const bool pair_on = pair_mode == 1 || (pair_mode == 2 && dw.n_ft % 2 == 0);
+    const bool pair_on = pair_mode == 1 || pair_mode == 3 || (pair_mode == 2 && dw.n_ft % 2 == 0);
     const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
                       h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
     if (pair && pair_mode == 2) {
@@ -1575,7 +1577,10 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         h->d0_rows = true;  // (dL/da3 is finished by the launch)
         const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        if (pair_mode == 3) {  // whole tiles in flight, cross-tile refills, two waves per SIMD
+            if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+            else hipLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, dw);
+        } else if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, dw);
     } else if (rows) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;

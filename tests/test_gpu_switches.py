@@ -123,7 +123,7 @@ def test_dense0_update_on_pairs_of_column_tiles_is_bit_identical(default_run):
     gradients itself (tile 0 + tile 1, k_da3_finalize's order), masks and writes the output forms -- no partials in HBM, no
     finalize launch.  IDQN_D0_PAIR=0 is the tile kernel + k_da3_finalize, =2 pairs of row tiles + finalize.  Same arithmetic in
     the same order everywhere: bit-identical."""
-    for mode in ("0", "2"):
+    for mode in ("0", "2", "3"):  # (3: the pair kernel with whole tiles in flight and cross-tile refills)
         got = _run(IDQN_D0_PAIR=mode)
         assert got["losses"] == default_run["losses"], mode
         assert got["probe"] == default_run["probe"], mode
