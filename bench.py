@@ -16,8 +16,9 @@ N > 1: data-parallel, weak scaling: every rank takes its own 32-sample shard of 
        batch.  IDQN_DP_MODE=allreduce all-reduces the 80.9 MB gradient arena instead.
        `value` counts 32-sample gradient steps: N per global step (units all ranks processed / time).
 
-roofline: the dominant kernel (k_dense0_wgrad, HBM-bound) timed with hipEvents on its own stream inside
-the timed region; cpu_baseline: the oracle's torch-CPU fp32 restatement of the same step, timed on this
+roofline: the dominant kernel (the fused Dense_0 update, HBM-bound) timed with hipEvents on its own stream inside
+the timed regions, on every 4th step (PROFILE_EVERY: the bracket keeps the launch from overlapping its neighbours and
+costs a bracketed step 4.5 - 5 us); cpu_baseline: the oracle's torch-CPU fp32 restatement of the same step, timed on this
 box's host cores on a bounded sample (rank 0, N = 1 only) -- a reported baseline, not the target.
 """
 import argparse
