@@ -913,12 +913,16 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
         }
     }
 }
-__global__ __launch_bounds__(256) void k_td_dh(TdArgs a) { td_dh_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
+    warm_kernargs<sizeof(TdArgs)>();
+    td_dh_body(a, blockIdx.x, blockIdx.y);
+}
 
 // The TD / loss kernel has J / 32 x K workgroups (80 for the Atari net) and is latency-bound; the re-indexing of the
 // Conv_1 / Conv_2 kernels for the data gradients (k_wt_build) depends on nothing this step computes, so its
 // workgroups ride in the same launch instead of costing one of their own.
 __global__ __launch_bounds__(256) void k_td_dh_wt(TdArgs a, WtBuildArgs w, int wt_nx) {
+    warm_kernargs<(sizeof(TdArgs) + sizeof(WtBuildArgs) + 16 < 2048 ? sizeof(TdArgs) + sizeof(WtBuildArgs) + 16 : 2048)>();
     const int njc = a.J / 32, n_td = njc * a.K, b = blockIdx.x;
     if (b < n_td) {
         td_dh_body(a, b % njc, b / njc);
@@ -1401,6 +1405,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(SlabReduceArgs a) {
 // --------------------------------------------------------------------------------------------
 // (AdamArgs and the per-thread body adam_thread: dense0_update.h)
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    warm_kernargs<sizeof(AdamArgs)>();  // (latency-bound launches: the lazily loaded argument fields cost dependent scalar round trips)
     const int k = blockIdx.y;
     if (a.ep_count && blockIdx.x == 0 && threadIdx.x == 0) {
         a.ep_count[k] += 1;
