@@ -304,10 +304,11 @@ def main():
                     help="ONE GPU: the compute side of rank 0 of an N-rank factored data-parallel step (the fused Dense_0 update "
                          "runs over N sample blocks: this rank's factors N times), no collective; a regression guard for the "
                          "part of weak scaling that does not depend on xGMI")
-    ap.add_argument("--emulate-copies", choices=["serial", "side"], default="serial",
+    ap.add_argument("--emulate-copies", choices=["serial", "side", "none"], default="serial",
                     help="--emulate-ranks: the N factor-block copies that stand in for the all-gather run on the compute stream "
                          "(serial: the tracked figure) or on a second stream under the conv backward, where the product path runs "
-                         "its all-gather (side)")
+                         "its all-gather (side), or not at all (none: the gathered block is filled once before the timed region -- the "
+                         "kernels' work does not depend on its contents)")
     ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
                     help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
                          "has no quantile code), one GPU, its own JSON line")
@@ -687,7 +688,9 @@ def emulate_ranks_bench(args, json_fd, Batch):
         agent._learn(batches[it[0] % 8], flags=_hip.F_STOP_BEFORE_DENSE0_WGRAD, mean_divisor=32 * N)
         it[0] += 1
         _hip.check(lib.idqn_export_dense0_factors(agent._handle, _hip.ptr(send), _hip.ptr(send[n_a3:]), q()), "export")
-        if side is None:
+        if args.emulate_copies == "none" and it[0] > 1:
+            pass
+        elif side is None:
             for r in range(N):  # (stands for the all-gather: every slot holds this rank's factors)
                 gathered[r * (n_a3 + n_dh) : (r + 1) * (n_a3 + n_dh)].copy_(send)
         else:  # as the product path runs its all-gather: on a second stream, under the conv backward
@@ -718,7 +721,7 @@ def emulate_ranks_bench(args, json_fd, Batch):
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "copies": args.emulate_copies,
            "note": f"includes {N} device copies of the 5.3 MB factor block standing in for the all-gather "
-                   f"({'on the compute stream' if side is None else 'on a second stream under the conv backward, as the all-gather runs'}); "
+                   f"({'none inside the timed region' if args.emulate_copies == 'none' else 'on the compute stream' if side is None else 'on a second stream under the conv backward, as the all-gather runs'}); "
                    f"the Dense_0 update contracts {N} sample blocks per head",
            "final_losses": [float(x) for x in agent._losses.cpu().numpy()]}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
