@@ -1,0 +1,53 @@
+"""The bench line the driver parses (task contract): one JSON object on stdout with the metric, the timing fields, `roofline` (the
+dominant kernel priced against HBM, measured with hipEvents inside the timed regions) and, unless switched off, `cpu_baseline`.
+Run here with a handful of steps: the figures are meaningless, the structure and the arithmetic between the fields are checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_fields_and_consistent_arithmetic():
+    d = _bench("--gpus", "1", "--steps", "8", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]  # grad-steps/s of one GPU = 1 / step time
+    assert len(d["timing"]["ms_per_step_all"]) == 3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["algorithmic_bytes"] == 5 * (6 * 7744 * 512 * 4 + 2 * 7744 * 32 * 4 + 512 * 32 * 4)
+    assert r["launches_timed"] == 3 * 2 and r["timed_every"] == 4  # steps 0 and 4 of each 8-step region carry the event bracket
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert 0.2 < r["frac"] < 1.0  # an HBM-bound kernel on an MI355X, whatever the box
+    assert r["launch_ms"] < d["ms_per_step"]
+    assert {"gather_B32", "sumtree_B32", "prioritized_protocol"} <= set(d["sampling"])
+    names = [k["launch"] for k in d["kernels"]]
+    assert any("dense0 wgrad" in n for n in names) and not any("finalize" in n for n in names)  # the pair kernel finishes dL/da3 itself
+
+
+def test_cpu_baseline_object():
+    d = _bench("--steps", "4", "--warmup", "1", "--repeats", "1")
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["gpu_over_cpu"] > 10
