@@ -41,15 +41,59 @@ MFMA_BF16_PEAK = 2.5e15  # dense bf16 MFMA (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12  # f32-input MFMA / f32 vector rate; the step's FLOPs are f32 FLOPs whatever the matrix cores run
 
 
-def synthetic(seed, n_actions=N_ACTIONS):
+def synthetic(seed, n_actions=N_ACTIONS, batch=BATCH):
     """SURVEY 8d inputs: iid uint8 frames, uniform actions, rewards in {-1,0,1}, 1 % terminals."""
     rng = np.random.default_rng(seed)
-    s = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
-    s2 = rng.integers(0, 256, size=(BATCH,) + OBS, dtype=np.uint8)
-    a = rng.integers(0, n_actions, size=BATCH).astype(np.int32)
-    r = rng.integers(-1, 2, size=BATCH).astype(np.float32)
-    t = (rng.random(BATCH) < 0.01).astype(np.uint8)
+    s = rng.integers(0, 256, size=(batch,) + OBS, dtype=np.uint8)
+    s2 = rng.integers(0, 256, size=(batch,) + OBS, dtype=np.uint8)
+    a = rng.integers(0, n_actions, size=batch).astype(np.int32)
+    r = rng.integers(-1, 2, size=batch).astype(np.float32)
+    t = (rng.random(batch) < 0.01).astype(np.uint8)
     return s, a, r, s2, t
+
+
+def step_work(K, B, A):
+    """Whole-step algorithmic work: FLOPs = K B (2 F_fwd + F_bwd), bytes = K 7 4 P + 2 B 28224 + 9 B."""
+    macs = 3612672 + 3964928 + 4460544 + 3964928 + 512 * A
+    f_fwd = 2 * macs
+    f_bwd = 2 * f_fwd - 2 * 3612672
+    P = 8 * 8 * 4 * 32 + 32 + 4 * 4 * 32 * 64 + 64 + 3 * 3 * 64 * 64 + 64 + 7744 * 512 + 512 + 512 * A + A
+    return K * B * (2 * f_fwd + f_bwd), K * 7 * 4 * P + 2 * B * 28224 + 9 * B
+
+
+def heads_fit(A, heads=(1, 2, 3, 5), steps=200, warmup=30):
+    """The K-independent part of the step as a tracked number: the plain step at K = 1, 2, 3, 5 heads (K = 1 is DQN,
+    slimdqn/networks/dqn.py:60-73), B = 32, least-squares line us(K) = fixed_us + per_head_us * K."""
+    import torch
+
+    from collections import namedtuple
+
+    from slimdqn.networks.idqn import iDQN
+
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(2000 + i, A))) for i in range(4)]
+    us = []
+    for K in heads:
+        agent = iDQN(0, OBS, A, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+        for i in range(warmup):
+            agent._learn(batches[i % 4])
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                agent._learn(batches[i % 4])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e6
+            best = dt if best is None else min(best, dt)
+        us.append(best)
+        agent._destroy_handle()
+        del agent
+    slope, icpt = np.polyfit(np.asarray(heads, np.float64), np.asarray(us), 1)
+    flops1, bytes1 = step_work(1, BATCH, A)
+    return {"heads": list(heads), "us_per_step": us, "fixed_us": float(icpt), "per_head_us": float(slope),
+            "k1_floor_us_mfma_f32": flops1 / MFMA_F32_PEAK * 1e6, "k1_floor_us_hbm": bytes1 / (HBM_PEAK_GBS * 1e9) * 1e6,
+            "what": f"plain step, B = 32, best of 3 x {steps} steps per K; line fit over K = {list(heads)}"}
 
 
 def usable_cores():
@@ -69,7 +113,7 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("IDQN_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(budget_s=15.0, n_actions=N_ACTIONS):
+def cpu_baseline(budget_s=15.0, n_actions=N_ACTIONS, heads=K_HEADS, batch=BATCH):
     """The oracle's torch-CPU fp32 restatement (K heads batched), all host cores, bounded sample."""
     import torch
 
@@ -78,23 +122,22 @@ def cpu_baseline(budget_s=15.0, n_actions=N_ACTIONS):
 
     cores = usable_cores()
     torch.set_num_threads(cores)
-    p = Q.init_params(0, "cnn", OBS, n_actions, FEATURES, K_HEADS)
-    pt = Q.init_params(1, "cnn", OBS, n_actions, FEATURES, K_HEADS)
+    p = Q.init_params(0, "cnn", OBS, n_actions, FEATURES, heads)
+    pt = Q.init_params(1, "cnn", OBS, n_actions, FEATURES, heads)
     step = T.BatchedStep(p, pt, n_actions, 0.99, 6.25e-5, 1.5e-4)
-    s, a, r, s2, t = synthetic(0, n_actions)
-    batch = (s, a, r, s2, t.astype(bool))
-    step.step(batch)
-    step.step(batch)
+    s, a, r, s2, t = synthetic(0, n_actions, batch)
+    b = (s, a, r, s2, t.astype(bool))
+    step.step(b)
     n, t0 = 0, time.perf_counter()
     while True:
-        step.step(batch)
+        step.step(b)
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 200:
             break
     return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of the same K=5 B=32 Nature-CNN step in {dt:.1f} s (oracle/torch_ref.BatchedStep, "
-                      f"torch-CPU fp32, {cores} threads; the JAX leg is probed separately: cpu_baseline.jax)"}
+            "sample": f"{n} steps of the same K={heads} B={batch} Nature-CNN step in {dt:.1f} s (oracle/torch_ref.BatchedStep, "
+                      f"torch-CPU fp32, {cores} threads, timed before the GPU regions; the JAX leg is probed separately: cpu_baseline.jax)"}
 
 
 def sampling_leg(reps=300):
@@ -309,6 +352,13 @@ def main():
                          "(serial: the tracked figure) or on a second stream under the conv backward, where the product path runs "
                          "its all-gather (side), or not at all (none: the gathered block is filled once before the timed region -- the "
                          "kernels' work does not depend on its contents)")
+    ap.add_argument("--heads", default=str(K_HEADS),
+                    help="heads K of the single-GPU step (default 5 = the headline; 64 = BASELINE config 5's single-device leg); a "
+                         "comma list (1,2,3,5) prints ONLY the K-sweep fit: fixed_us + per_head_us * K")
+    ap.add_argument("--batch", type=int, default=BATCH,
+                    help="minibatch per GPU (default 32 = the headline; 256 = BASELINE config 4's per-step work on one device)")
+    ap.add_argument("--dp-streams", choices=["side", "inline"], default=None,
+                    help="data-parallel step (idqn_dp_step): collectives on the library's side stream (default) or on the compute stream")
     ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
                     help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
                          "has no quantile code), one GPU, its own JSON line")
@@ -377,6 +427,12 @@ def main():
         torch.cuda.set_device(0)
 
     Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    if "," in args.heads:  # the K-sweep alone
+        fit = heads_fit(args.actions, tuple(int(x) for x in args.heads.split(",")), steps=min(args.steps, 300))
+        os.write(json_fd, (json.dumps({"metric": "i-DQN step time by heads K (B = 32), line fit", "unit": "us", "n_gpus": 1, **fit}) + "\n").encode())
+        return
+    K, B = int(args.heads), int(args.batch)
+    headline = K == K_HEADS and B == BATCH
     if args.heads_per_gpu:
         return head_parallel_bench(args, rank, world, json_fd, Batch)
     if args.algo == "iiqn":
@@ -384,14 +440,20 @@ def main():
     if args.emulate_ranks:
         return emulate_ranks_bench(args, json_fd, Batch)
     A = args.actions
-    agent = iDQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
-    # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
-    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i, A))) for i in range(8)]
-    it = [0]
     dp = world > 1 or args.force_dp
-    global_batch = BATCH * world
+    # The CPU leg FIRST (the reference path is timed before the GPU runs), rank 0 of a single-GPU run only.
+    cpu = None
+    if rank == 0 and not dp and not args.no_cpu_baseline:
+        cpu = cpu_baseline(n_actions=A, heads=K, batch=B)
+        cpu["jax"] = jax_cpu_probe(n_actions=A) if headline else {"status": "probed on the headline configuration only"}
+    agent = iDQN(0, OBS, A, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    # 8 distinct synthetic minibatches per rank, resident in HBM before the timed region, used round-robin
+    batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + 64 * rank + i, A, B))) for i in range(8)]
+    it = [0]
+    global_batch = B * world
+    dp_mode = (os.environ.get("IDQN_DP_MODE", "native") if dp else "single")
     if dp and rank == 0:  # the first multi-GPU run should show which algorithm / protocol RCCL picks over xGMI
-        print(f"[bench] NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} IDQN_DP_MODE={os.environ.get('IDQN_DP_MODE', 'factored')}",
+        print(f"[bench] NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} IDQN_DP_MODE={dp_mode} streams={args.dp_streams or os.environ.get('IDQN_DP_STREAMS', 'side')}",
               file=sys.stderr, flush=True)
 
     def step(flags=0):
@@ -400,7 +462,7 @@ def main():
         if not dp:
             agent._learn(batch, flags=flags)
         else:
-            data_parallel_step(agent, batch, global_batch, extra_flags=flags)
+            data_parallel_step(agent, batch, global_batch, extra_flags=flags, mode=dp_mode, streams=args.dp_streams)
 
     for _ in range(args.warmup):
         step()
@@ -449,35 +511,32 @@ def main():
     assert np.isfinite(losses).all(), losses
     if rank == 0:
         P_w0 = 7744 * 512
-        dp_mode = os.environ.get("IDQN_DP_MODE", "factored") if dp else "single"
         fused = dp_mode != "allreduce"
         # algorithmic HBM bytes of one launch of the dominant kernel:
-        # fused: theta, m, v of Dense_0/kernel read + written; unfused: gradient written; + a3 and dh read once
-        # (factored data-parallel: the factors of all `world` ranks)
-        n_blocks = world if dp_mode == "factored" else 1
+        # fused: theta, m, v of Dense_0/kernel read + written; unfused: gradient written; + a3 and dh read once per sample block
+        # (data-parallel: the factors of all `world` ranks)
+        nb = -(-B // 32)
+        n_blocks = nb * (world if fused else 1)
         per_head = (6 if fused else 1) * P_w0 * 4 + n_blocks * (7744 * 32 * 4 + 512 * 32 * 4)
-        if not dp and os.environ.get("IDQN_NO_FUSE_DGRAD") is None:
-            per_head += 7744 * 32 * 4  # single-device path: the kernel also emits dL/da3 (counted once; it writes two partials)
-        alg_bytes = K_HEADS * per_head
+        if not dp:
+            per_head += nb * 7744 * 32 * 4  # single-device path: the kernel also emits dL/da3 (counted once)
+        alg_bytes = K * per_head
         achieved = alg_bytes / (mean_ms.value * 1e-3) / 1e9 if mean_ms.value > 0 else 0.0
-        traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh)
+        # HBM bytes from the committed PMC passes (tools/gpu_pmc.sh -> tools/pmc_summarise.py): per launch of the dominant
+        # kernel, and summed over the launches of one step (headline configuration only: that is what the passes ran)
+        traffic, traffic_source, step_traffic = None, None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            if not dp:
+            if headline and not dp:
                 traffic = pmc["hbm_bytes_per_launch"]
+                step_traffic = pmc.get("step_hbm_bytes")
                 traffic_source = f"profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, library {pmc.get('git', '?')}; not this run)"
         except Exception:
             pass
-        # whole-step algorithmic work: FLOPs = K B (2 F_fwd + F_bwd), bytes = K 7 4 P + 2 B 28224 + 9 B
-        macs = 3612672 + 3964928 + 4460544 + 3964928 + 512 * A
-        f_fwd = 2 * macs
-        f_bwd = 2 * f_fwd - 2 * 3612672
-        step_flops = K_HEADS * BATCH * (2 * f_fwd + f_bwd)
-        P = 8 * 8 * 4 * 32 + 32 + 4 * 4 * 32 * 64 + 64 + 3 * 3 * 64 * 64 + 64 + 7744 * 512 + 512 + 512 * A + A
-        step_bytes = K_HEADS * 7 * 4 * P + 2 * BATCH * 28224 + 9 * BATCH
+        step_flops, step_bytes = step_work(K, B, A)
         ms_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "i-DQN grad-steps/sec, Nature-CNN K=5 batch=32",
+            "metric": f"i-DQN grad-steps/sec, Nature-CNN K={K} batch={B}",
             "value": args.steps * world / elapsed,
             "unit": "grad-steps/s",
             "n_gpus": world,
@@ -489,13 +548,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Atari synthetic 84x84x4 uint8, i-DQN K=5 Nature-CNN [32,64,64,512] A={A}, "
-                                   f"batch 32 per GPU (global {global_batch}), "
+            "config": {"workload": f"Atari synthetic 84x84x4 uint8, i-DQN K={K} Nature-CNN [32,64,64,512] A={A}, "
+                                   f"batch {B} per GPU (global {global_batch}), "
                                    + {"single": "fused wgrad+Adam",
-                                      "factored": "Dense_0 factors all-gathered (RCCL), fused wgrad+Adam over the "
-                                                  "global batch, small leaves all-reduced",
+                                      "native": "ONE C call per step (idqn_dp_step): Dense_0 factors all-gathered (RCCL), fused "
+                                                "wgrad+Adam over the global batch, small leaves all-reduced",
+                                      "factored": "the same schedule issued from Python over torch.distributed",
                                       "allreduce": "grad all-reduce (RCCL) then Adam"}[dp_mode],
-                       "heads": K_HEADS, "batch_per_gpu": BATCH, "global_batch": global_batch, "actions": A,
+                       "heads": K, "batch_per_gpu": B, "global_batch": global_batch, "actions": A,
                        "parallelism": f"dp{world}" if dp else "single",
                        "conv_arithmetic": os.environ.get("IDQN_CONV", "bf16x3") + " (f32-accurate products)"},
             "timing": {"regions": args.repeats, "steps_per_region": args.steps, "reported": "median region",
@@ -512,23 +572,29 @@ def main():
                               "floor_us_mfma_f32": step_flops / MFMA_F32_PEAK * 1e6, "floor_us_hbm": step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6,
                               "frac_mfma": step_flops / MFMA_F32_PEAK / (ms_step * 1e-3),
                               "frac_hbm": step_bytes / (HBM_PEAK_GBS * 1e9) / (ms_step * 1e-3),
+                              # HBM bytes of ALL launches of one step from the PMC passes against the algorithmic bytes
+                              "traffic": step_traffic, "traffic_over_algorithmic": (step_traffic / step_bytes) if step_traffic else None,
                               "peaks": "157.3 TFLOP/s f32-rate MFMA, 8 TB/s HBM3E (MI355X_MICROARCH.md)"},
             "kernels": kernels,
             "final_losses": [float(x) for x in losses],
         }
         if dp:
-            out["rccl"] = rccl_report(dp_mode, world, agent)
-        if not dp:
+            out["rccl"] = rccl_report(dp_mode, world, agent, args.dp_streams or os.environ.get("IDQN_DP_STREAMS", "side"))
+        if headline and not dp:
             try:
                 out["sampling"] = sampling_leg()
             except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg
                 out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
-        if not dp and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n_actions=A)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline"]["jax"] = jax_cpu_probe(n_actions=A)  # "ImportError: ..." where jax is not installed
+            try:  # the K-independent part of the step, tracked
+                out["heads_fit"] = heads_fit(A)
+            except Exception as e:  # noqa: BLE001
+                out["heads_fit"] = {"error": f"{type(e).__name__}: {e}"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = out["value"] / cpu["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dp:
+        agent._destroy_handle()  # (the library-side communicator goes before the process group)
         dist.destroy_process_group()
 
 
@@ -579,6 +645,7 @@ def iiqn_bench(args, json_fd, Batch):
     from slimdqn.networks.iiqn import iIQN
 
     A, N = args.actions, 32
+    cpu = None if args.no_cpu_baseline else iiqn_cpu_baseline(A, N)  # the CPU leg first
     agent = iIQN(0, OBS, A, K_HEADS, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4, n_quantiles=N)
     batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(1000 + i, A))) for i in range(8)]
     it = [0]
@@ -655,9 +722,9 @@ def iiqn_bench(args, json_fd, Batch):
            "timing": {"regions": args.repeats, "steps_per_region": steps, "reported": "median region",
                       "ms_per_step_all": [r / steps * 1e3 for r in regions]},
            "roofline": roof, "kernels": kernels, "final_losses": [float(x) for x in losses]}
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = iiqn_cpu_baseline(A, N)
-        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = out["value"] / cpu["value"]
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
@@ -727,15 +794,18 @@ def emulate_ranks_bench(args, json_fd, Batch):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
-def rccl_report(dp_mode, world, agent):
+def rccl_report(dp_mode, world, agent, streams="side"):
     """What the first multi-GPU run should explain by itself: bytes handed to each collective per step, and RCCL's own
     lines about topology / algorithm / channels (NCCL_DEBUG_FILE of rank 0, set before the communicator is created)."""
-    K, P = K_HEADS, None
-    rep = {"mode": dp_mode, "world": world, "collectives_per_step": []}
+    K = agent._K
+    rep = {"mode": dp_mode, "world": world, "collectives_per_step": [],
+           "issued_by": ("idqn_dp_step (csrc/dp.hip): ncclAllGather / ncclAllReduce on the library's own communicator, "
+                         + ("a side stream ordered by hipEvents" if streams == "side" else "the compute stream")) if dp_mode == "native"
+                        else "slimdqn/networks/parallel.py over torch.distributed (backend nccl = RCCL)"}
     try:
         F, J = next(shape for name, _, shape in agent._leaves if name == "Dense_0/kernel")
         small = int(agent._grad_small.numel()) * 4
-        if dp_mode == "factored":
+        if dp_mode in ("factored", "native"):
             per_rank = K * (F + J) * 32 * 4
             rep["collectives_per_step"] = [
                 {"op": "all_gather", "what": "Dense_0 gradient factors a3 | dh", "bytes_sent_per_rank": per_rank,

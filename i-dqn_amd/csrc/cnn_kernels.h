@@ -531,6 +531,7 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
     }
 }
 
+#ifdef IDQN_VARIANTS
 // k_dense0_fwd3 with the weight stream through LDS-DMA (IDQN_D0_FWD_DMA=1; G = 1 form only).  The register version is bound by how
 // fast a CU streams through global_load_dwordx4 (its loads-only ablation takes the same time); the stand-alone probe
 // (tools/probes/ldsdma_stream_probe.hip) moves the same 158.6 MB at 6.0 - 6.3 TB/s through an LDS-DMA ring against 5.3 TB/s through
@@ -627,6 +628,8 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3d(DenseFwdArgs a) {
         P[(4 * i + 3) * 32] = acc[3][r];
     }
 }
+
+#endif  // IDQN_VARIANTS
 
 // --------------------------------------------------------------------------------------------
 // Head, stage 1 (all 2K nets in parallel): split-K reduce + bias + ReLU -> h, and the per-chunk partial
@@ -1130,6 +1133,7 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     *reinterpret_cast<u32x4*>(dst + 2 * plane + e * 8) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
 }
 
+#ifdef IDQN_VARIANTS
 // The fused kernel over FULL 512-column rows (NQ = 4, dense width 512): the workgroup then holds the complete data gradient
 // of its 32 rows and finishes it itself (ReLU mask, bf16 planes, per-position sums) -- no partial buffer and no finalize
 // launch.  80 KB of LDS (two workgroups per CU), hence dynamic.
@@ -1137,6 +1141,8 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gs_dyn[];
     dense0_wgrad_body<true, 4, true, false>(a, (int)blockIdx.x + a.item0, gs_dyn, (int)threadIdx.x);
 }
+
+#endif
 
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1, bool FIN = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
@@ -1150,11 +1156,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
     dense0_pair_body<ROWPAIR>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
 }
+#ifdef IDQN_VARIANTS
 // ... with whole tiles in flight and cross-tile refills (dense0_pair_body<.., 8>): two waves per SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_dense0_wgrad_pair8(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
     dense0_pair_body<false, 8>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
 }
+#endif
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
 template <int RT>  // 32 * RT rows x 256 columns

@@ -85,3 +85,20 @@ void idqn_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Run-time switches.  The shipped library (libidqn_hip.so) reads only the few documented in INTEGRATION.md, each with a
+// plain getenv().  The launch structures that rounds 2-4 built to bit-identity and measured neutral or slower
+// (profiles/README.md has their A/B files), the experiment knobs and the debug stamps sit behind variant_env(): it resolves
+// the name only in a -DIDQN_VARIANTS build (libidqn_hip_variants.so, used by tools/ and tests/test_gpu_switches.py); in the
+// default build it is a constant nullptr, the branches fold away, and their kernels (#ifdef IDQN_VARIANTS) are not compiled.
+#include <stdlib.h>
+#ifdef IDQN_VARIANTS
+static inline const char* variant_env(const char* name) { return getenv(name); }
+#else
+static inline constexpr const char* variant_env(const char*) { return nullptr; }
+#endif
+static inline int variant_int(const char* name, int dflt) {
+    const char* e = variant_env(name);
+    return e ? atoi(e) : dflt;
+}
+static inline bool variant_on(const char* name) { return variant_int(name, 0) != 0; }

@@ -23,6 +23,8 @@
 
 #include "convp_fwd_body.h"
 
+#ifdef IDQN_VARIANTS
+
 namespace {
 
 template <int NT0, int NT1, int NT2>
@@ -65,3 +67,9 @@ int convp_launch_chain_fwd(const CChainArgs& c, const int NT[3], int n_wg, size_
     if (NT[0] == 6 && NT[1] == 3 && NT[2] == 3) return launch_chain<6, 3, 3>(c, n_wg, lds_bytes, q);
     IDQN_REQUIRE(false, "conv chain: tiles per wave %d / %d / %d are not built (convp_chain_fwd_built says which are)", NT[0], NT[1], NT[2]);
 }
+#else  // default build: the chained launch is not compiled (measured neutral); three launches always
+bool convp_chain_fwd_built(const int*) { return false; }
+int convp_launch_chain_fwd(const CChainArgs&, const int*, int, size_t, hipStream_t) {
+    IDQN_REQUIRE(false, "conv chain: built with -DIDQN_VARIANTS only");
+}
+#endif

@@ -187,6 +187,10 @@ struct DenseWgradArgs {
 // delaying the second and third slot of every CU by one and two thirds of a workgroup's lifetime lets one workgroup of a CU
 // contract while the other two stream.
 __device__ __forceinline__ void d0_stagger(const int ticks) {
+#ifndef IDQN_VARIANTS
+    (void)ticks;
+    return;
+#endif
     const int slot = (int)blockIdx.x >> 8;
     if (ticks > 0 && slot > 0 && slot < 3) {
         const long long t0 = __builtin_amdgcn_s_memrealtime(), d = (long long)slot * ticks;

@@ -23,6 +23,7 @@
 #include "fc_kernels.h"
 #include "iqn_kernels.h"
 #include "gcnn_kernels.h"
+#include "dp_internal.h"
 
 namespace {
 
@@ -33,8 +34,12 @@ struct ConvL {
 
 // CUs the conv launches of the step are planned for (one 512-thread workgroup per CU, all co-resident).  IDQN_CUS < 256
 // leaves the rest of the chip to a concurrent stream (the overlapped Dense_0 update, tools/probes/overlap_cumask.py).
+// the few run-time switches of the shipped library (INTEGRATION.md lists them)
+bool plan_print() { static const bool on = getenv("IDQN_PLAN_PRINT") != nullptr; return on; }  // launch plans to stderr
+bool act_generic() { static const bool on = getenv("IDQN_ACT_GENERIC") != nullptr; return on; }  // acting through the batched forward
+
 int cu_budget() {
-    static const int n = getenv("IDQN_CUS") ? std::max(16, std::min(256, atoi(getenv("IDQN_CUS")))) : 256;
+    static const int n = variant_env("IDQN_CUS") ? std::max(16, std::min(256, atoi(variant_env("IDQN_CUS")))) : 256;
     return n;
 }
 
@@ -376,8 +381,8 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
     {
-        static const bool grp = (getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) != 0) ||
-                                (getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0);
+        static const bool grp = (variant_on("IDQN_D0_GROUP")) ||
+                                (variant_on("IDQN_D0_FUSE_HIDDEN"));
         s.G = (grp && h->planes && units_per_split <= 0 && s.NS >= 8 && s.NS % 4 == 0) ? 4 : 1;
     }
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
@@ -455,14 +460,14 @@ int cnn_setup(idqn_handle_s* h) {
     {
         const int units = h->F / 32;
         int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
-        if (const char* e = getenv("IDQN_D0_SPLITS")) ns = atoi(e);
+        if (const char* e = variant_env("IDQN_D0_SPLITS")) ns = atoi(e);
         h->NS = std::max(1, std::min(std::min(ns, 64), units));
         // IDQN_D0_GROUP=1 (implied by IDQN_D0_FUSE_HIDDEN=1): groups of four splits per workgroup (DenseFwdArgs::G), NS a
         // multiple of 4 that still keeps <= 256 workgroups busy.  Opt-in: a quarter of the partial slabs (-12 MB, k_hidden
         // 5.5 -> 4.9 us) against +2.4 us in the forward itself (240 instead of 250 workgroups, the LDS reduce; rocprofv3),
         // step +-1 us depending on the box (profiles/r4_d0fwd_group_fuse_ab.txt).
-        static const bool grp = (getenv("IDQN_D0_GROUP") && atoi(getenv("IDQN_D0_GROUP")) != 0) ||
-                                (getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0);
+        static const bool grp = (variant_on("IDQN_D0_GROUP")) ||
+                                (variant_on("IDQN_D0_FUSE_HIDDEN"));
         if (grp && h->planes && h->NS >= 8) h->NS = h->NS / 4 * 4;
     }
     const int K = c.n_heads, nb = h->nb_max;
@@ -481,8 +486,8 @@ int cnn_setup(idqn_handle_s* h) {
     }
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
     if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
-    if (h->planes && getenv("IDQN_CONV_PROF")) {
-        h->cprof_role = atoi(getenv("IDQN_CONV_PROF"));
+    if (h->planes && variant_env("IDQN_CONV_PROF")) {
+        h->cprof_role = atoi(variant_env("IDQN_CONV_PROF"));
         // role 10 = the chained forward launch: one [2][4096][8] block of stamps per layer
         if ((rc = alloc_zero(&h->cprof, (h->cprof_role == 10 ? 3 : 1) * 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
     }
@@ -569,14 +574,14 @@ int cnn_setup(idqn_handle_s* h) {
         {
             char nm[16];
             snprintf(nm, sizeof nm, "IDQN_PPC%d", i);  // experiment knob: positions per weight-gradient chunk
-            if (const char* e = getenv(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
+            if (const char* e = variant_env(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
         }
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
             const int per_chunk = K * (i == 0 ? 1 : cl.K);
             int nch = cu_budget() / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
-            if (const char* e = getenv("IDQN_WCHUNKS")) nch = atoi(e);
-            if (const char* e = getenv("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
+            if (const char* e = variant_env("IDQN_WCHUNKS")) nch = atoi(e);
+            if (const char* e = variant_env("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
             h->npc[i] = std::max(1, std::min(nch, npos));
         }
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
@@ -591,7 +596,7 @@ int cnn_setup(idqn_handle_s* h) {
         IDQN_REQUIRE(h->J % 256 == 0, "i-IQN heads: dense width %d must be a multiple of 256", h->J);
         IqnWs& w = h->iqn;
         w.N = c.n_quantiles; w.V = 3 * K;
-        if (const char* e = getenv("IDQN_IQN_SPLITS")) w.NS = std::max(1, std::min(64, atoi(e)));
+        if (const char* e = variant_env("IDQN_IQN_SPLITS")) w.NS = std::max(1, std::min(64, atoi(e)));
         w.off_we = h->L.leaves[10].offset; w.off_be = h->L.leaves[11].offset;
         const long VN = (long)w.V * w.N, KN = (long)K * w.N;
         IDQN_HIP_CHECK(hipMalloc((void**)&w.wbase_v, sizeof(float*) * w.V));
@@ -622,14 +627,14 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
         if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
         // the embedding backward deals the fractions of a feature tile to QG workgroups (IDQN_IQN_EMBED_QG; a divisor of N)
-        w.QG = getenv("IDQN_IQN_EMBED_QG") ? std::max(1, atoi(getenv("IDQN_IQN_EMBED_QG"))) : 4;
+        w.QG = variant_env("IDQN_IQN_EMBED_QG") ? std::max(1, atoi(variant_env("IDQN_IQN_EMBED_QG"))) : 4;
         while (w.QG > 1 && w.N % w.QG != 0) --w.QG;
         if ((rc = alloc_zero(&w.dpsi, (long)w.QG * K * h->F * 32, h, "iqn_dpsi"))) return rc;
         if ((rc = alloc_zero(&w.gpart, (long)w.QG * K * 65 * h->F, h, "iqn_gpart"))) return rc;
-        w.HG = getenv("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(getenv("IDQN_IQN_DH_GROUPS"))) : 8;
+        w.HG = variant_env("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(variant_env("IDQN_IQN_DH_GROUPS"))) : 8;
         while (w.HG > 1 && w.N % w.HG != 0) --w.HG;
         if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
-        if (getenv("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
+        if (variant_env("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
@@ -771,7 +776,7 @@ int fc_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
     h->fc_plan_ = fc_plan(n);
-    if (getenv("IDQN_FC_GENERIC") || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
+    if (variant_env("IDQN_FC_GENERIC") || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
     if (h->fc_plan_.BS) {
         const int bytes = (int)(h->fc_plan_.floats * 4);
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -779,9 +784,9 @@ int fc_setup(idqn_handle_s* h) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     h->fcm_plan_ = fc_mfma_plan(n);
-    if (getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
+    if (variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
     h->fcm_global_ = false;
-    if (!h->fcm_plan_.floats && !(getenv("IDQN_FC_GENERIC") || getenv("IDQN_FC_NO_MFMA") || getenv("IDQN_FC_NO_MFMA_G") || n.dmax > FC_MAX_WIDTH)) {
+    if (!h->fcm_plan_.floats && !(variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") || variant_env("IDQN_FC_NO_MFMA_G") || n.dmax > FC_MAX_WIDTH)) {
         // the matrix does not fit LDS beside the activations: the same kernel with the weight operand read from global memory
         h->fcm_plan_ = fc_mfma_plan_g(n);
         h->fcm_global_ = h->fcm_plan_.floats != 0;
@@ -964,7 +969,7 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     auto key = std::make_tuple(role, n_nets, nb, target);
     auto itp = h->fwd_plans.find(key);
     if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
-    static const int forced = getenv("IDQN_CONV_WGS") ? atoi(getenv("IDQN_CONV_WGS")) : 0;
+    static const int forced = variant_int("IDQN_CONV_WGS", 0);
     FwdPlan pl;
     int rc = IDQN_E_INVALID;
     if (forced > 256 && target == cu_budget()) {
@@ -977,13 +982,13 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     // takes the smaller grid: the matrix loop is as long, the staging traffic and the fill burst are smaller (Conv_1 / Conv_2
     // forward at K = 5: 250 -> 210 workgroups, 24.5 -> 23.7 and 24.1 -> 23.2 us, profiles/r3_conv_cu_budget_sweep.txt;
     // Conv_0 would need 6 tiles instead of 5 and keeps 250).  IDQN_CONV_TRIM=0 switches the rule off.
-    static const bool trim = !(getenv("IDQN_CONV_TRIM") && atoi(getenv("IDQN_CONV_TRIM")) == 0);
+    static const bool trim = (variant_int("IDQN_CONV_TRIM", 1) != 0);
     if (trim && !forced && target == cu_budget() && (role & 7) <= 2) {
         FwdPlan p2;
         if (plan_fwd_target(role & 7, n_nets, nb, g, target * 13 / 16, 160 * 1024, p2) == IDQN_OK && p2.NT == pl.NT && p2.n_items < pl.n_items)
             pl = p2;
     }
-    if (getenv("IDQN_PLAN_PRINT"))
+    if (plan_print())
         fprintf(stderr, "[plan] fwd role %d nets %d nb %d target %d: %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B, supersteps %d, "
                 "ranges/slot %d (NPA %d CT %d NQ %d)\n", role, n_nets, nb, target, pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds,
                 g.KH * g.NCC, pl.items_per_slot, g.NPA, g.CT, g.NQ);
@@ -1013,12 +1018,12 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunk
     // rows of one chunk share its x / dy strips through L2; Conv_0 chunk-major, because its K heads read the SAME staged
     // minibatch and a pixel strip then crosses the fabric once per XCD instead of once per head.  The kernel derives its
     // item (head, chunk, kernel row, balanced position range) from the workgroup index.
-    static const bool net_major = getenv("IDQN_NET_MAJOR") != nullptr;  // A/B switch
+    static const bool net_major = variant_env("IDQN_NET_MAJOR") != nullptr;  // A/B switch
     pl.chunk_major = (layer == 0 && !net_major) ? 1 : 0;
     pl.n_chunks = nch;
     pl.n_items = K * nch * (layer == 0 ? 1 : l.K);
     (void)nb;
-    if (getenv("IDQN_PLAN_PRINT"))
+    if (plan_print())
         fprintf(stderr, "[plan] wgrad layer %d: %d workgroups, %d chunks of ~%d positions, PG %d, MT %d, lds %zu B\n", layer,
                 pl.n_items, nch, npos / nch, pl.PG, pl.MT, pl.lds);
     *out = &(h->wgrad_plans[key] = pl);
@@ -1065,7 +1070,7 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
     }
     a.n_jobs = nj;
     if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; a.epoch = h->chain_ws; }
-    static const int part = getenv("IDQN_STAGE_PART") ? atoi(getenv("IDQN_STAGE_PART")) : 0;  // timing experiments only
+    static const int part = variant_int("IDQN_STAGE_PART", 0);  // timing experiments only
     if (part == 1) return convp_launch_stage(a, a.n_prep_blocks, q);
     if (part == 2) { const int np = a.n_prep_blocks; a.n_prep_blocks = 0; (void)np; return convp_launch_stage(a, (int)blocks, q); }
     return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q);
@@ -1099,7 +1104,7 @@ int conv_args(idqn_handle_s* h, NetSet& s, int role, int nb, int target, CFwdArg
         gin = gi[role]; gout = go[role];
         a.in = ins[role]; a.out3 = outs[role]; a.epilogue = 0; a.b_off = l.b_off; a.CO = l.CO;
         a.in_split = role == 0 ? (s.n_in_sets > 1 ? s.n_nets / 2 : s.n_nets + 1) : 0;
-        static const bool net_major = getenv("IDQN_NET_MAJOR") != nullptr;  // A/B switch
+        static const bool net_major = variant_env("IDQN_NET_MAJOR") != nullptr;  // A/B switch
         a.range_major = role == 0 && !net_major;
         if (role == 2) { a.out_f32 = s.a3; a.f32_slot = h->ga3.block; a.f32_W = l.OW; }
         a.pix_bytes = g.NPA * l.CI * 64; a.plane_bytes = l.CI * 64;
@@ -1198,14 +1203,14 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
     *done = false;
     if (spare) *spare = 0;
     const int cus = budget > 0 ? budget : cu_budget();
-    static const bool no_pair = getenv("IDQN_NO_PAIR") != nullptr;  // A/B switch
+    static const bool no_pair = variant_env("IDQN_NO_PAIR") != nullptr;  // A/B switch
     if (no_pair || layer < 1 || layer > 2) return IDQN_OK;
     // experiment knobs: IDQN_PAIR_D<layer> = workgroups planned for the data gradient, IDQN_PAIR_C<layer> = position chunks
     // of the weight gradient (default: what the data gradient leaves of the 256 CUs)
     auto knob = [&](const char* stem, int dflt) {
         char nm[32];
         snprintf(nm, sizeof nm, "%s%d", stem, layer);
-        const char* e = getenv(nm);
+        const char* e = variant_env(nm);
         return e ? atoi(e) : dflt;
     };
     const int d_target = knob("IDQN_PAIR_D", cus / 2);
@@ -1247,8 +1252,9 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
 #define CHAIN_FLAG_WORDS 4096  // per layer
 int planes_chain_fwd(idqn_handle_s* h, NetSet& s, int nb, hipStream_t q, bool* done) {
     *done = false;
-    static const bool chain_on = getenv("IDQN_CONV_CHAIN") && atoi(getenv("IDQN_CONV_CHAIN")) != 0;
+    static const bool chain_on = variant_on("IDQN_CONV_CHAIN");
     if (!chain_on || &s != &h->train || !h->chain_ws) return IDQN_OK;
+#ifdef IDQN_VARIANTS
     CChainArgs c;
     memset(&c, 0, sizeof(c));
     RoleGeom g[3];
@@ -1289,6 +1295,10 @@ int planes_chain_fwd(idqn_handle_s* h, NetSet& s, int nb, hipStream_t q, bool* d
     c.epoch = h->chain_ws;
     *done = true;
     return convp_launch_chain_fwd(c, NT, n_wg, lds, q);
+#else
+    (void)nb; (void)q;
+    return IDQN_OK;
+#endif
 }
 
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
@@ -1351,7 +1361,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     // bit-identical and measured neutral (profiles/r4_d0fwd_group_fuse_ab.txt: the launch grows by the 7 us the head stage,
     // the write-through drain, the arrival add and the acquire take on the 40 last-arriving workgroups; k_hidden took 5.5 + a
     // boundary) -- the in-launch split-K seam costs what the launch it replaces did, as on the conv chain.
-    static const bool fuse_hidden = getenv("IDQN_D0_FUSE_HIDDEN") && atoi(getenv("IDQN_D0_FUSE_HIDDEN")) != 0;
+    static const bool fuse_hidden = variant_on("IDQN_D0_FUSE_HIDDEN");
     s.hidden_fused = false;
     if (d.G == 4 && fuse_hidden && &s == &h->train && h->chain_ws && h->J % 128 == 0 && (long)s.n_nets * nb * d.n_jt <= 4096 &&
         128 * 33 + 128 * h->cfg.n_actions <= 16384) {
@@ -1363,17 +1373,21 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         if (attr.needs(65536 + 16)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     }
     // IDQN_D0_FWD_DMA=1: the weight stream through a per-wave LDS-DMA ring (k_dense0_fwd3d, bit-identical partials)
-    static const bool fwd_dma = getenv("IDQN_D0_FWD_DMA") && atoi(getenv("IDQN_D0_FWD_DMA")) != 0;
+    static const bool fwd_dma = variant_on("IDQN_D0_FWD_DMA");
+    (void)fwd_dma;
+#ifdef IDQN_VARIANTS
     if (h->planes && fwd_dma && d.G == 1 && d.F / 16 >= d.NS && (long)h->J * 32 * 4 < (1L << 31)) {
         static LdsAttrMark attr;
         constexpr int lds = 4 * 4 * (8192 + 2048);  // all of the CU's 160 KB
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3d, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(k_dense0_fwd3d, dim3(cdiv(d.n_items, 4)), dim3(256), lds, q, d);
-    } else if (h->planes) {
+    } else
+#endif
+    if (h->planes) {
         hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
         // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
         // the previous launches leave the memory system in
-        static const bool twice = getenv("IDQN_D0_FWD_TWICE") && atoi(getenv("IDQN_D0_FWD_TWICE")) != 0;
+        static const bool twice = variant_on("IDQN_D0_FWD_TWICE");
         if (twice && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     } else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
@@ -1464,13 +1478,13 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
     dw.a3p = dw.dhp = nullptr;
-    static const int stagger = getenv("IDQN_D0_STAGGER") ? atoi(getenv("IDQN_D0_STAGGER")) : 0;
+    static const int stagger = variant_int("IDQN_D0_STAGGER", 0);
     dw.stagger = stagger;
     dw.fin_ctr = nullptr;
     // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
     // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
-    static const bool dp_f32 = getenv("IDQN_DP_F32") != nullptr;
-    static const int dp_bf3_min = getenv("IDQN_DP_BF3_MIN") ? atoi(getenv("IDQN_DP_BF3_MIN")) : 2;
+    static const bool dp_f32 = variant_env("IDQN_DP_F32") != nullptr;
+    static const int dp_bf3_min = variant_int("IDQN_DP_BF3_MIN", 2);
     const bool bf3 = h->planes && fuse_adam && !fuse_dg && !dp_f32 && nb_total >= dp_bf3_min && h->J % 256 == 0;
     if (bf3) {
         if (h->fact_planes_cap < nb_total) {  // (first step of a job, or a larger world: outside any timed region)
@@ -1496,17 +1510,17 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // dL/da3 itself and k_da3_finalize is not launched.  Measured: the kernel takes 104-108 us against 95 + 9 for the
     // two-column-tile kernel + finalize (two workgroups per CU instead of three, twice the MFMA phases per workgroup), the
     // step 0.2974-0.3017 against 0.2941 ms (profiles/r3_dense0_rows_ab.txt): kept as a second schedule for the tests.
-    static const bool rows_on = getenv("IDQN_D0_ROWS") && atoi(getenv("IDQN_D0_ROWS")) != 0;
+    static const bool rows_on = variant_on("IDQN_D0_ROWS");
     const bool rows = rows_on && fuse_adam && fuse_dg && h->J == 512 && h->ov.n_def == 0;
     h->d0_rows = rows;
     // IDQN_DP_TILE64=1: the bf16-plane update over several sample blocks (factored data-parallel step) on 64 x 128 tiles, a
     // third less operand traffic per block than 32 x 256 (dense0_update.h).  Opt-in: parity green, measured neutral
     // (profiles/r4_emulate_ranks_tile64_ab.txt: N = 8 emulated 414.9 against 412.7 us) -- the per-block cost of the contraction
     // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
-    static const bool tile64_on = getenv("IDQN_DP_TILE64") && atoi(getenv("IDQN_DP_TILE64")) != 0;
+    static const bool tile64_on = variant_on("IDQN_DP_TILE64");
     // IDQN_DP_ALDS=0: the register version of the contraction (one dependent HBM round trip per sample block)
     //   =2: the same on 64 x 256 tiles (two row tiles share every dh fragment; two workgroups per CU)
-    static const int alds_mode = getenv("IDQN_DP_ALDS") ? atoi(getenv("IDQN_DP_ALDS")) : 1;
+    static const int alds_mode = variant_int("IDQN_DP_ALDS", 1);
     const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
     const bool alds = alds_mode != 0 && !tile64, tall = alds && alds_mode == 2 && h->F % 64 == 0;
     const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
@@ -1530,7 +1544,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     }
     // (the extended launch only when there is something to time: it is not a capturable node of a step graph)
     // IDQN_D0W_PAD: extra (unused) dynamic LDS per workgroup = fewer co-resident workgroups per CU (occupancy experiments)
-    static const int pad = getenv("IDQN_D0W_PAD") ? atoi(getenv("IDQN_D0W_PAD")) : 0;
+    static const int pad = variant_int("IDQN_D0W_PAD", 0);
 #define D0W_LAUNCH(...)                                                                                   \
     do {                                                                                                  \
         static bool attr_set = false;                                                                     \
@@ -1546,7 +1560,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // measured 1 us SLOWER (profiles/r4_d0_fin_ab.txt): before its arrival add a workgroup has to drain its stores -- vmcnt
     // counts in order, so that is every theta / m / v store of its streaming phase -- and the fused kernel grows by 7.6 us,
     // the 5.4 us launch it saves (+ a boundary) notwithstanding.
-    static const bool fin_on = getenv("IDQN_D0_FIN") && atoi(getenv("IDQN_D0_FIN")) != 0;
+    static const bool fin_on = variant_on("IDQN_D0_FIN");
     h->d0_fin = false;
     if (!rows && fuse_adam && nq == 2 && fuse_dg && fin_on && h->fin_ctr && h->planes) {
         dw.fin_ctr = h->fin_ctr;
@@ -1565,23 +1579,21 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     //   k_da3_finalize): 3.5 us SLOWER than the tile kernel -- what pays in the pair is the finished data gradient, not the pairing.
     //   =3: the pair kernel with whole tiles in flight and cross-tile refills at two waves per SIMD (k_dense0_wgrad_pair8): the same
     //   time to 0.4 us.
-    static const int pair_mode = getenv("IDQN_D0_PAIR") ? atoi(getenv("IDQN_D0_PAIR")) : 1;
+    static const int pair_mode = variant_int("IDQN_D0_PAIR", 1);
     const bool pair_on = pair_mode == 1 || pair_mode == 3 || (pair_mode == 2 && dw.n_ft % 2 == 0);
     const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
                       h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
+#ifdef IDQN_VARIANTS
     if (pair && pair_mode == 2) {
         const dim3 pgrid((unsigned)(K * dw.n_ft));  // K * (n_ft / 2) * 2 column tiles
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, dw);
-    } else if (pair) {
+    } else if (pair && pair_mode == 3) {  // whole tiles in flight, cross-tile refills, two waves per SIMD
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
-        h->d0_rows = true;  // (dL/da3 is finished by the launch)
+        h->d0_rows = true;
         const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (pair_mode == 3) {  // whole tiles in flight, cross-tile refills, two waves per SIMD
-            if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-            else hipLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, dw);
-        } else if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, dw);
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, dw);
     } else if (rows) {
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         const size_t lds = (size_t)(32 * 512 + 4096) * 4;
@@ -1589,17 +1601,26 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, dw);
-    } else if (fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
-    else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
-    else if (tile64) D0W_LAUNCH(true, 1, false, true, 2);
-    else if (bf3 && alds && tall) {
+    } else if (!pair && fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
+    else if (!pair && tile64) D0W_LAUNCH(true, 1, false, true, 2);
+    else if (!pair && bf3 && alds && tall) {
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, dw);
-    } else if (bf3 && alds) {
+    } else if (!pair && bf3 && !alds) D0W_LAUNCH(true, 2, false, true);
+    else
+#endif
+    if (pair) {
+        // one workgroup per PAIR of column tiles; the launch finishes dL/da3 itself
+        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
+        h->d0_rows = true;
+        const dim3 pgrid((unsigned)(K * dw.n_ft));
+        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, dw);
+    } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
+    else if (bf3) {  // the factored data-parallel update over >= 2 sample blocks: a3 fragments through LDS
         if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
         else hipLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, dw);
     }
-    else if (bf3) D0W_LAUNCH(true, 2, false, true);
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
     else if (nq == 2) D0W_LAUNCH(false, 2);
@@ -1638,7 +1659,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
     ta.chain_err = h->chain_ws ? h->chain_ws + 32 : nullptr;
-    static const bool stage_part = getenv("IDQN_STAGE_PART") && atoi(getenv("IDQN_STAGE_PART")) == 1;  // (timing experiment: no packing blocks)
+    static const bool stage_part = variant_env("IDQN_STAGE_PART") && atoi(variant_env("IDQN_STAGE_PART")) == 1;  // (timing experiment: no packing blocks)
     ta.bcinv_done = (h->planes && !stage_part) ? 1 : 0;
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
@@ -1653,7 +1674,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient).  On the fused single-device path it is
     // computed INSIDE the weight-gradient + Adam kernel (theta streams once) and finished by k_da3_finalize; the two-call
     // paths of the data-parallel step need it before the weight gradient and keep the separate kernel.
-    static const bool no_fuse_dg = getenv("IDQN_NO_FUSE_DGRAD") != nullptr;
+    static const bool no_fuse_dg = variant_env("IDQN_NO_FUSE_DGRAD") != nullptr;
     const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg;
     if (!fuse_dg) {
         DenseDgradArgs dd;
@@ -1680,10 +1701,10 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // deferred to stream roles of the Conv_2 pair and Conv_0 weight-gradient launches (they only emit their data-gradient
     // share here); IDQN_OV_S2 / IDQN_OV_R2 / IDQN_OV_S0 / IDQN_OV_R0: stream workgroups and rounds per launch.
     h->ov.n_def = h->ov.left = 0;
-    static const bool overlap = getenv("IDQN_OVERLAP") && atoi(getenv("IDQN_OVERLAP")) != 0;
+    static const bool overlap = variant_on("IDQN_OVERLAP");
     if (overlap && fuse_dg && nb == 1 && h->planes) {
-        static const int S2 = getenv("IDQN_OV_S2") ? atoi(getenv("IDQN_OV_S2")) : 40, R2 = getenv("IDQN_OV_R2") ? atoi(getenv("IDQN_OV_R2")) : 2;
-        static const int S0 = getenv("IDQN_OV_S0") ? atoi(getenv("IDQN_OV_S0")) : 96, R0 = getenv("IDQN_OV_R0") ? atoi(getenv("IDQN_OV_R0")) : 1;
+        static const int S2 = variant_int("IDQN_OV_S2", 40), R2 = variant_int("IDQN_OV_R2", 2);
+        static const int S0 = variant_int("IDQN_OV_S0", 96), R0 = variant_int("IDQN_OV_R0", 1);
         const int n_items = K * (h->F / 32) * (h->J / 256);
         // S2 / S0 ask for that many CUs; the plans say how many workgroups the launches really leave (whole position chunks)
         int sp2 = 0, sp0 = 0;
@@ -1762,8 +1783,8 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bo
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
             if (!rc && i == 0 && adam_role && !ovl) {
-                static const bool role_on = getenv("IDQN_ADAM_ROLE") && atoi(getenv("IDQN_ADAM_ROLE")) != 0;
-                static const int role_cus = getenv("IDQN_ADAM_ROLE_CUS") ? atoi(getenv("IDQN_ADAM_ROLE_CUS")) : 96;
+                static const bool role_on = variant_on("IDQN_ADAM_ROLE");
+                static const int role_cus = variant_int("IDQN_ADAM_ROLE_CUS", 96);
                 CWgradArgs wa;
                 WgradPlan* pl = nullptr;
                 const int conv_budget = std::max(K, cu_budget() - role_cus);
@@ -2041,7 +2062,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     IqnWs& w = h->iqn;
     IqnCosArgs ca;
     // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
-    static const bool embed3 = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
+    static const bool embed3 = (variant_int("IDQN_IQN_EMBED3", 1) != 0);
     ca.tau = tau; ca.cosb = w.cosb; ca.cost = embed3 ? nullptr : w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
@@ -2049,7 +2070,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     ea.cosb = w.cosb; ea.wbase = wbase_v; ea.psi = psi; ea.x = w.xq; ea.we_off = w.off_we; ea.be_off = w.off_be;
     ea.K = K_for_index; ea.N = w.N; ea.F = h->F;
     {   // fractions per wave: 8 when that still leaves >= 8 waves per SIMD to overlap, else fewer (IDQN_IQN_EMBED_Q overrides)
-        static const int qenv = getenv("IDQN_IQN_EMBED_Q") ? atoi(getenv("IDQN_IQN_EMBED_Q")) : 0;
+        static const int qenv = variant_int("IDQN_IQN_EMBED_Q", 0);
         int per = qenv > 0 ? qenv : 8;
         while (per > 1 && (w.N % per != 0)) --per;
         const dim3 grid((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per));
@@ -2063,7 +2084,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
             e3.cosp = w.cosp; e3.wep = w.wep; e3.wbase = wbase_v; e3.psi = psi; e3.x = w.xq; e3.be_off = w.off_be;
             e3.K = K_for_index; e3.N = w.N; e3.F = h->F; e3.n_packed = n_packed;
             // cos fragments through LDS, once per workgroup (IDQN_IQN_EMBED_LDS=0: every wave fetches its own from L2)
-            static const bool e3lds = !(getenv("IDQN_IQN_EMBED_LDS") && atoi(getenv("IDQN_IQN_EMBED_LDS")) == 0);
+            static const bool e3lds = (variant_int("IDQN_IQN_EMBED_LDS", 1) != 0);
             if (e3lds) hipLaunchKernelGGL(k_iqn_embed3l, grid, dim3(256), 2 * 12288, q, e3);
             else hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
         } else {
@@ -2077,7 +2098,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
     d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
-    static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+    static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;
         g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
@@ -2159,14 +2180,14 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         dd.dh = w.dh; dd.raw = w.dx; dd.wbase = h->train.wbase; dd.w_off = h->off_w0;
         dd.K = K; dd.nb = w.N; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = h->conv[2].CO; dd.g = h->gda3;
         dd.n_items = (long)K * w.N * cdiv(dd.n_ft, 4);
-        static const bool gemm = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+        static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
         if (gemm && w.N % 8 == 0 && h->J % 16 == 0) {
             IqnD0DgradArgs g;
             g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
             const size_t lds = 2 * (size_t)IG_STAGE;
             const int n_d = K * (w.N / 8) * cdiv(h->F, 256);
             // the weight-gradient GEMM rides in the same launch (IDQN_IQN_MERGE=0: two launches)
-            static const bool merge = !(getenv("IDQN_IQN_MERGE") && atoi(getenv("IDQN_IQN_MERGE")) == 0);
+            static const bool merge = (variant_int("IDQN_IQN_MERGE", 1) != 0);
             if (merge && w.g1 && w.N % 16 == 0) {
                 IqnD0WgradArgs gw;
                 gw.x = w.xq; gw.dh = w.dh; gw.g[0] = h->grad + h->g_w0_base; gw.g[1] = w.g1; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 2;
@@ -2189,7 +2210,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     eb.cosb = w.cosb; eb.cost = w.cost; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
     eb.we_off = w.off_we; eb.be_off = w.off_be;
     eb.K = K; eb.N = w.N; eb.F = h->F;
-    static const bool embed3b = !(getenv("IDQN_IQN_EMBED3") && atoi(getenv("IDQN_IQN_EMBED3")) == 0);
+    static const bool embed3b = (variant_int("IDQN_IQN_EMBED3", 1) != 0);
     if (embed3b) {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
         IqnEmbedBwd3Args e3;
         e3.cosp = w.cosp; e3.cosa = w.cosa; e3.wep = w.wep; e3.wbase = w.wbase_v; e3.psi = h->train.a3; e3.dx = w.dx;
@@ -2218,7 +2239,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     }
     // Dense_0 weight gradient over the N fraction blocks of every head + Adam: as a GEMM with two block splits and one
     // streaming Adam pass (iqn_gemm.h), or (IDQN_IQN_GEMM=0, N not a multiple of 16) the plain step's fused kernel
-    static const bool gemm_w = !(getenv("IDQN_IQN_GEMM") && atoi(getenv("IDQN_IQN_GEMM")) == 0);
+    static const bool gemm_w = (variant_int("IDQN_IQN_GEMM", 1) != 0);
     if (gemm_w && w.g1 && w.N % 16 == 0) {
         const long n = (long)h->F * h->J;
         IqnD0WgradArgs g;
@@ -2317,6 +2338,15 @@ extern "C" int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_de
     return IDQN_OK;
 }
 
+int idqn_internal_dp_view(idqn_handle_t h, IdqnDpView* v) {  // (csrc/dp.hip)
+    IDQN_REQUIRE(h && v, "null handle");
+    IDQN_REQUIRE(h->cfg.arch == IDQN_ARCH_CNN && !h->gc.on && h->cfg.n_quantiles == 0,
+                 "the data-parallel step is built for the MFMA cnn path of the i-DQN heads");
+    v->grad = h->grad; v->losses = h->losses; v->n_small = (long)h->cfg.n_heads * h->gP + 64;
+    v->K = h->cfg.n_heads; v->F = h->F; v->J = h->J;
+    return IDQN_OK;
+}
+
 extern "C" int idqn_set_per_buffers(idqn_handle_t h, const float* weights_dev, float* td_abs_out_dev) {
     IDQN_REQUIRE(h, "idqn_set_per_buffers: null handle");
     h->is_weight = weights_dev;
@@ -2384,7 +2414,6 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     IDQN_REQUIRE(n >= 1 && n <= 32, "idqn_q_values: n = %d, must be in [1, 32]", n);
     hipStream_t q = (hipStream_t)stream;
     const float* params = (which ? h->target : h->online) + (long)head * h->L.head_stride;
-    static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
     if (h->gc.on) {  // general-shape cnn: trunk of the one net on the n states, then the generic dense forward
         const float* const* wb = h->train.wbase + (which * h->cfg.n_heads + head);
         int rc = gcnn_trunk(h, wb, 1, 1, n, (const uint8_t*)states_dev, (const uint8_t*)states_dev, h->gc.inf_act, q);
@@ -2398,7 +2427,7 @@ static int q_values_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    if (h->cfg.arch == IDQN_ARCH_CNN && n == 1 && !act_generic && h->J <= 512 && h->cfg.n_actions <= 32) {
+    if (h->cfg.arch == IDQN_ARCH_CNN && n == 1 && !act_generic() && h->J <= 512 && h->cfg.n_actions <= 32) {
         // one state: the latency path (act_kernels.h) -- pixels and parameter leaves as they are, five small launches
         const float* in = nullptr;
         int ih = h->cfg.obs_h, iw = h->cfg.obs_w;
@@ -2493,9 +2522,8 @@ static int act_host_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
     }
     // The single-state path ends in a kernel that can write the action straight into mapped host memory, followed by a
     // sequence number the host polls (IDQN_ACT_POLL=0: a device-to-host copy and a stream synchronisation instead).
-    static const bool act_generic = getenv("IDQN_ACT_GENERIC") != nullptr;
     static const bool no_poll = getenv("IDQN_ACT_POLL") && atoi(getenv("IDQN_ACT_POLL")) == 0;
-    const bool poll = !no_poll && ((cnn && !h->gc.on) ? (!act_generic && h->J <= 512 && h->cfg.n_actions <= 32) : true);
+    const bool poll = !no_poll && ((cnn && !h->gc.on) ? (!act_generic() && h->J <= 512 && h->cfg.n_actions <= 32) : true);
     if (poll && !h->act_mail) {
         IDQN_HIP_CHECK(hipHostMalloc((void**)&h->act_mail, 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(h->act_mail, 0, 64);

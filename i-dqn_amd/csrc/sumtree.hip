@@ -22,7 +22,7 @@ void idqn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* idqn_last_error(void) { return g_err; }
-extern "C" int idqn_abi_version(void) { return 2; }  // 2: idqn_config_t.n_quantiles, the i-IQN entry points
+extern "C" int idqn_abi_version(void) { return 3; }  // 2: idqn_config_t.n_quantiles, the i-IQN entry points; 3: sumtree_query_host(n_live), the idqn_dp_* family
 
 #define ST_THREADS 1024
 #define ST_MAX_N 4096
@@ -487,7 +487,7 @@ struct SamplerMailbox {
 };
 
 __global__ __launch_bounds__(256) void k_sumtree_query_mail(const double* __restrict__ nodes, int depth, int n, int scale_by_root,
-                                                            const int32_t* __restrict__ index_to_key, unsigned char* mail,
+                                                            const int32_t* __restrict__ index_to_key, int n_live, unsigned char* mail,
                                                             int max_n, unsigned* ctl, unsigned seq) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;  // wave-uniform
@@ -505,7 +505,11 @@ __global__ __launch_bounds__(256) void k_sumtree_query_mail(const double* __rest
     if ((threadIdx.x & 63) == 0) {
         const int leaf = (int)(node - first_leaf);
         leaves[i] = leaf;
-        keys[i] = index_to_key ? index_to_key[leaf] : leaf;
+        // the map holds n_live entries: a descent that ends on an empty leaf behind them (drift in the node sums, a target at
+        // the root) is the reference's IndexError from `_index_to_key[index]` (samplers.py:114), not a stale or foreign key
+        const bool past = index_to_key && n_live >= 0 && leaf >= n_live;
+        if (past) bad |= 4;
+        keys[i] = index_to_key ? (past ? -1 : index_to_key[leaf]) : leaf;
         if (bad) atomicOr(&ctl[1], (unsigned)bad);
         __threadfence_system();  // this wave's results are visible to the host before its arrival counts
         if (atomicAdd(&ctl[0], 1u) == (unsigned)n - 1u) {  // the last wave of the launch announces it
@@ -548,7 +552,7 @@ extern "C" int sampler_mailbox_destroy(void* mailbox) {
 }
 
 extern "C" int sumtree_query_host(const double* nodes_dev, int32_t depth, const double* values_host, int32_t n,
-                                  int32_t scale_by_root, const int32_t* index_to_key_dev, void* mailbox,
+                                  int32_t scale_by_root, const int32_t* index_to_key_dev, int32_t n_live, void* mailbox,
                                   int32_t* leaves_out_host, int32_t* keys_out_host, double* root_out_host,
                                   int32_t* status_out_host, void* stream) {
     SamplerMailbox* mb = (SamplerMailbox*)mailbox;
@@ -559,7 +563,7 @@ extern "C" int sumtree_query_host(const double* nodes_dev, int32_t depth, const 
     memcpy(mb->host + 64, values_host, (size_t)n * 8);
     const unsigned want = ++mb->seq;
     hipLaunchKernelGGL(k_sumtree_query_mail, dim3(cdiv(n, 4)), dim3(256), 0, q, nodes_dev, depth, n, scale_by_root, index_to_key_dev,
-                       mb->dev, mb->max_n, mb->ctl, want);
+                       (int)n_live, mb->dev, mb->max_n, mb->ctl, want);
     IDQN_HIP_CHECK(hipGetLastError());
     volatile unsigned* seqp = reinterpret_cast<volatile unsigned*>(mb->host + 12);
     bool seen = false;

@@ -14,6 +14,7 @@ IDQN_ARCH_CNN, IDQN_ARCH_FC = 0, 1
 IDQN_MAX_FEATURES, IDQN_MAX_LEAVES = 8, 24
 F_GRADS_ONLY, F_PROFILE, F_STOP_AFTER_DENSE0, F_STOP_BEFORE_DENSE0_WGRAD, F_PROFILE_ALL = 1, 2, 4, 8, 16
 FACTORED_DENSE0, FACTORED_REST = 1, 2
+DP_SIDE_STREAM, DP_UNIQUE_ID_BYTES = 1, 128
 E_INVALID, E_HIP, E_RANGE, E_ASSERT = -1, -2, -3, -4
 
 
@@ -53,11 +54,18 @@ SYMBOLS = {
     "idqn_dense0_factors": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "idqn_finish_step_factored": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32] + [C.c_int64] * 6 + [C.c_uint32, _P]),
     "idqn_apply_adam": (C.c_int, [_P, _P]),
+    "idqn_dp_unique_id": (C.c_int, [_P]),
+    "idqn_dp_create": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_P)]),
+    "idqn_dp_create_from_comm": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    "idqn_dp_destroy": (C.c_int, [_P]),
+    "idqn_dp_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "idqn_dp_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "idqn_dp_exchange_row": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
     "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
     "sumtree_set_one": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]),
     "sampler_mailbox_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),
     "sampler_mailbox_destroy": (C.c_int, [_P]),
-    "sumtree_query_host": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.POINTER(C.c_double),
+    "sumtree_query_host": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), _P]),
     "sampler_map_set": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "sampler_map_indices": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

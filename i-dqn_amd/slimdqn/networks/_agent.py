@@ -44,10 +44,12 @@ class _PendingHostAction:
     def item(self):
         if self._value is None:
             a = self._agent
-            _hip.check(_hip.lib().idqn_act_host_end(a._handle, C.c_void_p(a._act_out.data_ptr()), _hip.current_stream()),
-                       "idqn_act_host_end")
-            self._value = int(a._act_out_np[0])
-            a._act_in_flight = None
+            try:
+                _hip.check(_hip.lib().idqn_act_host_end(a._handle, C.c_void_p(a._act_out.data_ptr()), _hip.current_stream()),
+                           "idqn_act_host_end")
+                self._value = int(a._act_out_np[0])
+            finally:  # the library has dropped its pending launch either way: a failure must not wedge every later call
+                a._act_in_flight = None
         return self._value
 
     __int__ = __index__ = item
@@ -141,6 +143,9 @@ class DeviceAgent:
                 pending.item()
             except Exception:
                 self._act_in_flight = None
+        dp = self.__dict__.pop("_dp", None)  # (slimdqn/networks/parallel.py: the RCCL side of this handle goes first)
+        if dp is not None:
+            _hip.lib().idqn_dp_destroy(dp[0])
         if getattr(self, "_handle", None) is not None:
             _hip.lib().idqn_destroy(self._handle)
             self._handle = None
@@ -160,17 +165,14 @@ class DeviceAgent:
         return t.to(device="cuda", dtype=dtype).contiguous()
 
     # ---- the step ------------------------------------------------------------------------------------
-    def _learn(self, batch, flags=0, mean_divisor=None):
-        """One gradient step on a ReplayElement-like batch; returns the per-head losses (device, [K])."""
+    def _prepare(self, batch):
+        """``(B, pointers)`` of a ReplayElement-like batch on the device: state, next_state, action, reward, terminal."""
         # The replay buffer hands out the SAME ReplayElement object (views of a staging set) every other sample: its
         # converted tensors and argument pointers are kept per object (a handful of entries; the entry holds the object).
         cache = self.__dict__.setdefault("_learn_cache", {})
         hit = cache.get(id(batch))
         if hit is not None and hit[0] is batch and self._handle is not None and hit[1] <= self._handle_batch:
-            _, B, ptrs = hit
-            _hip.check(_hip.lib().idqn_learn_on_batch(self._handle, *ptrs, B, int(mean_divisor or B), int(flags),
-                                                      _hip.current_stream()), "idqn_learn_on_batch")
-            return self._losses
+            return hit[1], hit[2]
         if self._arch == "cnn":
             s, s2 = self._dev(batch.state, torch.uint8), self._dev(batch.next_state, torch.uint8)
             assert tuple(s.shape[1:]) == self._obs, f"state shape {tuple(s.shape)} vs observation_dim {self._obs}"
@@ -184,14 +186,19 @@ class DeviceAgent:
         assert a.numel() == B and r.numel() == B and t.numel() == B
         self._ensure_handle(B)
         self._keep = (s, s2, a, r, t)  # keep inputs alive until the stream has consumed them
+        ptrs = (_hip.ptr(s), _hip.ptr(s2), _hip.ptr(a), _hip.ptr(r), _hip.ptr(t))
         if type(batch).__name__ == "ReplayElement" and all(hasattr(f, "tensor") for f in (batch.state, batch.action)):
             if len(cache) >= 8:
                 cache.clear()
             if all(x.data_ptr() == getattr(f, "tensor", f).data_ptr() for x, f in
                    ((s, batch.state), (s2, batch.next_state), (a, batch.action), (r, batch.reward), (t, batch.is_terminal))):
-                cache[id(batch)] = (batch, B, (_hip.ptr(s), _hip.ptr(s2), _hip.ptr(a), _hip.ptr(r), _hip.ptr(t)))
-        _hip.check(_hip.lib().idqn_learn_on_batch(self._handle, _hip.ptr(s), _hip.ptr(s2), _hip.ptr(a), _hip.ptr(r),
-                                                  _hip.ptr(t), B, int(mean_divisor or B), int(flags),
+                cache[id(batch)] = (batch, B, ptrs)
+        return B, ptrs
+
+    def _learn(self, batch, flags=0, mean_divisor=None):
+        """One gradient step on a ReplayElement-like batch; returns the per-head losses (device, [K])."""
+        B, ptrs = self._prepare(batch)
+        _hip.check(_hip.lib().idqn_learn_on_batch(self._handle, *ptrs, B, int(mean_divisor or B), int(flags),
                                                   _hip.current_stream()), "idqn_learn_on_batch")
         return self._losses
 

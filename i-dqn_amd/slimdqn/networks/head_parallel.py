@@ -122,7 +122,7 @@ class HeadShardedIDQN(iDQN):
         action = torch.zeros(1, dtype=torch.int64, device=self._cum.device)
         if owner == self._rank:
             assert params is self.params or params is self.target_params
-            action[0] = self._best_action(0 if params is self.params else 1, local, state)
+            action[0] = int(self._best_action(0 if params is self.params else 1, local, state))  # (also a pending host action)
         dist.broadcast(action, src=dist.get_global_rank(self._group, owner) if self._group is not None else owner,
                        group=self._group)
         return action[0]

@@ -24,6 +24,14 @@ library: nothing is copied before the collective) instead of all-reducing the
 gather runs while ``idqn_backward_rest`` computes the conv backward; the 1.6 MB of small leaves (and the K losses)
 are all-reduced under the fused Dense_0 update, which needs only the gathered factors.  Every rank sums the same blocks in the same order, so replicas stay bit-identical.
 ``IDQN_DP_MODE=allreduce`` selects the all-reduce variants above.
+
+Native mode (GPU, cnn path, RCCL backend: the default there): the SAME factored schedule issued by ONE C call,
+``idqn_dp_step`` (``include/idqn_hip.h``, ``csrc/dp.hip``) -- the library owns an RCCL communicator (``idqn_dp_create``: rank 0's
+``ncclGetUniqueId`` bytes are broadcast over this process group once) and enqueues forward -> ``ncclAllGather`` of the factor
+run -> conv backward -> ``ncclAllReduce`` of the small region -> fused update itself, with the collectives on a side stream of
+its own ordered by events (``IDQN_DP_STREAMS=inline``: on the compute stream).  The Python schedule below stays as the
+oracle of that call (``tests/test_gpu_configs.py``: bit-identical) and as the path of the gloo tests.
+``IDQN_DP_MODE=factored`` selects it on RCCL too.
 """
 import ctypes as C
 import os
@@ -77,12 +85,50 @@ def _factored_step(agent, shard, global_batch, group, extra_flags, serial=False)
     return agent._losses
 
 
+def _native_handle(agent, group, streams=None):
+    """The library-side RCCL communicator of this agent's handle (``idqn_dp_create``), created on first use: collective."""
+    import torch
+
+    dp = agent.__dict__.get("_dp")
+    if dp is not None and dp[1] == agent._handle.value:
+        return dp[0]
+    if dp is not None:  # the handle was re-created for a larger batch: its dp object went with it (DeviceAgent._destroy_handle)
+        agent.__dict__.pop("_dp", None)
+    lib = _hip.lib()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = (C.c_ubyte * _hip.DP_UNIQUE_ID_BYTES)()
+    if rank == 0:
+        _hip.check(lib.idqn_dp_unique_id(uid), "idqn_dp_unique_id")
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if streams is None:
+        streams = os.environ.get("IDQN_DP_STREAMS", "side")
+    flags = _hip.DP_SIDE_STREAM if streams == "side" else 0
+    h = C.c_void_p()
+    torch.cuda.synchronize()
+    _hip.check(lib.idqn_dp_create(agent._handle, box[0], rank, world, flags, C.byref(h)), "idqn_dp_create")
+    agent._dp = (h, agent._handle.value)
+    return h
+
+
+def _native_step(agent, shard, global_batch, group, extra_flags, streams=None):
+    B, ptrs = agent._prepare(shard)
+    dp = _native_handle(agent, group, streams)
+    _hip.check(_hip.lib().idqn_dp_step(dp, *ptrs, B, int(global_batch), int(extra_flags), _hip.current_stream()), "idqn_dp_step")
+    return agent._losses
+
+
 def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags: int = 0, overlap=None, mode=None,
-                       serial: bool = False):
+                       serial: bool = False, streams=None):
     """One global gradient step; ``shard`` is this rank's ReplayElement-like slice of the global batch."""
     on_gpu_cnn = agent._grad.is_cuda and getattr(agent, "_arch", "") == "cnn"
     if mode is None:
-        mode = os.environ.get("IDQN_DP_MODE", "factored")
+        rccl = on_gpu_cnn and dist.get_backend(group) == "nccl"  # one rank per GPU: the library's own communicator works
+        mode = os.environ.get("IDQN_DP_MODE", "native" if rccl else "factored")
+    if mode == "native" and on_gpu_cnn and overlap is None and not serial:
+        return _native_step(agent, shard, global_batch, group, extra_flags, streams)
+    if mode == "native":
+        mode = "factored"
     if mode == "factored" and on_gpu_cnn and overlap is None:
         return _factored_step(agent, shard, global_batch, group, extra_flags, serial)
     if overlap is None:

@@ -159,7 +159,7 @@ class _MemoryView:
     def __getitem__(self, key):
         if key not in self.keys():
             raise KeyError(key)
-        rb = self._rb
+        rb = self._rb  # (`keys()` above read add_count: a postponed add has been applied)
         slot = key % rb._max_capacity
         el = rb._gather(np.asarray([slot], np.int32))
         return ReplayElement(np.asarray(el.state)[0], int(rb._action[slot]), float(rb._reward64[slot]),
@@ -169,10 +169,22 @@ class _MemoryView:
 class ReplayBuffer:
     STAGING = 64  # pinned host frames in flight towards the ring
 
+    # `add_count` (and through it `_memory`) is read by callers at any time: a read first applies a postponed add
+    # (add_deferred), so that every observer sees the buffer `add` would have left -- mid-epoch callbacks included.
+    @property
+    def add_count(self) -> int:
+        if getattr(self, "_deferred", None) is not None:
+            self.flush_deferred()
+        return self._add_count
+
+    @add_count.setter
+    def add_count(self, value: int) -> None:
+        self._add_count = value
+
     def __init__(self, sampling_distribution, batch_size: int, max_capacity: int, stack_size: int = 4,
                  update_horizon: int = 1, gamma: float = 0.99, checkpoint_duration: int = 4, compress: bool = True,
                  clipping: callable = None):
-        self.add_count = 0
+        self._add_count = 0
         self._max_capacity = max_capacity
         self._compress = compress  # accepted for signature parity; the HBM store is uncompressed
         self._sampling_distribution = sampling_distribution

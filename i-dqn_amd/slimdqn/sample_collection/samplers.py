@@ -67,11 +67,14 @@ class UniformSamplingDistribution:
     def enable_device_map(self, capacity: int) -> None:
         """Keeps a copy of ``index -> key`` in HBM (``sampler_map_set`` on every add / remove) so that ``sample_device``
         can hand out the sampled keys as a device tensor.  Not part of the reference's protocol: opt-in."""
+        assert int(capacity) >= len(self._map), "capacity below the number of keys already held"
         self._i2k_dev = torch.zeros(int(capacity), dtype=torch.int32, device="cuda")
         for i, k in enumerate(self._map.index_to_key):
             _hip.check(_hip.lib().sampler_map_set(_hip.ptr(self._i2k_dev), i, int(k), _hip.current_stream()), "sampler_map_set")
 
     def add(self, key: ReplayItemID) -> None:
+        if self._i2k_dev is not None and len(self._map) >= self._i2k_dev.numel():
+            raise IndexError(f"device index map holds {self._i2k_dev.numel()} entries (enable_device_map capacity)")
         index = self._map.add(key)
         if self._i2k_dev is not None:
             _hip.check(_hip.lib().sampler_map_set(_hip.ptr(self._i2k_dev), index, int(key), _hip.current_stream()), "sampler_map_set")
@@ -129,8 +132,7 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         self._sum_tree.set(local, shaped)
 
     def remove(self, key: ReplayItemID) -> None:
-        assert key in self._map.key_to_index, ValueError(f"Key {key} not found.")
-        hole = self._map.key_to_index[key]
+        hole = self._map.key_to_index[key]  # unknown key: KeyError, as the reference's `self._key_to_index[key]` (samplers.py:90)
         last = len(self._map) - 1
         # one launch, no host read: the last entry's priority moves into the hole by the two-leaf set
         # {hole: leaf[last], last: 0} (samplers.py:98-102; hole == last: {hole: 0}), its key in the device map
@@ -145,7 +147,7 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         # doubles (the PCG64 stream IS the parity), the device multiplies by the root it holds -- no read of the root first
         before = self._rng_key.bit_generator.state
         u = self._rng_key.random(size)
-        _, keys, root, status = self._sum_tree.query_host(u, scale_by_root=True, index_to_key=self._i2k_dev)
+        _, keys, root, status = self._sum_tree.query_host(u, scale_by_root=True, index_to_key=self._i2k_dev, n_live=len(self._map))
         if root == 0.0:
             # the reference's branch here is `super().sample(size).keys` -> AttributeError (samplers.py:106-108), after
             # drawing `integers` from the generator: replay exactly that on the restored stream
@@ -155,6 +157,8 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         if status & 1:
             raise ValueError(f"Targets must be in the interval [0.0, {root}).")
         assert not (status & 2), "sum tree traversal: target not below its node (sum_tree.py:81)"
+        if status & 4:  # a descent ended on an empty leaf behind the live entries: `self._index_to_key[index]` (samplers.py:114)
+            raise IndexError("list index out of range")
         return keys
 
     def enable_device_map(self, capacity: int) -> None:

@@ -124,10 +124,11 @@ class SumTree:
                                             _hip.current_stream()), "sumtree_query")
         return out
 
-    def query_host(self, values: np.ndarray, scale_by_root: bool = False, index_to_key=None):
+    def query_host(self, values: np.ndarray, scale_by_root: bool = False, index_to_key=None, n_live: int = -1):
         """ONE launch + ONE host read (a polled mailbox in mapped host memory): the leaves of `values` (targets, or --
         scale_by_root -- uniforms in [0, 1) turned into numpy's ``uniform(0, root)`` on the device), the keys
-        ``index_to_key[leaf]`` when a device map is given, the root and the status bits."""
+        ``index_to_key[leaf]`` when a device map is given (``n_live`` = its valid entries: a leaf behind them sets status
+        bit 2 and gets key -1), the root and the status bits."""
         vals = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
         lib = _hip.lib()
         if self._mailbox is None:
@@ -141,7 +142,7 @@ class SumTree:
             n = min(_MAIL_N, vals.size - lo)
             _hip.check(lib.sumtree_query_host(
                 _hip.ptr(self._nodes_dev), self._depth, C.c_void_p(vals[lo:].ctypes.data), n, 1 if scale_by_root else 0,
-                _hip.ptr(index_to_key), self._mailbox, C.c_void_p(leaves[lo:].ctypes.data),
+                _hip.ptr(index_to_key), int(n_live), self._mailbox, C.c_void_p(leaves[lo:].ctypes.data),
                 C.c_void_p(keys[lo:].ctypes.data) if keys is not None else None, C.byref(root), C.byref(status),
                 _hip.current_stream()), "sumtree_query_host")
             st_all |= status.value

@@ -151,6 +151,38 @@ int idqn_finish_step_factored(idqn_handle_t h, const float* a3_all_dev, const fl
 /* Second half of the data-parallel step: Adam from grad_dev, count += 1. */
 int idqn_apply_adam(idqn_handle_t h, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The data-parallel step with its collectives inside the library (RCCL over xGMI, one process per GPU).  No reference
+ * counterpart: iDQN.learn_on_batch (idqn.py:96-109) is single-device; this shards its minibatch mean (idqn.py:111-112).
+ * RCCL is resolved at run time (librccl.so.1), the single-GPU entry points do not depend on it.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct idqn_dp_s* idqn_dp_t;
+#define IDQN_DP_UNIQUE_ID_BYTES 128
+#define IDQN_DP_SIDE_STREAM 1u /* collectives on a stream of the library's own, ordered by events (the all-gather then runs under
+                                  the conv backward); 0: on the caller's stream, in program order, no cross-stream hand-over */
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank (any channel: a file, MPI, torch.distributed). */
+int idqn_dp_unique_id(void* id_out /*[IDQN_DP_UNIQUE_ID_BYTES]*/);
+/* ncclCommInitRank on the calling thread's current device: collective over the `world` ranks of the job. */
+int idqn_dp_create(idqn_handle_t h, const void* unique_id, int32_t rank, int32_t world, uint32_t flags, idqn_dp_t* out);
+/* The same around a communicator the caller already owns (an ncclComm_t passed as void*; not destroyed by idqn_dp_destroy). */
+int idqn_dp_create_from_comm(idqn_handle_t h, void* nccl_comm, uint32_t flags, idqn_dp_t* out);
+int idqn_dp_destroy(idqn_dp_t dp);
+/* rank, world, bytes a rank contributes to the all-gather per 32-sample block of its shard, bytes of the all-reduce (any NULL). */
+int idqn_dp_info(idqn_dp_t dp, int32_t* rank, int32_t* world, int64_t* gather_bytes_per_rank, int64_t* allreduce_bytes);
+/* One global gradient step: this rank's `batch`-sample shard of a global batch of global_batch = world * batch samples.
+ * Enqueues idqn_learn_on_batch(IDQN_F_STOP_BEFORE_DENSE0_WGRAD) -> ncclAllGather of the [dL/dh | a3] run -> conv backward
+ * (idqn_backward_rest) -> ncclAllReduce(sum) of the small-leaf gradient region and the K losses -> the fused Dense_0 update
+ * over the gathered factors -> Adam on every other leaf, count += 1, cum_losses += losses (idqn_finish_step_factored).
+ * Nothing synchronises with the host.  losses_dev then holds the loss of the GLOBAL batch.  flags: IDQN_F_PROFILE(_ALL). */
+int idqn_dp_step(idqn_dp_t dp, const void* state_dev, const void* next_state_dev, const int32_t* action_dev,
+                 const float* reward_dev, const uint8_t* terminal_dev, int32_t batch, int32_t global_batch, uint32_t flags,
+                 void* stream);
+/* Head-parallel chain maintenance (K / world consecutive heads per rank, no per-step collective): one parameter row to /
+ * from a direct neighbour as ncclSend / ncclRecv in one group on the caller's stream; a negative peer skips that half.
+ * T-step shift (idqn.py:13-17,80): send_to = rank - 1, recv_from = rank + 1; D-step sync (idqn.py:20-24,92): the reverse. */
+int idqn_dp_exchange_row(idqn_dp_t dp, const float* send_dev, int32_t send_to, float* recv_dev, int32_t recv_from,
+                         int64_t n_floats, void* stream);
+
 /* iDQN.update_target_params, T-step (idqn.py:78-80): target <- online (a REAL copy; the reference
  * aliases immutable arrays), then online[k] <- online[k+1] for k < K-1.  Adam state is not shifted. */
 int idqn_target_update(idqn_handle_t h, void* stream);
@@ -216,11 +248,13 @@ int sumtree_query(const double* nodes_dev, int32_t depth, const double* targets_
  * (samplers.py:110).  One launch reads them from a mapped host mailbox, descends, maps leaf -> key through
  * index_to_key_dev (int32 [capacity], NULL: keys = leaves) and writes leaves, keys, root and status back; the host polls
  * the mailbox's sequence number -- no device->host copy, no stream synchronisation, no separate read of the root.
- * status: bit 0 a target outside [0, root) (-> ValueError), bit 1 the per-level assert (:81).  root == 0: leaves are 0.  */
+ * status: bit 0 a target outside [0, root) (-> ValueError), bit 1 the per-level assert (:81), bit 2 a leaf >= n_live, the
+ * number of valid entries of index_to_key_dev (-> the reference's IndexError from `_index_to_key[index]`, samplers.py:114;
+ * its key is returned as -1; n_live < 0: not checked).  root == 0: leaves are 0.  */
 int sampler_mailbox_create(int32_t max_n, void** mailbox_out);
 int sampler_mailbox_destroy(void* mailbox);
 int sumtree_query_host(const double* nodes_dev, int32_t depth, const double* values_host, int32_t n,
-                       int32_t scale_by_root, const int32_t* index_to_key_dev, void* mailbox,
+                       int32_t scale_by_root, const int32_t* index_to_key_dev, int32_t n_live, void* mailbox,
                        int32_t* leaves_out_host, int32_t* keys_out_host, double* root_out_host,
                        int32_t* status_out_host, void* stream);
 /* UniformSamplingDistribution's index -> key map on the device (samplers.py:26-49), for callers that keep sampled keys on

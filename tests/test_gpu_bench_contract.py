@@ -42,6 +42,22 @@ def test_default_line_has_the_contract_fields_and_consistent_arithmetic():
     assert {"gather_B32", "sumtree_B32", "prioritized_protocol"} <= set(d["sampling"])
     names = [k["launch"] for k in d["kernels"]]
     assert any("dense0 wgrad" in n for n in names) and not any("finalize" in n for n in names)  # the pair kernel finishes dL/da3 itself
+    hf = d["heads_fit"]  # the K-independent part of the step as a tracked number
+    assert hf["heads"] == [1, 2, 3, 5] and len(hf["us_per_step"]) == 4 and hf["per_head_us"] > 0 and hf["fixed_us"] > 0
+    assert abs(hf["fixed_us"] + 5 * hf["per_head_us"] - hf["us_per_step"][3]) < 0.15 * hf["us_per_step"][3]
+    assert "traffic" in d["step_roofline"]
+
+
+@pytest.mark.parametrize("flags,K,B", [(("--batch", "256"), 5, 256), (("--heads", "64"), 64, 32)])
+def test_config_4_and_5_single_device_lines(flags, K, B):
+    """BASELINE configs 4 (B = 256 per step) and 5 (K = 64) as kept single-device bench lines with their floors."""
+    d = _bench(*flags, "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline")
+    assert d["config"]["heads"] == K and d["config"]["batch_per_gpu"] == B and f"K={K} batch={B}" in d["metric"]
+    nb = B // 32
+    assert d["roofline"]["algorithmic_bytes"] == K * (6 * 7744 * 512 * 4 + nb * (2 * 7744 * 32 * 4 + 512 * 32 * 4))
+    sr = d["step_roofline"]
+    assert sr["flops"] > 0 and sr["floor_us_mfma_f32"] > 0 and 0 < sr["frac_mfma"] < 1.0
+    assert "sampling" not in d and "heads_fit" not in d  # side legs ride on the headline line only
 
 
 def test_cpu_baseline_object():

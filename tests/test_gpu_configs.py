@@ -180,11 +180,13 @@ def test_hundred_step_drift_against_the_oracle():
     assert drift <= 2 * h["lr"]  # a ReLU that flips near zero moves a weight by a fraction of one update
 
 
-@pytest.mark.parametrize("mode", ["factored", "allreduce"])
+@pytest.mark.parametrize("mode", ["native-side", "native-inline", "factored", "allreduce"])
 def test_rccl_stream_ordering_stress(mode):
     """World-size-1 RCCL, 200 steps of B = 128 (four blocks per rank) per mode: the asynchronous step (collectives on
     RCCL's stream under the conv backward / the fused update) must equal, BIT FOR BIT, the same step with every
-    collective waited for and the device synchronised around it.  A missing stream dependency shows as a difference."""
+    collective waited for and the device synchronised around it.  A missing stream dependency shows as a difference.
+    native-*: the whole schedule issued by ONE C call (idqn_dp_step: the library's own RCCL communicator, collectives on its
+    side stream / on the compute stream) against the serialised Python schedule over torch.distributed -- its oracle."""
     import socket
 
     import torch
@@ -212,13 +214,20 @@ def test_rccl_stream_ordering_stress(mode):
         agents = [iDQN(0, obs, A, K, feats, arch, 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4) for _ in range(2)]
         for s in range(200):
             for agent, serial in zip(agents, (False, True)):
-                data_parallel_step(agent, batches[s % 4], B, mode=mode, serial=serial,
-                                   overlap=None if mode == "factored" else True)
+                if mode.startswith("native"):
+                    data_parallel_step(agent, batches[s % 4], B, mode="factored" if serial else "native", serial=serial,
+                                       streams=mode.split("-")[1])
+                else:
+                    data_parallel_step(agent, batches[s % 4], B, mode=mode, serial=serial,
+                                       overlap=None if mode == "factored" else True)
         torch.cuda.synchronize()
         a, b = agents[0]._online.cpu().numpy(), agents[1]._online.cpu().numpy()
         assert np.isfinite(a).all()
         assert (a.view(np.uint32) == b.view(np.uint32)).all(), int((a.view(np.uint32) != b.view(np.uint32)).sum())
         assert (agents[0]._mu.cpu().numpy().view(np.uint32) == agents[1]._mu.cpu().numpy().view(np.uint32)).all()
+        assert (agents[0]._cum.cpu().numpy() == agents[1]._cum.cpu().numpy()).all() and (agents[0]._count == agents[1]._count).all()
+        for ag in agents:  # the library-side communicators go before the process group
+            ag._destroy_handle()
     finally:
         if owns:
             dist.destroy_process_group()

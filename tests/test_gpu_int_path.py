@@ -245,7 +245,7 @@ def test_prioritized_sampler_device_paths_match_the_oracle(capacity, alpha):
             np.testing.assert_array_equal(a._sum_tree._nodes, b.tree.nodes, err_msg=f"op {op}")
             assert list(a._index_to_key) == list(b.index_to_key)
             np.testing.assert_array_equal(a._i2k_dev[: len(live)].cpu().numpy(), np.asarray(b.index_to_key, np.int32))
-    with pytest.raises(AssertionError):
+    with pytest.raises(KeyError):  # the reference's first statement is `self._key_to_index[key]` (samplers.py:90)
         a.remove(10**8)
 
 
@@ -299,3 +299,71 @@ def test_uniform_sampler_device_map_and_device_samples():
         pa.remove(k); pb.remove(k)
     for n in (1, 32, 100):
         np.testing.assert_array_equal(pa.sample_device(n).cpu().numpy(), pb.sample(n))
+
+
+def test_prioritized_sample_past_the_live_entries_is_an_index_error():
+    """A descent that ends on an empty leaf behind the live entries (drift in the node sums; here forced by writing mass
+    into a leaf the map has no key for) is the reference's IndexError from `self._index_to_key[index]` (samplers.py:114) --
+    not a stale key of a removed item read from the device map."""
+    Prioritized = _classes()[2]
+    a = Prioritized(3, 8, 1.0)
+    for k in range(3):
+        a.add(k, priority=0.0)
+    a._sum_tree.set(np.asarray([5], np.int32), np.asarray([2.0]))  # leaf 5 carries all the mass, the map has 3 entries
+    with pytest.raises(IndexError):
+        a.sample(4)
+    _, keys, _, status = a._sum_tree.query_host(np.asarray([0.5]), index_to_key=a._i2k_dev, n_live=3)
+    assert status & 4 and keys[0] == -1
+    leaves, _, _, status = a._sum_tree.query_host(np.asarray([0.5]))  # no map: leaves only, nothing to check
+    assert leaves[0] == 5 and not status & 4
+
+
+def test_uniform_device_map_refuses_adds_past_its_capacity():
+    """enable_device_map(capacity) allocates `capacity` entries: an add past them must fail on the host, not write HBM."""
+    Uniform = _classes()[1]
+    u = Uniform(0)
+    u.enable_device_map(4)
+    for k in range(4):
+        u.add(k)
+    with pytest.raises(IndexError):
+        u.add(4)
+    assert len(u._index_to_key) == 4  # nothing was appended
+    u.remove(1)
+    u.add(9)
+    np.testing.assert_array_equal(u._i2k_dev.cpu().numpy(), np.asarray(u._index_to_key, np.int32))
+
+
+@pytest.mark.parametrize("n,obs_bytes", [(1, 16), (32, 28224), (77, 4100)])
+def test_replay_gather_of_whole_pair_stores(n, obs_bytes):
+    """replay_gather / replay_gather_scalars (stores that keep (state, next_state) pairs per slot; ReplayBuffer.sample's fetch
+    + stack, replay_buffer.py:223-229): plain row gathers, bit-exact against numpy indexing, repeated slots included."""
+    import ctypes as C
+
+    import torch
+
+    from slimdqn import _hip
+
+    rng = np.random.default_rng(n)
+    cap = 50
+    store = torch.from_numpy(rng.integers(0, 256, (cap, 2, obs_bytes), dtype=np.uint8)).cuda()
+    act = torch.from_numpy(rng.integers(0, 18, cap).astype(np.int32)).cuda()
+    rew = torch.from_numpy(rng.standard_normal(cap).astype(np.float32)).cuda()
+    term = torch.from_numpy((rng.random(cap) < 0.3).astype(np.uint8)).cuda()
+    slots_h = rng.integers(0, cap, n).astype(np.int32)
+    slots = torch.from_numpy(slots_h).cuda()
+    s_out = torch.empty((n, obs_bytes), dtype=torch.uint8, device="cuda")
+    s2_out = torch.empty_like(s_out)
+    a_out = torch.empty(n, dtype=torch.int32, device="cuda")
+    r_out = torch.empty(n, dtype=torch.float32, device="cuda")
+    t_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    lib, q = _hip.lib(), _hip.current_stream()
+    _hip.check(lib.replay_gather(_hip.ptr(store), C.c_int64(obs_bytes), _hip.ptr(slots), n, _hip.ptr(s_out), _hip.ptr(s2_out), q), "replay_gather")
+    _hip.check(lib.replay_gather_scalars(_hip.ptr(act), _hip.ptr(rew), _hip.ptr(term), _hip.ptr(slots), n, _hip.ptr(a_out), _hip.ptr(r_out),
+                                         _hip.ptr(t_out), q), "replay_gather_scalars")
+    torch.cuda.synchronize()
+    host = store.cpu().numpy()
+    np.testing.assert_array_equal(s_out.cpu().numpy(), host[slots_h, 0])
+    np.testing.assert_array_equal(s2_out.cpu().numpy(), host[slots_h, 1])
+    np.testing.assert_array_equal(a_out.cpu().numpy(), act.cpu().numpy()[slots_h])
+    np.testing.assert_array_equal(r_out.cpu().numpy().view(np.uint32), rew.cpu().numpy()[slots_h].view(np.uint32))
+    np.testing.assert_array_equal(t_out.cpu().numpy(), term.cpu().numpy()[slots_h])

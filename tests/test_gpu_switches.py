@@ -63,9 +63,24 @@ print("RESULT" + json.dumps({"losses": losses, "acts": acts, "probe": probe}))
 """
 
 
-def _run(**env):
+# Switches the shipped library reads itself; every other IDQN_* switch exists only in the -DIDQN_VARIANTS build
+# (i-dqn_amd/libidqn_hip_variants.so, built by __graft_entry__.build()), which the child then loads through IDQN_HIP_LIB.
+SHIPPED = {"IDQN_STEP_GRAPH", "IDQN_ACT_POLL", "IDQN_ACT_GRAPH", "IDQN_ACT_GENERIC", "IDQN_CONV", "IDQN_CNN_GENERAL",
+           "IDQN_PLAN_PRINT", "IDQN_LOOP_OVERLAP", "IDQN_DP_MODE", "IDQN_DP_OVERLAP"}
+VARIANTS_LIB = os.path.join(ROOT, "i-dqn_amd", "libidqn_hip_variants.so")
+
+
+def _child_env(env):
     e = dict(os.environ)
     e.update(env)
+    if any(k.startswith("IDQN_") and k not in SHIPPED for k in env):
+        assert os.path.exists(VARIANTS_LIB), "run __graft_entry__.build() first: it also builds the variants library"
+        e["IDQN_HIP_LIB"] = VARIANTS_LIB
+    return e
+
+
+def _run(**env):
+    e = _child_env(env)
     out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
@@ -187,8 +202,7 @@ def test_factored_update_contraction_variants_are_bit_identical(ranks):
     IDQN_DP_ALDS=2 the same on 64 x 256 tiles (chunks of 4 blocks); IDQN_DP_ALDS=0 the register version.  Every accumulator
     takes the same products in the same order: bit-identical parameters after 4 emulated N-rank steps."""
     def run(**env):
-        e = dict(os.environ, SW_RANKS=str(ranks))
-        e.update(env)
+        e = _child_env(dict(env, SW_RANKS=str(ranks)))
         out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD_DP], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
@@ -322,7 +336,7 @@ def test_mlp_kernel_variants_agree():
     which one runs is a matter of what fits LDS.  Forced onto the slower ones, the same seeded steps must give the same
     losses and parameters to fp32 round-off (the sums run in another order)."""
     def run(**env):
-        e = dict(os.environ, **env)
+        e = _child_env(env)
         out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FC_CHILD], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
@@ -362,7 +376,7 @@ def test_iqn_gemm_kernels_match_the_per_block_kernels():
     loss bit-identical); the gradients sum in another order and the data gradient moves from the f32 to the split-bf16
     products: parameters agree to fp32 round-off."""
     def run(**env):
-        e = dict(os.environ, **env)
+        e = _child_env(env)
         out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + IQN_CHILD], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])

@@ -42,7 +42,13 @@ dom = [k for k in out if "k_dense0_wgrad_pair" in k] or [k for k in out if "k_de
 if dom:
     import subprocess
     git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    # HBM bytes of ALL launches of one step: every step kernel's mean bytes x its launches per step (the dominant kernel runs
+    # once per step; acting / sampling kernels of the bench's side legs are not step kernels)
+    steps = out[dom[0]]["launches"]
+    step_kernels = {k: e for k, e in out.items() if "hbm_bytes" in e and not any(x in k for x in ("k_act_", "k_sumtree", "k_replay", "k_per_", "k_sampler", "k_argmax"))}
+    step_bytes = sum(e["hbm_bytes"] * e["launches"] / steps for e in step_kernels.values())
     json.dump({"kernel": dom[0], "git": git, "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
+               "step_hbm_bytes": step_bytes, "step_kernels": {k: round(e["hbm_bytes"] * e["launches"] / steps) for k, e in sorted(step_kernels.items())},
                "read": out[dom[0]]["hbm_read_bytes"], "write": out[dom[0]]["hbm_write_bytes"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md)"},
