@@ -335,6 +335,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="profiling runs (rocprofv3 --pmc / --kernel-trace): nothing but the warm-up and the timed steps of THIS "
+                         "configuration touches the GPU -- no per-launch event table, no sampling leg, no K-sweep")
     ap.add_argument("--heads-per-gpu", type=int, default=0,
                     help="head-parallel mode (BASELINE config 5, not the headline metric): K = this x gpus heads, every "
                          "rank steps its own window of heads on the same minibatch, no per-step collective; a T-step "
@@ -498,7 +501,7 @@ def main():
     _hip.check(_hip.lib().idqn_profile_read(agent._handle, C.byref(mean_ms), C.byref(n_l), name), "idqn_profile_read")
     # per-launch table: a short extra run (outside the timed regions) with one hipEvent behind every launch
     kernels = []
-    if not dp:
+    if not dp and not args.no_side_legs:
         for _ in range(60):
             step(_hip.F_PROFILE_ALL)
         torch.cuda.synchronize()
@@ -580,7 +583,7 @@ def main():
         }
         if dp:
             out["rccl"] = rccl_report(dp_mode, world, agent, args.dp_streams or os.environ.get("IDQN_DP_STREAMS", "side"))
-        if headline and not dp:
+        if headline and not dp and not args.no_side_legs:
             try:
                 out["sampling"] = sampling_leg()
             except Exception as e:  # noqa: BLE001 -- the headline line must not depend on this leg

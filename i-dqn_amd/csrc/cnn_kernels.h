@@ -348,11 +348,13 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 // MFMA chain (704 x 64 cycles per wave on < 1 wave per SIMD: 4.1 TB/s); this one by HBM and the split's VALU work.
 __device__ __forceinline__ bf16x8 planes8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, (u32x4){p[0], p[1], p[2], p[3]}); }
 
-__global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
+template <int RING, bool PLAIN = true, int ABL = 0, bool XW = false>  // XW: the k-step's 2 KB of activations as two 16-byte loads per lane, turned round in wave-private LDS; ABL (timing ablations, WRONG results): 1 no activation loads, 2 no partial stores, 4 no split / products, 8 four k-steps requested at once; RING: k-steps of W / activation rows in flight per lane (4: one wave per SIMD; 3: two);
+__device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PLAIN: the compiler's own order of split and products (A/B)
     extern __shared__ __attribute__((aligned(16))) float d3_red[];  // G == 4: [wave][tile q][register r][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
     long item = (long)blockIdx.x * 4 + wave;
     int jt, s;
+#ifdef IDQN_VARIANTS
     if (a.G == 4) {  // workgroup = (net, block, group of 4 splits, column tile); wave = split inside the group
         item = (long)blockIdx.x;
         if (item * 4 >= a.n_items) return;
@@ -361,7 +363,9 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
         const int nsg = a.NS / 4;
         s = (int)(item % nsg) * 4 + wave;
         item /= nsg;
-    } else {
+    } else
+#endif
+    {
         if (item >= a.n_items) return;
         jt = (int)(item % a.n_jt);
         item /= a.n_jt;
@@ -387,14 +391,53 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     // a ring of four k-steps of W / activation rows per lane (32 KB of loads in flight per wave: with less than one wave
     // per SIMD the kernel was bound by how many bytes it kept in flight, not by HBM or the matrix cores)
-    float4 wv[4][8];
-    float xv[4][8];
+    float4 wv[RING][8];
+    float xv[RING][8];
+    // XW: a k-step's 16 activation rows are 2 KB contiguous; lane l takes bytes [16 l, 16 l + 16) of each KB (two coalesced 1 KB
+    // loads instead of eight 256-byte ones: timing ablations put 2.9 of the kernel's 36 us on those eight, profiles/r5_d0fwd_ablations.txt)
+    // and the wave turns them round through its own 2 KB of LDS into the MFMA's k-major operand
+    __shared__ __attribute__((aligned(16))) float d3_xs[XW ? 4 * 512 : 4];
+    f32x4v xq0[RING], xq1[RING];
+    const float* XQ = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(16 * s) * 32 + 4 * lane;
+    float* const xs_w = d3_xs + (XW ? wave * 512 : 0);
 #define D3_LOAD(c, s)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
         wv[s][jj] = ld4<D0_FWD_NT != 0>(W + ((long)(c) * step_rows + jj) * a.J);                      \
-        xv[s][jj] = X[((long)(c) * step_rows + jj) * 32];                                             \
+        if (XW) { if (jj == 0) xq0[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32);          \
+                  if (jj == 1) xq1[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32 + 256); }  \
+        else if (!(ABL & 1)) xv[s][jj] = X[((long)(c) * step_rows + jj) * 32]; else xv[s][jj] = 1.0f;  \
     }
-#define D3_TILE(s, q, comp)                                                                    \
+#define D3_GETX(s)                                                                             \
+    float xr[8];                                                                               \
+    if (XW) {                                                                                  \
+        *reinterpret_cast<f32x4v*>(xs_w + 4 * lane) = xq0[s];                                  \
+        *reinterpret_cast<f32x4v*>(xs_w + 256 + 4 * lane) = xq1[s];                            \
+        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xr[jj] = xs_w[(8 * h + jj) * 32 + bl]; \
+    } else {                                                                                   \
+        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xr[jj] = xv[s][jj];                   \
+    }
+// One k-step: the three planes of the activations, then per column tile q six products.  hipcc leaves each tile's six MFMAs back
+// to back behind its 44-instruction split (rocprofv3 --pmc, profiles/r5_d0fwd_pmc_vs_reader.txt: a wave spent 33 % of its cycles
+// issuing VALU and another 32 % stalled at MFMA issue, against 9 % + 1 % for a plain reader of the same bytes in the same
+// shape), so the split of tile q + 1 is threaded by hand into the gaps between the products of tile q (one operand pair per gap,
+// order pinned by sched_barrier): the matrix pipe runs under the vector work instead of after it.
+#define D3_PAIR(P, s, m, comp) split3_pk(wv[s][2 * (m)].comp, wv[s][2 * (m) + 1].comp, P##0[m], P##1[m], P##2[m]);
+#define D3_SB __builtin_amdgcn_sched_barrier(0);
+#define D3_TILE(s, q, A, B, ncomp, HAS_NEXT)                                                   \
+    {                                                                                          \
+        const bf16x8 w0 = planes8(A##0), w1 = planes8(A##1), w2 = planes8(A##2);               \
+        D3_SB acc[q] = mfma_bf16(w2, x0, acc[q]); D3_SB                                        \
+        if (HAS_NEXT) { D3_PAIR(B, s, 0, ncomp) } D3_SB                                        \
+        acc[q] = mfma_bf16(w0, x2, acc[q]); D3_SB                                              \
+        if (HAS_NEXT) { D3_PAIR(B, s, 1, ncomp) } D3_SB                                        \
+        acc[q] = mfma_bf16(w1, x1, acc[q]); D3_SB                                              \
+        if (HAS_NEXT) { D3_PAIR(B, s, 2, ncomp) } D3_SB                                        \
+        acc[q] = mfma_bf16(w1, x0, acc[q]); D3_SB                                              \
+        if (HAS_NEXT) { D3_PAIR(B, s, 3, ncomp) } D3_SB                                        \
+        acc[q] = mfma_bf16(w0, x1, acc[q]);                                                    \
+        acc[q] = mfma_bf16(w0, x0, acc[q]); D3_SB                                              \
+    }
+#define D3_TILE_P(s, q, comp)                                                                  \
     {                                                                                          \
         unsigned p0[4], p1[4], p2[4];                                                          \
         _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(wv[s][2 * m].comp, wv[s][2 * m + 1].comp, p0[m], p1[m], p2[m]); \
@@ -406,35 +449,61 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
         acc[q] = mfma_bf16(w0, x1, acc[q]);                                                    \
         acc[q] = mfma_bf16(w0, x0, acc[q]);                                                    \
     }
-#define D3_MMA(s)                                                                              \
+#define D3_MMA_P(s)                                                                            \
     {                                                                                          \
         unsigned q0[4], q1[4], q2[4];                                                          \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xv[s][2 * m], xv[s][2 * m + 1], q0[m], q1[m], q2[m]); \
+        D3_GETX(s)                                                                             \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xr[2 * m], xr[2 * m + 1], q0[m], q1[m], q2[m]); \
         const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
-        D3_TILE(s, 0, x) D3_TILE(s, 1, y) D3_TILE(s, 2, z) D3_TILE(s, 3, w)                    \
+        D3_TILE_P(s, 0, x) D3_TILE_P(s, 1, y) D3_TILE_P(s, 2, z) D3_TILE_P(s, 3, w)            \
     }
-#ifdef D3_ABLATE  /* timing experiment: loads only (results are wrong) -- same duration: the kernel is bound by how fast
-                     a CU can stream (~10 B/clk at the clock it holds here), not by its split / MFMA work */
-#undef D3_MMA
-#define D3_MMA(s) { _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) acc[0][0] += wv[s][jj].x + wv[s][jj].y + wv[s][jj].z + wv[s][jj].w + xv[s][jj]; }
-#endif
-#define D3_AHEAD 3
+#define D3_MMA(s)                                                                              \
+    {                                                                                          \
+        unsigned q0[4], q1[4], q2[4], pa0[4], pa1[4], pa2[4], pb0[4], pb1[4], pb2[4];          \
+        D3_GETX(s)                                                                             \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xr[2 * m], xr[2 * m + 1], q0[m], q1[m], q2[m]); \
+        const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) { D3_PAIR(pa, s, m, x) }                 \
+        D3_TILE(s, 0, pa, pb, y, true) D3_TILE(s, 1, pb, pa, z, true)                          \
+        D3_TILE(s, 2, pa, pb, w, true) D3_TILE(s, 3, pb, pa, x, false)                         \
+    }
+#define D3_MMA_A(s) { D3_GETX(s) _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) acc[0][0] += wv[s][jj].x + wv[s][jj].y + wv[s][jj].z + wv[s][jj].w + xr[jj]; }
 #define D3_STEP(u)                                                                             \
-    D3_LOAD(min(c + (u) + D3_AHEAD, NC - 1), ((u) + D3_AHEAD) & 3)                             \
+    D3_LOAD(min(c + (u) + RING - 1, NC - 1), ((u) + RING - 1) % RING)                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if (c + (u) < NC) D3_MMA(u)                                                                \
+    if (c + (u) < NC) { if (ABL & 4) D3_MMA_A(u) else if (PLAIN) D3_MMA_P(u) else D3_MMA(u) }  \
     __builtin_amdgcn_sched_barrier(0);
     D3_LOAD(0, 0)
     D3_LOAD(min(1, NC - 1), 1)
-    D3_LOAD(min(2, NC - 1), 2)
+    if (RING == 4) { D3_LOAD(min(2, NC - 1), 2) }
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < NC; c += 4) {
-        D3_STEP(0) D3_STEP(1) D3_STEP(2) D3_STEP(3)
+    if (ABL & 8) {  // (RING == 4) whole rings at a time: the next four k-steps are requested only when all four slots are free
+        for (int c = 0; c < NC; c += 4) {
+            if (c > 0) { D3_LOAD(min(c, NC - 1), 0) D3_LOAD(min(c + 1, NC - 1), 1) D3_LOAD(min(c + 2, NC - 1), 2) }
+            D3_LOAD(min(c + 3, NC - 1), 3)
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < NC) D3_MMA_P(0)
+            if (c + 1 < NC) D3_MMA_P(1)
+            if (c + 2 < NC) D3_MMA_P(2)
+            if (c + 3 < NC) D3_MMA_P(3)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
+    for (int c = 0; c < NC; c += RING) {
+        D3_STEP(0) D3_STEP(1) D3_STEP(2)
+        if (RING == 4) { D3_STEP(3) }
     }
 #undef D3_STEP
 #undef D3_LOAD
 #undef D3_TILE
+#undef D3_PAIR
+#undef D3_SB
+#undef D3_TILE_P
+#undef D3_MMA_P
+#undef D3_MMA_A
+#undef D3_GETX
 #undef D3_MMA
+#ifdef IDQN_VARIANTS
     if (a.G == 4) {
         // the four splits of the group meet in LDS and are added in split order, ((s0 + s1) + s2) + s3 -- a fixed order, so
         // the step stays bit-reproducible.  Element (tile q, register r, lane) of a wave's accumulators is column
@@ -520,7 +589,15 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
             }
         return;
     }
+#endif
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
+    if (ABL & 2) {  // keep the accumulators alive, store one value per wave
+        float t_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t_ += acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r];
+        if (t_ == 123.456f) P[0] = t_;
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int i = mfma_row(r, h);
@@ -530,8 +607,22 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
         P[(4 * i + 3) * 32] = acc[3][r];
     }
 }
+__global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) { dense0_fwd3_body<4, true>(a); }
 
 #ifdef IDQN_VARIANTS
+// the same with three k-steps in flight per lane at two waves per SIMD (IDQN_D0_OCC2=1 with IDQN_D0_SPLITS=50: two 4-wave
+// workgroups per CU): the experiment behind DESIGN.md section 3.2's "a CU is the unit of streaming bandwidth"
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense0_fwd3o(DenseFwdArgs a) { dense0_fwd3_body<3, true>(a); }
+// ... with the W split of tile q + 1 threaded by hand between the products of tile q (IDQN_D0_FWD_THREAD=1): 40 % fewer issue cycles
+// per k-step, the same duration -- the arithmetic is hidden under the stream either way (profiles/r5_d0fwd_ablations.txt)
+__global__ __launch_bounds__(256) void k_dense0_fwd3t(DenseFwdArgs a) { dense0_fwd3_body<4, false>(a); }
+// timing ablations of the forward inside the step (IDQN_D0_FWD_ABL = 1 / 2 / 4 / 8 / 6 / 7; results are WRONG)
+template <int ABL>
+__global__ __launch_bounds__(256) void k_dense0_fwd3a(DenseFwdArgs a) { dense0_fwd3_body<4, true, ABL>(a); }
+// the plain schedule with the wide activation loads (IDQN_D0_FWD_XW=1), and with the partial stores ablated on top (=2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense0_fwd3x(DenseFwdArgs a) { dense0_fwd3_body<4, true, 0, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense0_fwd3x2(DenseFwdArgs a) { dense0_fwd3_body<4, true, 2, true>(a); }
+
 // k_dense0_fwd3 with the weight stream through LDS-DMA (IDQN_D0_FWD_DMA=1; G = 1 form only).  The register version is bound by how
 // fast a CU streams through global_load_dwordx4 (its loads-only ablation takes the same time); the stand-alone probe
 // (tools/probes/ldsdma_stream_probe.hip) moves the same 158.6 MB at 6.0 - 6.3 TB/s through an LDS-DMA ring against 5.3 TB/s through

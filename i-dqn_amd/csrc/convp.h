@@ -66,6 +66,7 @@ struct CFwdArgs {
     int out_Wp, out_lo_h, out_lo_w, out_W, out_H;  // out_W x out_H: unpadded grid (pb indexing)
     int mask_Wp, mask_lo_h, mask_lo_w, mask_C;
     int f32_W;
+    int tune;  // experiment bits (IDQN_CONV_TUNE, variants build; 0 in the shipped library): 1 early kernel copies, 2 nt epilogue stores, 4 loader priority
     CVar var[4];
 };
 

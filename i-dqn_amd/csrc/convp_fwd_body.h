@@ -106,6 +106,18 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     }
     const CVar& v = a.var[vi];
     const int OW = v.OW, p0 = it.p0, np = it.np;
+    // (tune & 1) the packed kernels of the first stages depend on nothing but the net: requested HERE, before the strip and
+    // tile tables are worked out, so that their round trip runs under the rest of the prologue
+    const bool early_w = !CHAIN && (a.tune & 1) && loader;
+    if (a.tune & 4) { if (loader) __builtin_amdgcn_s_setprio(1); }
+    if (early_w) {
+        const unsigned lds0e = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&lds[0];
+        const unsigned long wb0e = (unsigned long)a.wq + (unsigned long)it.net * a.wq_stride + (unsigned long)v.w_off;
+        const int NSSe = a.KH * a.NCC;
+        for (int s0 = 0; s0 < ring - 1 && s0 < NSSe; ++s0)
+            for (int i = wave; i < NWP; i += 4)
+                dma16((unsigned)lane * 16, wb0e + (unsigned long)s0 * WB + (unsigned long)i * 1024, lds0e + s0 * stage_bytes + i * 1024);
+    }
     const int in_slot = (a.in_split > 0 ? (it.net >= a.in_split ? 1 : 0) : it.net) * a.nb + it.bb;
     const int out_slot = it.net * a.nb + it.bb;
     const unsigned long in_base = (unsigned long)a.in + (unsigned long)in_slot * a.in_slot;
@@ -216,6 +228,8 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
             for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_w(s0, lds0 + s0 * stage_bytes, wave, 4);
             __builtin_amdgcn_s_barrier();  // (B) the acquire behind the poll has completed
             for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_x(s0, lds0 + s0 * stage_bytes, wave, 4);
+        } else if (early_w) {
+            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_x(s0, lds0 + s0 * stage_bytes, wave, 4);
         } else {
             for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
         }
@@ -225,7 +239,7 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
             const long long c0 = prof ? clock64() : 0;
             // (issue order behind a hand-off: kernels 0, kernels 1, pixels 0, pixels 1 -- superstep 0 has landed once at most
             // the pixel copies of superstep 1 are outstanding)
-            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? (waits && ss == 0 ? cnt_x : cnt) : 0);
+            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? ((waits || early_w) && ss == 0 ? cnt_x : cnt) : 0);
             const long long c1 = prof ? clock64() : 0;
             __builtin_amdgcn_s_barrier();  // everybody's copies of ss have landed; nobody still reads the buffer re-filled next
             const long long c2 = prof ? clock64() : 0;
@@ -443,14 +457,18 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
                 for (int j = 0; j < 2; ++j) {
                     const u32x4 x = *LDS_PTR(const u32x4, R + pl * 2048 + j * 1024 + rsw);
                     if (CHAIN && ch->done_flags) store16_sc1(O + (unsigned long)pl * a.CO * 64 + j * 1024, x);  // handed off in-launch
+                    else if (a.tune & 2) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024));
                     else *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = x;
                 }
         }
         if (a.out_f32) {
             float* F = a.out_f32 + (long)out_slot * a.f32_slot + (((long)yh * a.f32_W + yw) * a.CO + ct * 32) * 32 + lane * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(F + j * 256) = *LDS_PTR(const f32x4, R + r_f32 + j * 1024 + fsw);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 x = *LDS_PTR(const f32x4, R + r_f32 + j * 1024 + fsw);
+                if (a.tune & 2) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(F + j * 256));
+                else *reinterpret_cast<f32x4*>(F + j * 256) = x;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next one overwrites it
     }

@@ -34,10 +34,6 @@ struct RcclApi {
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -62,10 +58,6 @@ void load_rccl() {
     RCCL_SYM(CommUserRank, "ncclCommUserRank");
     RCCL_SYM(AllGather, "ncclAllGather");
     RCCL_SYM(AllReduce, "ncclAllReduce");
-    RCCL_SYM(Send, "ncclSend");
-    RCCL_SYM(Recv, "ncclRecv");
-    RCCL_SYM(GroupStart, "ncclGroupStart");
-    RCCL_SYM(GroupEnd, "ncclGroupEnd");
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
 }
@@ -236,22 +228,4 @@ extern "C" int idqn_dp_step(idqn_dp_t dp, const void* state_dev, const void* nex
         return rc;
     if (side) IDQN_HIP_CHECK(hipStreamWaitEvent(q, dp->ev_small, 0));
     return idqn_finish_step_factored(h, a3_all, dh_all, dp->world * nb, nb, n, nb * X, X, n, nb * Y, Y, IDQN_FACTORED_REST, stream);
-}
-
-// Chain maintenance of the head-parallel mode (BASELINE config 5: K / world consecutive heads per rank, no per-step
-// collective): one parameter row to / from a direct neighbour, as RCCL send / recv on the caller's stream.
-//   T-step (idqn.py:78-80, shift): rank g's last head takes the OLD first head of rank g + 1  -> send_to = g - 1, recv_from = g + 1
-//   D-step (idqn.py:20-24, sync):  rank g's first target takes the last head of rank g - 1    -> send_to = g + 1, recv_from = g - 1
-// A negative peer skips that half (the ends of the chain).  Buffers are device pointers of n_floats floats.
-extern "C" int idqn_dp_exchange_row(idqn_dp_t dp, const float* send_dev, int32_t send_to, float* recv_dev, int32_t recv_from,
-                                    int64_t n_floats, void* stream) {
-    IDQN_REQUIRE(dp && n_floats > 0, "idqn_dp_exchange_row: bad arguments");
-    IDQN_REQUIRE(send_to < dp->world && recv_from < dp->world, "idqn_dp_exchange_row: peer out of range");
-    IDQN_REQUIRE((send_to < 0 || send_dev) && (recv_from < 0 || recv_dev), "idqn_dp_exchange_row: null buffer");
-    hipStream_t q = (hipStream_t)stream;
-    IDQN_NCCL_CHECK(g_rccl.GroupStart());
-    if (send_to >= 0) IDQN_NCCL_CHECK(g_rccl.Send(send_dev, (size_t)n_floats, ncclFloat, send_to, dp->comm, q));
-    if (recv_from >= 0) IDQN_NCCL_CHECK(g_rccl.Recv(recv_dev, (size_t)n_floats, ncclFloat, recv_from, dp->comm, q));
-    IDQN_NCCL_CHECK(g_rccl.GroupEnd());
-    return IDQN_OK;
 }

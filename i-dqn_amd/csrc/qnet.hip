@@ -1091,6 +1091,7 @@ int conv_args(idqn_handle_s* h, NetSet& s, int role, int nb, int target, CFwdArg
     if (&s == &h->infer) { a.pbase[0] = a.pbase[1] = h->infer_pbase; a.n_first = 1; }
     else { a.pbase[0] = h->online; a.pbase[1] = h->target; a.n_first = h->cfg.n_heads; }
     a.pstride = h->L.head_stride; a.wq_stride = h->wq_stride; a.nb = nb; a.n_var = g.n_var;
+    { static const int tune = variant_int("IDQN_CONV_TUNE", 0); a.tune = tune; }
     a.KH = g.KH; a.NCC = g.NCC; a.S = g.S; a.SX = g.SX;
     for (int v = 0; v < g.n_var; ++v) a.var[v] = g.var[v];
     const ActGeom* gin;   // input planes
@@ -1384,6 +1385,29 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     } else
 #endif
     if (h->planes) {
+#ifdef IDQN_VARIANTS
+        static const bool occ2 = variant_on("IDQN_D0_OCC2");
+        static const bool thread = variant_on("IDQN_D0_FWD_THREAD");
+        if (occ2 && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3o, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+        else if (thread && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3t, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+        else if (variant_int("IDQN_D0_FWD_XW", 0) && d.G == 1) {
+            if (variant_int("IDQN_D0_FWD_XW", 0) == 2) hipLaunchKernelGGL(k_dense0_fwd3x2, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+            else hipLaunchKernelGGL(k_dense0_fwd3x, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+        }
+        else if (variant_int("IDQN_D0_FWD_ABL", 0) && d.G == 1) {
+            static const int abl = variant_int("IDQN_D0_FWD_ABL", 0);
+            const dim3 g(cdiv(d.n_items, 4));
+            switch (abl) {
+                case 1: hipLaunchKernelGGL(k_dense0_fwd3a<1>, g, dim3(256), 0, q, d); break;
+                case 2: hipLaunchKernelGGL(k_dense0_fwd3a<2>, g, dim3(256), 0, q, d); break;
+                case 4: hipLaunchKernelGGL(k_dense0_fwd3a<4>, g, dim3(256), 0, q, d); break;
+                case 6: hipLaunchKernelGGL(k_dense0_fwd3a<6>, g, dim3(256), 0, q, d); break;
+                case 7: hipLaunchKernelGGL(k_dense0_fwd3a<7>, g, dim3(256), 0, q, d); break;
+                default: hipLaunchKernelGGL(k_dense0_fwd3a<8>, g, dim3(256), 0, q, d); break;
+            }
+        }
+        else
+#endif
         hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
         // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
         // the previous launches leave the memory system in

@@ -60,7 +60,6 @@ SYMBOLS = {
     "idqn_dp_destroy": (C.c_int, [_P]),
     "idqn_dp_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "idqn_dp_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
-    "idqn_dp_exchange_row": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
     "idqn_set_per_buffers": (C.c_int, [_P, _P, _P]),
     "sumtree_set_one": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P]),
     "sampler_mailbox_create": (C.c_int, [C.c_int32, C.POINTER(_P)]),

@@ -177,11 +177,6 @@ int idqn_dp_info(idqn_dp_t dp, int32_t* rank, int32_t* world, int64_t* gather_by
 int idqn_dp_step(idqn_dp_t dp, const void* state_dev, const void* next_state_dev, const int32_t* action_dev,
                  const float* reward_dev, const uint8_t* terminal_dev, int32_t batch, int32_t global_batch, uint32_t flags,
                  void* stream);
-/* Head-parallel chain maintenance (K / world consecutive heads per rank, no per-step collective): one parameter row to /
- * from a direct neighbour as ncclSend / ncclRecv in one group on the caller's stream; a negative peer skips that half.
- * T-step shift (idqn.py:13-17,80): send_to = rank - 1, recv_from = rank + 1; D-step sync (idqn.py:20-24,92): the reverse. */
-int idqn_dp_exchange_row(idqn_dp_t dp, const float* send_dev, int32_t send_to, float* recv_dev, int32_t recv_from,
-                         int64_t n_floats, void* stream);
 
 /* iDQN.update_target_params, T-step (idqn.py:78-80): target <- online (a REAL copy; the reference
  * aliases immutable arrays), then online[k] <- online[k+1] for k < K-1.  Adam state is not shifted. */

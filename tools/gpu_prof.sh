@@ -1,7 +1,7 @@
 # kernel-time profile of the bench step (rocprofv3 --kernel-trace --stats); prints per-kernel averages
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-cur}
-rm -rf gpurun_out/prof_$tag; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
+rm -rf gpurun_out/prof_$tag; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-side-legs > gpurun_out/prof_$tag.log 2>&1
 python - $tag <<'PY'
 import csv,glob,sys,shutil
 tag=sys.argv[1]
