@@ -278,6 +278,7 @@ struct DenseFwdArgs {
     float* qpart;       // [n_nets][nb][J / 32][32][32]
     long b0_off, w1_off;
     int A;
+    int bb_inner;  // k_dense0_fwd3: the sample block is the FASTEST index of the work item (B > 32)
 };
 
 __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 // MFMA chain (704 x 64 cycles per wave on < 1 wave per SIMD: 4.1 TB/s); this one by HBM and the split's VALU work.
 __device__ __forceinline__ bf16x8 planes8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, (u32x4){p[0], p[1], p[2], p[3]}); }
 
-template <int RING, bool PLAIN = true, int ABL = 0, bool XW = false>  // XW: the k-step's 2 KB of activations as two 16-byte loads per lane, turned round in wave-private LDS; ABL (timing ablations, WRONG results): 1 no activation loads, 2 no partial stores, 4 no split / products, 8 four k-steps requested at once; RING: k-steps of W / activation rows in flight per lane (4: one wave per SIMD; 3: two);
+template <int RING, bool PLAIN = true, int ABL = 0, bool XW = false, bool WNT = (D0_FWD_NT != 0)>  // XW: the k-step's 2 KB of activations as two 16-byte loads per lane, turned round in wave-private LDS; ABL (timing ablations, WRONG results): 1 no activation loads, 2 no partial stores, 4 no split / products, 8 four k-steps requested at once; RING: k-steps of W / activation rows in flight per lane (4: one wave per SIMD; 3: two);
 __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PLAIN: the compiler's own order of split and products (A/B)
     extern __shared__ __attribute__((aligned(16))) float d3_red[];  // G == 4: [wave][tile q][register r][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
@@ -367,13 +368,28 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
 #endif
     {
         if (item >= a.n_items) return;
+    }
+    int bb, n;
+    if (a.bb_inner) {
+        // several sample blocks (B > 32): the blocks of one (net, split, column tile) are NEIGHBOURING waves -- they read the same
+        // window of W at the same time, so it comes from HBM once and from L1 / L2 for the others (default-policy loads), instead of
+        // once per block as with the block as the slow index (B = 256: 268 -> see profiles/r5_b256_*.txt)
+        bb = (int)(item % a.nb);
+        item /= a.nb;
         jt = (int)(item % a.n_jt);
         item /= a.n_jt;
         s = (int)(item % a.NS);
-        item /= a.NS;
+        n = ((int)(item / a.NS) + a.net_rot) % a.n_nets;
+    } else {
+        if (a.G != 4) {
+            jt = (int)(item % a.n_jt);
+            item /= a.n_jt;
+            s = (int)(item % a.NS);
+            item /= a.NS;
+        }
+        bb = (int)(item % a.nb);
+        n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
     }
-    const int bb = (int)(item % a.nb);
-    const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
     // INTERLEAVED split-K: split s takes the 16-row k-steps s, s + NS, s + 2 NS, ...  The NS workgroups of a net then
     // read one contiguous NS x 32 KB window of the kernel at any time, like a grid-stride copy does (6.1-6.4 TB/s for a
     // pure read, tools/probes/read_bw_probe.hip); with a contiguous row range per split the chip ran 250 separate
@@ -402,7 +418,7 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
     float* const xs_w = d3_xs + (XW ? wave * 512 : 0);
 #define D3_LOAD(c, s)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
-        wv[s][jj] = ld4<D0_FWD_NT != 0>(W + ((long)(c) * step_rows + jj) * a.J);                      \
+        wv[s][jj] = ld4<WNT>(W + ((long)(c) * step_rows + jj) * a.J);                                    \
         if (XW) { if (jj == 0) xq0[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32);          \
                   if (jj == 1) xq1[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32 + 256); }  \
         else if (!(ABL & 1)) xv[s][jj] = X[((long)(c) * step_rows + jj) * 32]; else xv[s][jj] = 1.0f;  \
@@ -608,6 +624,9 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
     }
 }
 __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) { dense0_fwd3_body<4, true>(a); }
+// several sample blocks per net: block-inner work items, default-policy W loads (the neighbours' re-reads hit on-chip)
+// -- and the threaded split: with every window of W serving several blocks the waves are bound by their own issue, not by the stream
+__global__ __launch_bounds__(256) void k_dense0_fwd3b(DenseFwdArgs a) { dense0_fwd3_body<4, false, 0, false, false>(a); }
 
 #ifdef IDQN_VARIANTS
 // the same with three k-steps in flight per lane at two waves per SIMD (IDQN_D0_OCC2=1 with IDQN_D0_SPLITS=50: two 4-wave

@@ -377,6 +377,14 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
     h->tl_name[h->tl_used++] = name;
 }
 
+// k-splits of the Dense_0 forward of `n_nets` nets x `nb` sample blocks: as many 4-wave workgroups as CUs, never more (a 257th
+// would stream alone after the others), with balanced splits of the F / 32 row units (cnn_setup has the reasoning)
+int d0_splits(const idqn_handle_s* h, int n_nets, int nb) {
+    static const int forced = variant_int("IDQN_D0_SPLITS", 0);
+    const int ns = forced > 0 ? forced : 256 * 4 / std::max(1, n_nets * nb * (h->J / 128));
+    return std::max(1, std::min(std::min(ns, 64), h->F / 32));
+}
+
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
@@ -419,7 +427,10 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
         s.a3 = base + front;
         h->dbg.push_back({t + "a3", {(void*)s.a3, n_a3 * 4}});
     }
-    if ((rc = alloc_zero(&s.part, (long)n_nets * nb * s.NS * h->J * 32, h, (t + "part").c_str()))) return rc;
+    long slabs = (long)nb * s.NS;  // the training set picks its splits per call (fewer, longer ones for more blocks): room for the largest
+    if (&s == &h->train)
+        for (int b = 1; b <= nb; ++b) slabs = std::max(slabs, (long)b * d0_splits(h, n_nets, b));
+    if ((rc = alloc_zero(&s.part, (long)n_nets * slabs * h->J * 32, h, (t + "part").c_str()))) return rc;
     return IDQN_OK;
 }
 
@@ -1351,9 +1362,12 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
+    if (&s == &h->train && s.G == 1 && nb > 1) s.NS = d0_splits(h, s.n_nets, nb);  // (nb == 1: the value cnn_setup chose)
+    else if (&s == &h->train && s.G == 1) s.NS = h->NS;
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
+    d.bb_inner = (h->planes && s.G == 1 && nb > 1) ? 1 : 0;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
     d.G = h->planes ? s.G : 1;
@@ -1408,7 +1422,8 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         }
         else
 #endif
-        hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
+        if (d.bb_inner) hipLaunchKernelGGL(k_dense0_fwd3b, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
+        else hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
         // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
         // the previous launches leave the memory system in
         static const bool twice = variant_on("IDQN_D0_FWD_TWICE");
@@ -1699,7 +1714,13 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // computed INSIDE the weight-gradient + Adam kernel (theta streams once) and finished by k_da3_finalize; the two-call
     // paths of the data-parallel step need it before the weight gradient and keep the separate kernel.
     static const bool no_fuse_dg = variant_env("IDQN_NO_FUSE_DGRAD") != nullptr;
-    const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg;
+    // Several sample blocks on ONE device (B > 32): the schedule of the factored data-parallel step without its collectives -- the
+    // data gradient as its own launch, the factors split once into bf16 planes, the update contracting them at the bf16 MFMA rate
+    // (k_dense0_wgrad_alds) -- instead of the fused kernel's f32 MFMAs over every block (IDQN_NB_FUSED=1: that kernel; B = 256:
+    // profiles/r5_b256_ab.txt)
+    static const bool nb_fused = variant_on("IDQN_NB_FUSED");
+    const bool many = nb >= 3 && h->planes && h->J % 256 == 0 && !nb_fused;  // (two blocks: the same either way, 0.5065 against 0.5085 ms)
+    const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg && !many;
     if (!fuse_dg) {
         DenseDgradArgs dd;
         dd.dh = dh_of(h, nb); dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
@@ -2120,7 +2141,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
-    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0;
+    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
     static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
