@@ -1,4 +1,5 @@
 # conv launch plans and per-launch times when the conv launches are planned for fewer CUs (IDQN_CUS)
+export IDQN_HIP_LIB=${IDQN_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/i-dqn_amd/libidqn_hip_variants.so}  # the switches below exist in the variants build only
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for cus in "$@"; do
   echo "== IDQN_CUS=$cus"

@@ -1,3 +1,4 @@
+export IDQN_HIP_LIB=${IDQN_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/i-dqn_amd/libidqn_hip_variants.so}  # the switches below exist in the variants build only
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"; mkdir -p gpurun_out/twice
 IDQN_D0_FWD_TWICE=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/twice -o tw -- python3 bench.py --steps 100 --warmup 20 --repeats 1 --no-cpu-baseline > gpurun_out/twice/b.json 2> gpurun_out/twice/b.err || exit 1
 python3 - <<'PY'

@@ -1,5 +1,6 @@
 # A/B of the factored data-parallel update's contraction on ONE box: bench.py --emulate-ranks N under IDQN_DP_ALDS = 0 (registers),
 # 1 (a3 fragments through LDS, 32 x 256 tiles), 2 (the same on 64 x 256 tiles); prints step time and final losses (bit-identical)
+export IDQN_HIP_LIB=${IDQN_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/i-dqn_amd/libidqn_hip_variants.so}  # the switches below exist in the variants build only
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 run() { # label, N, env...
   lbl="$1"; n="$2"; shift 2

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the i-IQN bench line under a list of environment settings ("A=1 B=2" per argument; "" = defaults): step time + the big launches
+export IDQN_HIP_LIB=${IDQN_HIP_LIB:-${GRAFT_REPO_ROOT:-$PWD}/i-dqn_amd/libidqn_hip_variants.so}  # the switches below exist in the variants build only
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" && mkdir -p gpurun_out
 i=0
 for e in "$@"; do

@@ -1,6 +1,8 @@
 """Timeline of the chained forward conv launch (IDQN_CONV_PROF=10): per layer, when its items start and end relative to the
 launch (100 MHz wall clock), the shader cycles of each phase, and what an item spends polling its producers' flags."""
 import os
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_variants.so"))  # variants build: the stamps / switches used here
+import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

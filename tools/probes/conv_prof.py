@@ -1,6 +1,8 @@
 """Phase timing inside one plane conv launch (IDQN_CONV_PROF=role): medians over workgroups of the shader-clock cycles
 spent in the prologue, the first fill, the superstep loop (and waiting inside it) and the epilogue."""
 import os
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_variants.so"))  # variants build: the stamps / switches used here
+import os
 import sys
 
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),

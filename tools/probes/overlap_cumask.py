@@ -12,6 +12,8 @@ conv launches planned for IDQN_CUS = 256 - n_b workgroups.  Modes:
    include/idqn_hip.h declares)
 usage: python tools/probes/overlap_cumask.py <n_b> <pattern: low|stride|none> [steps]
 """
+import os
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_variants.so"))  # variants build: the stamps / switches used here
 import ctypes as C
 import os
 import sys
