@@ -1211,13 +1211,14 @@ struct SplitFactorsArgs {
     const float *a3, *dh;
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, F, J;
-    unsigned short *a3p, *dhp;
+    unsigned short *a3p, *dhp;  // a3p == nullptr: dh only
 };
 __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     const int slot = blockIdx.y, bb = slot / a.K, k = slot - bb * a.K;
     const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
     const long na = (long)a.F * 4, nd = (long)a.J * 4;  // pairs of float4 per (block, head): 16-byte stores per plane
     long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (!a.a3p) e += na;  // dh only: the update kernel splits its a3 tiles itself (dense0_update.h, ALDS) and the grid covers J rows
     const float* src;
     unsigned short* dst;
     long plane;
@@ -1276,7 +1277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
 template <int RT>  // 32 * RT rows x 256 columns
-__global__ __launch_bounds__(256) void k_dense0_wgrad_alds(DenseWgradArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 3 : 2))) void k_dense0_wgrad_alds(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(1024))) float gs[RT == 1 ? 32 * 256 + 4096 : 64 * 256];
     d0_stagger(a.stagger);
     dense0_wgrad_body<true, 2, false, true, RT, false, true>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);

@@ -1536,7 +1536,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         sa.dh_outer = dh_outer; sa.dh_head = dh_head; sa.dh_inner = dh_inner;
         sa.K = K; sa.nb = nb_total; sa.nb_inner = nb_inner; sa.F = h->F; sa.J = h->J;
         sa.a3p = h->fact_planes; sa.dhp = h->fact_planes + (long)3 * nb_total * K * h->F * 32;
-        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)(h->F + h->J) * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
+        // The default update kernel (k_dense0_wgrad_alds<1>) splits its a3 tiles itself, straight from the gathered f32 factors:
+        // only dL/dh (6 % of the factor bytes) goes through the plane copy.  IDQN_DP_A3_PLANES=1 (variants): a3 planes as in round 4.
+        static const bool a3_planes = variant_on("IDQN_DP_A3_PLANES");
+        static const int alds_m = variant_int("IDQN_DP_ALDS", 1);
+        static const bool t64 = variant_on("IDQN_DP_TILE64");
+        const bool a3_in_kernel = !a3_planes && alds_m == 1 && !t64;
+        if (a3_in_kernel) sa.a3p = nullptr;
+        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)((a3_in_kernel ? 0 : h->F) + h->J) * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
         tl_mark(h, q, "factor planes");
         dw.a3p = sa.a3p; dw.dhp = sa.dhp;
     }
