@@ -166,6 +166,7 @@ int idqn_dp_unique_id(void* id_out /*[IDQN_DP_UNIQUE_ID_BYTES]*/);
 int idqn_dp_create(idqn_handle_t h, const void* unique_id, int32_t rank, int32_t world, uint32_t flags, idqn_dp_t* out);
 /* The same around a communicator the caller already owns (an ncclComm_t passed as void*; not destroyed by idqn_dp_destroy). */
 int idqn_dp_create_from_comm(idqn_handle_t h, void* nccl_comm, uint32_t flags, idqn_dp_t* out);
+/* Destroys the step object (and the communicator idqn_dp_create made).  Call it BEFORE idqn_destroy of the handle it was built on. */
 int idqn_dp_destroy(idqn_dp_t dp);
 /* rank, world, bytes a rank contributes to the all-gather per 32-sample block of its shard, bytes of the all-reduce (any NULL). */
 int idqn_dp_info(idqn_dp_t dp, int32_t* rank, int32_t* world, int64_t* gather_bytes_per_rank, int64_t* allreduce_bytes);
