@@ -519,6 +519,8 @@ def main():
             kernels.append({"launch": nm, "us": float(us), "n": int(cnt)})
     losses = agent._losses.cpu().numpy()
     assert np.isfinite(losses).all(), losses
+    if dp_mode == "native" and getattr(agent, "_native_dp_failed", False):
+        dp_mode = "factored"  # (the library's communicator did not come up on every rank: parallel.py ran its Python schedule)
     if rank == 0:
         P_w0 = 7744 * 512
         fused = dp_mode != "allreduce"

@@ -106,9 +106,21 @@ def _native_handle(agent, group, streams=None):
     flags = _hip.DP_SIDE_STREAM if streams == "side" else 0
     h = C.c_void_p()
     torch.cuda.synchronize()
-    _hip.check(lib.idqn_dp_create(agent._handle, box[0], rank, world, flags, C.byref(h)), "idqn_dp_create")
+    rc = lib.idqn_dp_create(agent._handle, box[0], rank, world, flags, C.byref(h))
+    # every rank has to agree on the outcome: a communicator that came up on some ranks only would hang the first collective
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=agent._grad.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        msg = lib.idqn_last_error().decode(errors="replace") if rc else "another rank failed"
+        if rc == 0:
+            lib.idqn_dp_destroy(h)
+        raise _NativeUnavailable(f"idqn_dp_create: {msg}")
     agent._dp = (h, agent._handle.value)
     return h
+
+
+class _NativeUnavailable(RuntimeError):
+    """The library-side RCCL communicator could not be created on every rank (the Python schedule over torch.distributed runs instead)."""
 
 
 def _native_step(agent, shard, global_batch, group, extra_flags, streams=None):
@@ -125,8 +137,14 @@ def data_parallel_step(agent, shard, global_batch: int, group=None, extra_flags:
     if mode is None:
         rccl = on_gpu_cnn and dist.get_backend(group) == "nccl"  # one rank per GPU: the library's own communicator works
         mode = os.environ.get("IDQN_DP_MODE", "native" if rccl else "factored")
-    if mode == "native" and on_gpu_cnn and overlap is None and not serial:
-        return _native_step(agent, shard, global_batch, group, extra_flags, streams)
+    if mode == "native" and on_gpu_cnn and overlap is None and not serial and not getattr(agent, "_native_dp_failed", False):
+        try:
+            return _native_step(agent, shard, global_batch, group, extra_flags, streams)
+        except _NativeUnavailable as e:  # agreed on by all ranks (see _native_handle): the same HIP kernels, collectives issued from Python
+            import sys
+
+            agent._native_dp_failed = True
+            print(f"[idqn] native data-parallel step unavailable ({e}); using the Python schedule over torch.distributed", file=sys.stderr, flush=True)
     if mode == "native":
         mode = "factored"
     if mode == "factored" and on_gpu_cnn and overlap is None:
