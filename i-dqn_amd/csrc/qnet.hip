@@ -1728,6 +1728,24 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     static const bool nb_fused = variant_on("IDQN_NB_FUSED");
     const bool many = nb >= 3 && h->planes && h->J % 256 == 0 && !nb_fused;  // (two blocks: the same either way, 0.5065 against 0.5085 ms)
     const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg && !many;
+    // eight (or a multiple of eight) local sample blocks: the data gradient as the tiled bf16x3 GEMM the i-IQN heads use for their
+    // fraction blocks (csrc/iqn_gemm.h: W read once per group of 8 blocks, products at the bf16 rate) + the finalize launch for the
+    // ReLU mask / planes / per-position sums, instead of one f32-MFMA pass over W per block (IDQN_NB_DGRAD_F32=1: that kernel)
+    static const bool nb_dgrad_f32 = variant_on("IDQN_NB_DGRAD_F32");
+    if (!fuse_dg && many && nb % 8 == 0 && h->dpart && h->J % 16 == 0 && !nb_dgrad_f32) {
+        IqnD0DgradArgs g;
+        g.dh = dh_of(h, nb); g.wbase = s.wbase; g.dx = h->dpart; g.w_off = h->off_w0; g.K = K; g.nb = nb; g.F = h->F; g.J = h->J;
+        const size_t lds = 2 * (size_t)IG_STAGE;
+        static LdsAttrMark attr;
+        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3((unsigned)(K * (nb / 8) * cdiv(h->F, 256))), dim3(512), lds, q, g);
+        tl_mark(h, q, "dense0 dgrad (tiled GEMM)");
+        Da3FinalizeArgs fa;
+        fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
+        fa.n_rows = (long)K * nb * h->F; fa.n_jt = 1; fa.F = h->F; fa.C = c2->CO; fa.K = K; fa.nb = nb; fa.g = h->gda3;
+        hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
+        tl_mark(h, q, "da3 finalize (sum, mask, planes)");
+    } else
     if (!fuse_dg) {
         DenseDgradArgs dd;
         dd.dh = dh_of(h, nb); dd.a3 = s.a3; dd.da3 = h->da3; dd.da3p = h->da3p; dd.pb = h->pbuf[2]; dd.wbase = s.wbase; dd.w_off = h->off_w0;
