@@ -387,6 +387,46 @@ def test_ragged_batches_and_shapes_against_oracle(arch, obs, feats, A, K, B, con
         assert np.abs(got[leaf] - want[leaf]).max() <= 2e-5, leaf
 
 
+@pytest.mark.parametrize("feats,K,B", [
+    ([32, 64, 64, 256], 2, 100),   # four blocks, the last one ragged: separate data gradient + factored bf16x3 update
+    ([32, 64, 64, 512], 2, 250),   # eight blocks, the last one ragged: data gradient as the tiled GEMM + finalize
+    ([32, 32, 64, 512], 1, 512),   # sixteen blocks = two groups of eight
+])
+def test_many_block_step_against_oracle(feats, K, B, conv_mode):
+    """The route single-device steps of three or more 32-sample blocks take (block-inner Dense_0 forward, data gradient as its own
+    launch -- the tiled GEMM for groups of eight blocks --, factors split once, bf16x3 update with Adam fused): ONE full
+    `learn_on_batch` against the fp64 oracle, ragged last blocks included."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.idqn import iDQN
+
+    arch, obs, A = "cnn", (20, 20, 4), 5
+    p = Q.init_params(13, arch, obs, A, feats, K)
+    pt = Q.init_params(14, arch, obs, A, feats, K)
+    rng = np.random.default_rng(15)
+    for n in p:
+        if n.endswith("bias"):
+            p[n] = (0.05 * rng.standard_normal(p[n].shape)).astype(np.float32)
+    batch = list(Q.synthetic_batch(16, B, obs, A, arch))
+    batch[4][B // 3] = True
+    agent = iDQN(0, obs, A, K, feats, arch, 1e-3, 0.97, 3, 1, 10**9, 10**9, adam_eps=1e-6)
+    agent._load_flat(agent._online, p)
+    agent._load_flat(agent._target, pt)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    losses = agent._learn(Batch(*batch)).cpu().numpy()
+    gamma_n = 0.97 ** 3
+    zeros = {n: np.zeros(v.shape, np.float64) for n, v in p.items()}
+    want, _, _, _, want_losses = Q.learn_on_batch({n: v.astype(np.float64) for n, v in p.items()}, pt, zeros, zeros,
+                                                  np.zeros(K, np.int64), tuple(batch), arch, gamma_n, 1e-3, 1e-6)
+    assert np.abs(losses - np.asarray(want_losses)).max() <= LOSS_ATOL, (losses, want_losses)
+    got = agent._flat(agent._online)
+    for leaf in want:
+        err = np.abs(got[leaf] - want[leaf])
+        # (first Adam step: every element moves by ~lr; an element whose gradient is ~eps amplifies the fp32 gradient error)
+        assert err.max() <= 2e-5 and (err <= 3e-7).mean() >= 0.98, (leaf, err.max(), (err <= 3e-7).mean())
+
+
 def test_dqn_cnn_and_many_heads():
     """K = 1 without the head axis on the cnn, and K = 12 (more nets than the Atari config) in one launch set."""
     from collections import namedtuple
