@@ -102,13 +102,14 @@ int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_l
 
 }  // namespace
 
-// The pairs that are built: the Nature-CNN widths [32, 64, 64] at the tile counts a K = 5, one-batch-block plan gives
-//   Conv_2 data gradient <3, 2, 3, NT 3>  beside  Conv_2 weight gradient <3, 2, NTW 3, PG 2>
-//   Conv_1 data gradient <3, 1, 2, NT 4>  beside  Conv_1 weight gradient <3, 2, NTW 2, PG 2>
+// The pairs that are built: the Nature-CNN widths [32, 64, 64] at the tile counts one-batch-block plans give (K = 5: NT 3 / NT 4;
+// fewer heads: fewer tiles per wave, down to NT 1 for plain DQN)
+//   Conv_2 data gradient <3, 2, 3, NT 1..3>  beside  Conv_2 weight gradient <3, 2, NTW 3, PG 2>
+//   Conv_1 data gradient <3, 1, 2, NT 1..4>  beside  Conv_1 weight gradient <3, 2, NTW 2, PG 2>
 // anything else runs as two launches.
 bool convp_pair_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG) {
-    if (NPA == 3 && CT == 2 && NQ == 3 && NT == 3 && WNPX == 3 && WCT == 2 && WNTW == 3 && WPG == 2) return true;
-    if (NPA == 3 && CT == 1 && NQ == 2 && NT == 4 && WNPX == 3 && WCT == 2 && WNTW == 2 && WPG == 2) return true;
+    if (NPA == 3 && CT == 2 && NQ == 3 && NT >= 1 && NT <= 3 && WNPX == 3 && WCT == 2 && WNTW == 3 && WPG == 2) return true;
+    if (NPA == 3 && CT == 1 && NQ == 2 && NT >= 1 && NT <= 4 && WNPX == 3 && WCT == 2 && WNTW == 2 && WPG == 2) return true;
     return false;
 }
 
@@ -137,9 +138,16 @@ int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_
 #endif
     IDQN_REQUIRE(f_lds <= 160 * 1024 && w_lds + 2048 <= 160 * 1024, "conv pair: %zu / %zu bytes of LDS per workgroup", f_lds, w_lds + 2048);
     const int ntw = (MT * WCT + 3) / 4;
-    if (NPA == 3 && CT == 2 && NQ == 3 && NT == 3 && WNPX == 3 && WCT == 2 && ntw == 3 && w.PG == 2)
-        return launch_pair<3, 2, 3, 3, 3, 2, 3, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
-    if (NPA == 3 && CT == 1 && NQ == 2 && NT == 4 && WNPX == 3 && WCT == 2 && ntw == 2 && w.PG == 2)
-        return launch_pair<3, 1, 2, 4, 3, 2, 2, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+    if (NPA == 3 && CT == 2 && NQ == 3 && WNPX == 3 && WCT == 2 && ntw == 3 && w.PG == 2) {
+        if (NT == 3) return launch_pair<3, 2, 3, 3, 3, 2, 3, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+        if (NT == 2) return launch_pair<3, 2, 3, 2, 3, 2, 3, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+        if (NT == 1) return launch_pair<3, 2, 3, 1, 3, 2, 3, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+    }
+    if (NPA == 3 && CT == 1 && NQ == 2 && WNPX == 3 && WCT == 2 && ntw == 2 && w.PG == 2) {
+        if (NT == 4) return launch_pair<3, 1, 2, 4, 3, 2, 2, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+        if (NT == 3) return launch_pair<3, 1, 2, 3, 3, 2, 2, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+        if (NT == 2) return launch_pair<3, 1, 2, 2, 3, 2, 2, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+        if (NT == 1) return launch_pair<3, 1, 2, 1, 3, 2, 2, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof);
+    }
     IDQN_REQUIRE(false, "conv pair: this combination is not built (convp_pair_built says which are)");
 }

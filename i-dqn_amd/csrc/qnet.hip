@@ -590,7 +590,9 @@ int cnn_setup(idqn_handle_s* h) {
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
             const int per_chunk = K * (i == 0 ? 1 : cl.K);
-            int nch = cu_budget() / per_chunk;  // never more workgroups than CUs: a 257th would run alone after the others
+            // never more workgroups than CUs (a 257th would run alone after the others), never more than 64 chunks: k_adam adds a leaf's
+            // slabs one after the other (K = 1: 256 chunks of Conv_0 cost it 5 us more than they save the weight gradient)
+            int nch = std::min(cu_budget() / per_chunk, 64);
             if (const char* e = variant_env("IDQN_WCHUNKS")) nch = atoi(e);
             if (const char* e = variant_env("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
             h->npc[i] = std::max(1, std::min(nch, npos));

@@ -427,6 +427,35 @@ def test_many_block_step_against_oracle(feats, K, B, conv_mode):
         assert err.max() <= 2e-5 and (err <= 3e-7).mean() >= 0.98, (leaf, err.max(), (err <= 3e-7).mean())
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+def test_nature_shape_with_fewer_heads_against_oracle(K):
+    """The Nature-CNN step at K = 1 (plain DQN, networks/dqn.py:60-73) .. 4 heads: the launch plans (items of one to four tiles per wave,
+    the data-gradient | weight-gradient pairs built for those tile counts) differ from the K = 5 goldens' -- losses and every leaf
+    gradient against the live oracle."""
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn import _hip
+    from slimdqn.networks.idqn import iDQN
+
+    arch, obs, feats, A, B = "cnn", (84, 84, 4), [32, 64, 64, 512], 6, 32
+    p = Q.init_params(23, arch, obs, A, feats, K)
+    pt = Q.init_params(24, arch, obs, A, feats, K)
+    batch = list(Q.synthetic_batch(26, B, obs, A, arch))
+    batch[4][5] = True
+    agent = iDQN(0, obs, A, K, feats, arch, 1e-3, 0.99, 1, 1, 10**9, 10**9, adam_eps=1e-6)
+    agent._load_flat(agent._online, p)
+    agent._load_flat(agent._target, pt)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    losses = agent._learn(Batch(*batch), flags=_hip.F_GRADS_ONLY).cpu().numpy()
+    G = agent._flat_grad()
+    for k in range(K):
+        loss, grads, _ = Q.loss_and_grads(Q.head(p, k), Q.head(pt, k), tuple(batch), arch, 0.99)
+        assert abs(losses[k] - loss) <= LOSS_ATOL, (k, losses[k], loss)
+        for leaf, g in grads.items():
+            assert _relerr(G[leaf][k], g) < 2e-5, (k, leaf, _relerr(G[leaf][k], g))
+
+
 def test_dqn_cnn_and_many_heads():
     """K = 1 without the head axis on the cnn, and K = 12 (more nets than the Atari config) in one launch set."""
     from collections import namedtuple
