@@ -47,12 +47,13 @@ from slimdqn.networks.idqn import iDQN
 Batch = namedtuple("Batch", "state action reward next_state is_terminal")
 rng = np.random.default_rng(7)
 agent = iDQN(3, (84, 84, 4), 6, 5, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+B = int(os.environ.get("SW_BATCH", "32"))
 def batch():
-    return Batch(torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
-                 torch.from_numpy(rng.integers(0, 6, 32).astype(np.int32)).cuda(),
-                 torch.from_numpy(rng.standard_normal(32).astype(np.float32)).cuda(),
-                 torch.from_numpy(rng.integers(0, 256, (32, 84, 84, 4), dtype=np.uint8)).cuda(),
-                 torch.from_numpy((rng.random(32) < 0.1).astype(np.uint8)).cuda())
+    return Batch(torch.from_numpy(rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy(rng.integers(0, 6, B).astype(np.int32)).cuda(),
+                 torch.from_numpy(rng.standard_normal(B).astype(np.float32)).cuda(),
+                 torch.from_numpy(rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)).cuda(),
+                 torch.from_numpy((rng.random(B) < 0.1).astype(np.uint8)).cuda())
 bs = [batch(), batch()]  # two buffer sets, used in turn like the replay buffer's staging sets
 losses = [agent._learn(bs[i % 2]).cpu().numpy().astype(np.float64).tolist() for i in range(int(os.environ.get("SW_STEPS", "6")))]
 state = rng.integers(0, 256, (84, 84, 4), dtype=np.uint8)
@@ -143,6 +144,21 @@ def test_dense0_update_on_pairs_of_column_tiles_is_bit_identical(default_run):
         assert got["losses"] == default_run["losses"], mode
         assert got["probe"] == default_run["probe"], mode
         assert got["acts"] == default_run["acts"], mode
+
+
+def test_eight_block_data_gradient_finished_in_the_gemm_epilogue_is_bit_identical():
+    """Round 5 (groups of 8 sample blocks, B = 256): the Dense_0 data gradient is the tiled GEMM writing raw rows + k_da3_finalize.
+    IDQN_NB_DGRAD_FIN=1 (opt-in, measured neutral) masks, splits into planes and sums per position in the GEMM's epilogue: same
+    values, same summation order -> bit-identical.  (IDQN_NB_DGRAD_F32=1, the f32-MFMA kernel per block, is another
+    association: fp32 round-off.)"""
+    want = _run(SW_BATCH="256", SW_STEPS="3")
+    got = _run(SW_BATCH="256", SW_STEPS="3", IDQN_NB_DGRAD_FIN="1")
+    assert got["losses"] == want["losses"]
+    assert got["probe"] == want["probe"]
+    f32 = _run(SW_BATCH="256", SW_STEPS="3", IDQN_NB_DGRAD_F32="1")
+    np.testing.assert_allclose(np.asarray(f32["losses"]), np.asarray(want["losses"]), rtol=0, atol=1e-6)
+    for name, w in want["probe"].items():
+        np.testing.assert_allclose(np.asarray(f32["probe"][name]), np.asarray(w), rtol=0, atol=2e-6, err_msg=name)
 
 
 def test_dense0_forward_through_lds_dma_is_bit_identical(default_run):

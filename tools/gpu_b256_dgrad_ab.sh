@@ -3,8 +3,8 @@
 mkdir -p gpurun_out/r5h && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/r5h
 V=$PWD/i-dqn_amd/libidqn_hip_variants.so
-timeout -k 10 900 python -m pytest tests/test_gpu_fp_path.py tests/test_gpu_configs.py tests/test_gpu_dp_native.py -x -q -m gpu > $O/parity.log 2>&1; echo "parity rc=$?"; tail -3 $O/parity.log
-for cfg in "" "IDQN_HIP_LIB=$V IDQN_NB_DGRAD_F32=1" "" "IDQN_HIP_LIB=$V IDQN_NB_DGRAD_F32=1"; do
+timeout -k 10 900 python -m pytest tests/test_gpu_fp_path.py tests/test_gpu_configs.py tests/test_gpu_dp_native.py tests/test_gpu_switches.py -x -q -m gpu > $O/parity.log 2>&1; echo "parity rc=$?"; tail -3 $O/parity.log
+for cfg in "" "IDQN_HIP_LIB=$V IDQN_NB_DGRAD_FIN=1" "" "IDQN_HIP_LIB=$V IDQN_NB_DGRAD_FIN=1" "IDQN_HIP_LIB=$V IDQN_NB_DGRAD_F32=1"; do
   env $cfg timeout -k 10 200 python bench.py --batch 256 --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline > $O/b256.json 2> $O/b256.err || { echo "[$cfg] failed"; tail -5 $O/b256.err; continue; }
   python - "$cfg" <<'PY'
 import json, sys
