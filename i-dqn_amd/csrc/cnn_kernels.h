@@ -353,7 +353,7 @@ template <int RING, bool PLAIN = true, int ABL = 0, bool XW = false, bool WNT = 
 __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PLAIN: the compiler's own order of split and products (A/B)
     extern __shared__ __attribute__((aligned(16))) float d3_red[];  // G == 4: [wave][tile q][register r][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // (4 waves per workgroup; fewer when the launch has too few items to put one workgroup on every CU otherwise)
     int jt, s;
 #ifdef IDQN_VARIANTS
     if (a.G == 4) {  // workgroup = (net, block, group of 4 splits, column tile); wave = split inside the group

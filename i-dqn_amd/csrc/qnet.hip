@@ -1425,7 +1425,13 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         else
 #endif
         if (d.bb_inner) hipLaunchKernelGGL(k_dense0_fwd3b, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
-        else hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), d.G == 4 ? 65536 + 16 : 0, q, d);
+        else {
+            // fewer than 256 four-wave workgroups (plain DQN: 2 nets x 64 splits x 4 column tiles): two waves each, so that every
+            // CU streams (a CU is the unit of streaming bandwidth); IDQN_D0_FWD_WPW=4: always four
+            static const int wpw_forced = variant_int("IDQN_D0_FWD_WPW", 0);
+            const int wpw = d.G == 4 ? 4 : wpw_forced > 0 ? wpw_forced : d.n_items <= 512 ? 2 : 4;
+            hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, wpw)), dim3(64 * wpw), d.G == 4 ? 65536 + 16 : 0, q, d);
+        }
         // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
         // the previous launches leave the memory system in
         static const bool twice = variant_on("IDQN_D0_FWD_TWICE");
