@@ -279,6 +279,7 @@ struct DenseFwdArgs {
     long b0_off, w1_off;
     int A;
     int bb_inner;  // k_dense0_fwd3: the sample block is the FASTEST index of the work item (B > 32)
+    int nt_from;   // k_dense0_fwd3: W of nets [0, nt_from) with default-policy loads, of the others non-temporally
 };
 
 __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
@@ -623,7 +624,22 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
         P[(4 * i + 3) * 32] = acc[3][r];
     }
 }
-__global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) { dense0_fwd3_body<4, true>(a); }
+// Nets [0, nt_from) are read with default-policy loads, the others non-temporally.  The training set's online nets (the first K) are
+// read again 50 us later by the fused update: allocated in the memory-side cache by this launch, part of those 79 MB is still there
+// (update -3 ... -5 us); the target nets' 79 MB are read once per step and would only push the conv launches' working set out
+// (all 158 MB default-policy: every later conv launch +0.3 ... 1 us; profiles/r5_d0fwd_load_policy_ab.txt).  A workgroup's waves are the
+// column tiles of one (net, split): the choice is workgroup-uniform.
+__global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
+    if (a.nt_from > 0 && a.G == 1 && !a.bb_inner) {
+        const long item = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) / ((long)a.n_jt * a.NS * a.nb);
+        const int n = __builtin_amdgcn_readfirstlane(((int)item + a.net_rot) % a.n_nets);
+        if (n < a.nt_from) {
+            dense0_fwd3_body<4, true, 0, false, false>(a);
+            return;
+        }
+    }
+    dense0_fwd3_body<4, true>(a);
+}
 // several sample blocks per net: block-inner work items, default-policy W loads (the neighbours' re-reads hit on-chip)
 // -- and the threaded split: with every window of W serving several blocks the waves are bound by their own issue, not by the stream
 __global__ __launch_bounds__(256) void k_dense0_fwd3b(DenseFwdArgs a) { dense0_fwd3_body<4, false, 0, false, false>(a); }
@@ -1262,10 +1278,10 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 // The fused update on pairs of column tiles (dense0_update.h, dense0_pair_body): one workgroup per (head, 32 rows)
-template <bool ROWPAIR>
+template <bool ROWPAIR, bool TH_ST_NT = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_dense0_wgrad_pair(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
-    dense0_pair_body<ROWPAIR>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
+    dense0_pair_body<ROWPAIR, 4, TH_ST_NT>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
 }
 #ifdef IDQN_VARIANTS
 // ... with whole tiles in flight and cross-tile refills (dense0_pair_body<.., 8>): two waves per SIMD
@@ -1276,11 +1292,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #endif
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
-template <int RT>  // 32 * RT rows x 256 columns
+template <int RT, bool TH_ST_NT = true>  // 32 * RT rows x 256 columns
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 3 : 2))) void k_dense0_wgrad_alds(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(1024))) float gs[RT == 1 ? 32 * 256 + 4096 : 64 * 256];
     d0_stagger(a.stagger);
-    dense0_wgrad_body<true, 2, false, true, RT, false, true>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+    dense0_wgrad_body<true, 2, false, true, RT, false, true, TH_ST_NT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

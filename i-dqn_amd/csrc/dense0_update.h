@@ -232,7 +232,7 @@ __device__ __forceinline__ void d0_stagger(const int ticks) {
 // parked in afterwards (+ 16 KB): ONE HBM round trip per tile; the dh fragments (L2-resident: 0.8 MB per head) stay in registers,
 // two blocks ahead.  RT = 2 with ALDS: a 64 x 256 tile -- the two row tiles share every dh fragment (half the L2 -> CU operand
 // traffic, twice the products behind every fragment wait), 64 accumulator registers, two workgroups per CU.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false, bool ALDS = false>  // column tile JT = 128 * NQ (256 when the dense width allows it)
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false, bool ALDS = false, bool TH_ST_NT = (D0_WG_NT & 2) != 0>  // column tile JT = 128 * NQ (256 when the dense width allows it); TH_ST_NT: see dense0_pair_body
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
@@ -527,7 +527,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
             adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
             const long o = o0 + (long)(RPI * i) * a.J;
-            st4<(D0_WG_NT & 2) != 0>(a.theta + o, t4);
+            st4<TH_ST_NT>(a.theta + o, t4);
             st4<(D0_WG_NT & 2) != 0>(a.mu + o, m4);
             st4<(D0_WG_NT & 2) != 0>(a.nu + o, v4);
         }
@@ -684,7 +684,11 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 // DEPTH = 8 (= every row group of a tile; two waves per SIMD): the whole tile is requested at once, and every ring slot the first
 // tile's stream has consumed is re-filled with the SECOND tile's row group at once -- the workgroup's requests never stop across
 // the two MFMA phases between the tiles.
-template <bool ROWPAIR, int DEPTH = 4>
+// TH_ST_NT = false: theta_new is stored with the default policy instead of non-temporally -- the NEXT step reads it twice (forward,
+// update); while the online nets' Dense_0 kernels fit the memory-side cache
+// beside the step's other traffic (K = 5: 79 MB of 256) they are found there (forward -4 us, update -2 us per step; more heads: the
+// dirty lines only get in the way, K = 8 +8 us -- the host chooses, qnet.hip d0_keep_online).  m / v stay non-temporal both ways.
+template <bool ROWPAIR, int DEPTH = 4, bool TH_ST_NT = (D0_WG_NT & 2) != 0>
 __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
     constexpr int JT = 256, RPI = 4, NIT = 8;
     constexpr bool XT = DEPTH == NIT;  // cross-tile refills
@@ -801,7 +805,7 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
             adam_elem(a.ad, bc1, bc2, g.z, t4.z, m4.z, v4.z);
             adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
             const unsigned o = o0 + (unsigned)i * rowJ;
-            st4<(D0_WG_NT & 2) != 0>(atw(Th, o), t4);
+            st4<TH_ST_NT>(atw(Th, o), t4);
             st4<(D0_WG_NT & 2) != 0>(atw(Mu, o), m4);
             st4<(D0_WG_NT & 2) != 0>(atw(Nu, o), v4);
         }

@@ -377,6 +377,17 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
     h->tl_name[h->tl_used++] = name;
 }
 
+// The online nets' Dense_0 kernels are streamed three times per step (forward; fused update: read and written).  While they fit the
+// 256 MB memory-side cache beside the step's other traffic -- K * F * J * 4 <= 84 MB: K <= 5 at the Nature width -- the forward reads
+// them and the update stores them with the default policy, so that part of them is found on chip again; everything read or written
+// once per step (target nets, m, v) stays non-temporal.  More heads: every stream non-temporal, as in rounds 3-4 (the dirty lines
+// of a set that cannot stay only get in the way: K = 6 the same, K = 8 +13 us; profiles/r5_d0_keep_online_ab.txt).  IDQN_D0_KEEP=0 / 1 (variants build) forces the choice.
+bool d0_keep_online(const idqn_handle_s* h) {
+    static const int forced = variant_int("IDQN_D0_KEEP", -1);
+    if (forced >= 0) return forced != 0;
+    return (long)h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20;
+}
+
 // k-splits of the Dense_0 forward of `n_nets` nets x `nb` sample blocks: as many 4-wave workgroups as CUs, never more (a 257th
 // would stream alone after the others), with balanced splits of the F / 32 row units (cnn_setup has the reasoning)
 int d0_splits(const idqn_handle_s* h, int n_nets, int nb) {
@@ -1371,7 +1382,11 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.bb_inner = (h->planes && s.G == 1 && nb > 1) ? 1 : 0;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
-    d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
+    static const int rot_knob = variant_int("IDQN_D0_NET_ROT", -1);  // experiment knob: 0 = online nets first
+    d.net_rot = s.n_in_sets > 1 ? (rot_knob >= 0 ? rot_knob : s.n_nets / 2) : 0;
+    // the online nets' Dense_0 kernels (re-read by the fused update of the same step) with default-policy loads: k_dense0_fwd3
+    static const int nt_from = variant_int("IDQN_D0_FWD_NT_FROM", -1);  // experiment knob: 0 = every net non-temporally (round 3-4)
+    d.nt_from = s.n_in_sets > 1 ? (nt_from >= 0 ? std::min(nt_from, s.n_nets) : d0_keep_online(h) ? s.n_nets / 2 : 0) : 0;
     d.G = h->planes ? s.G : 1;
     d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
     // IDQN_D0_FUSE_HIDDEN=1: the training set's head stage 1 (k_hidden) rides in this launch (DenseFwdArgs::arrive).  Opt-in:
@@ -1668,12 +1683,18 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         h->d0_rows = true;
         const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_pair<false>, pgrid, dim3(256), 0, q, dw);
+        if (d0_keep_online(h)) {  // theta_new stays on chip for the next step's forward and update
+            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+            else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, dw);
+        } else if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, true>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, true>), pgrid, dim3(256), 0, q, dw);
     } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (bf3) {  // the factored data-parallel update over >= 2 sample blocks: a3 fragments through LDS
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_alds<1>, wgrid, dim3(256), 0, q, dw);
+        if (d0_keep_online(h)) {
+            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_alds<1, false>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+            else hipLaunchKernelGGL((k_dense0_wgrad_alds<1, false>), wgrid, dim3(256), 0, q, dw);
+        } else if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_alds<1, true>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
+        else hipLaunchKernelGGL((k_dense0_wgrad_alds<1, true>), wgrid, dim3(256), 0, q, dw);
     }
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
@@ -2191,7 +2212,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
-    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0;
+    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0; d.nt_from = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
     static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
