@@ -161,6 +161,18 @@ def test_eight_block_data_gradient_finished_in_the_gemm_epilogue_is_bit_identica
         np.testing.assert_allclose(np.asarray(f32["probe"][name]), np.asarray(w), rtol=0, atol=2e-6, err_msg=name)
 
 
+def test_dense0_cache_policy_changes_no_bit(default_run):
+    """Round 5 (default while the online nets' Dense_0 kernels fit the memory-side cache, K <= 5): the forward reads them with
+    default-policy loads and the fused update stores theta_new with the default policy (csrc/qnet.hip d0_keep_online).
+    IDQN_D0_KEEP=0 is rounds 3-4's policy (every Dense_0 stream non-temporal), IDQN_D0_FWD_NT_FROM=10 every net default-policy:
+    a cache policy changes no arithmetic -> bit-identical."""
+    for env in ({"IDQN_D0_KEEP": "0"}, {"IDQN_D0_FWD_NT_FROM": "10"}, {"IDQN_D0_NET_ROT": "0"}):
+        got = _run(**env)
+        assert got["losses"] == default_run["losses"], env
+        assert got["probe"] == default_run["probe"], env
+        assert got["acts"] == default_run["acts"], env
+
+
 def test_dense0_forward_through_lds_dma_is_bit_identical(default_run):
     """Round 4 (opt-in, measured neutral): IDQN_D0_FWD_DMA=1 sends the Dense_0 forward's weight stream and activations through
     per-wave LDS-DMA rings (k_dense0_fwd3d) instead of vector registers.  Same k order, splits and product order: bit-identical."""
