@@ -887,30 +887,39 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             s_term = a.terminal[bg0];
             if (a.is_weight) s_wgt = a.is_weight[bg0];
         }
-        if (bb == 0) {  // A <= 32: at most four elements per thread, all requested before the first LDS store
-            float wv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wv[r] = t + 256 * r < 32 * a.A ? w1[(long)jc * 32 * a.A + t + 256 * r] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (t + 256 * r < 32 * a.A) w1s[t + 256 * r] = wv[r];
-        }
+        // (this chunk's 32 rows of W1 -- A <= 32: at most four elements per thread -- and the Dense_1 biases hang on the nets' base
+        // pointers, which are themselves loaded (wbase[k]): they are requested BEHIND the q partials, which need nothing but the
+        // kernel arguments, so that the pointer fetch is not a round trip of its own in front of everything else)
+        float wv[4] = {0.f, 0.f, 0.f, 0.f};
         // (action, sample) elements in rounds of 256: every partial of every round of this thread (NJC = J / 32 <= 16 chunks x
         // 2 nets x up to 4 rounds) is requested before the first add -- one load latency whatever A is
         auto q_reduce = [&](auto NR_) {
             constexpr int NR = decltype(NR_)::value;
-            float x[NR][16], y[NR][16];
+            float x[NR][16], y[NR][16], b1o[NR], b1t[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int e = min(t + 256 * r, a.A * 32 - 1);
                 const float* qo_ = a.qpart + so * NJC * 1024 + e;
                 const float* qt_ = a.qpart + st * NJC * 1024 + e;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    x[r][u] = u < NJC ? qo_[u * 1024] : 0.f;
-                    y[r][u] = u < NJC ? qt_[u * 1024] : 0.f;
+                for (int u = 0; u < 16; ++u) {  // (unconditional loads, clamped: as `u < NJC ? load : 0` every load sat in a branch of
+                    const int uc = u < NJC ? u : 0;  //  its own and hipcc waited for the first pair -- vmcnt(0) -- before the other 30 went out)
+                    x[r][u] = qo_[uc * 1024];
+                    y[r][u] = qt_[uc * 1024];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int e = min(t + 256 * r, a.A * 32 - 1);
+                b1o[r] = po[a.b1_off + (e >> 5)];
+                b1t[r] = pt[a.b1_off + (e >> 5)];
+            }
+            if (bb == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wv[r] = t + 256 * r < 32 * a.A ? w1[(long)jc * 32 * a.A + t + 256 * r] : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int e = t + 256 * r;
@@ -920,8 +929,8 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
                     if (u < NJC) { vo += x[r][u]; vt += y[r][u]; }
-                vo += po[a.b1_off + ac];
-                vt += pt[a.b1_off + ac];
+                vo += b1o[r];
+                vt += b1t[r];
                 qo[e] = vo;
                 qt[e] = vt;
                 if (jc == 0) {
@@ -935,6 +944,11 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             case 2: q_reduce(std::integral_constant<int, 2>{}); break;
             case 3: q_reduce(std::integral_constant<int, 3>{}); break;
             default: q_reduce(std::integral_constant<int, 4>{}); break;
+        }
+        if (bb == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t + 256 * r < 32 * a.A) w1s[t + 256 * r] = wv[r];
         }
         __syncthreads();
         ts[1] = clock64();
