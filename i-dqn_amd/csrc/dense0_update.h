@@ -688,7 +688,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 // update); while the online nets' Dense_0 kernels fit the memory-side cache
 // beside the step's other traffic (K = 5: 79 MB of 256) they are found there (forward -4 us, update -2 us per step; more heads: the
 // dirty lines only get in the way, K = 8 +8 us -- the host chooses, qnet.hip d0_keep_online).  m / v stay non-temporal both ways.
-template <bool ROWPAIR, int DEPTH = 4, bool TH_ST_NT = (D0_WG_NT & 2) != 0>
+template <bool ROWPAIR, int DEPTH = 4, bool TH_ST_NT = (D0_WG_NT & 2) != 0, bool ALL_DEFAULT = false>  // ALL_DEFAULT: every stream default-policy (K = 1: theta, m, v and the target net fit the memory-side cache together)
 __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
     constexpr int JT = 256, RPI = 4, NIT = 8;
     constexpr bool XT = DEPTH == NIT;  // cross-tile refills
@@ -731,9 +731,9 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const unsigned on = o0 + (unsigned)d * rowJ;
-            th[d] = ld4<(D0_WG_NT & 1) != 0>(at(Th, on));
-            mm[d] = ld4<(D0_WG_NT & 1) != 0>(at(Mu, on));
-            vv[d] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
+            th[d] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Th, on));
+            mm[d] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Mu, on));
+            vv[d] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Nu, on));
         }
     };
     auto tile_base = [&](int tt) { return (unsigned)((tile_f0(tt) + prow) * a.J + tile_jt(tt) * JT + pcol) * 4; };
@@ -796,9 +796,9 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
             *reinterpret_cast<float4*>(gp) = t4;
             if (XT ? tt == 0 : i + DEPTH < NIT) {
                 const unsigned on = XT ? tile_base(1) + (unsigned)i * rowJ : o0 + (unsigned)(i + DEPTH) * rowJ;
-                th[s] = ld4<(D0_WG_NT & 1) != 0>(at(Th, on));
-                mm[s] = ld4<(D0_WG_NT & 1) != 0>(at(Mu, on));
-                vv[s] = ld4<(D0_WG_NT & 1) != 0>(at(Nu, on));
+                th[s] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Th, on));
+                mm[s] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Mu, on));
+                vv[s] = ld4<!ALL_DEFAULT && (D0_WG_NT & 1) != 0>(at(Nu, on));
             }
             adam_elem(a.ad, bc1, bc2, g.x, t4.x, m4.x, v4.x);
             adam_elem(a.ad, bc1, bc2, g.y, t4.y, m4.y, v4.y);
@@ -806,8 +806,8 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
             adam_elem(a.ad, bc1, bc2, g.w, t4.w, m4.w, v4.w);
             const unsigned o = o0 + (unsigned)i * rowJ;
             st4<TH_ST_NT>(atw(Th, o), t4);
-            st4<(D0_WG_NT & 2) != 0>(atw(Mu, o), m4);
-            st4<(D0_WG_NT & 2) != 0>(atw(Nu, o), v4);
+            st4<!ALL_DEFAULT && (D0_WG_NT & 2) != 0>(atw(Mu, o), m4);
+            st4<!ALL_DEFAULT && (D0_WG_NT & 2) != 0>(atw(Nu, o), v4);
         }
         __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
         if (tt == 0) {    // the second tile's contraction operands, in front of everything else it will request

@@ -1685,7 +1685,14 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
         h->d0_rows = true;
         const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (d0_keep_online(h)) {  // theta_new stays on chip for the next step's forward and update
+        // one or two heads at the Nature width: theta, m, v and the target nets (4 x 16 MB per head) fit the memory-side cache beside the step's
+        // other traffic -- every stream of the update default-policy (K = 1 -1.9 us, K = 2 -4 us; K = 3 +5, K = 5 +16: profiles/r5_d0_keep_online_ab.txt)
+        static const int all_knob = variant_int("IDQN_D0_KEEP_ALL", -1);
+        const bool keep_all = all_knob >= 0 ? all_knob != 0 : (d0_keep_online(h) && 4L * K * h->F * h->J * 4 <= 128L << 20);
+        if (keep_all) {
+            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, false, true>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
+            else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, false, true>), pgrid, dim3(256), 0, q, dw);
+        } else if (d0_keep_online(h)) {  // theta_new stays on chip for the next step's forward and update
             if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
             else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, dw);
         } else if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, true>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
