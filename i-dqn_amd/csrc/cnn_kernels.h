@@ -1292,10 +1292,12 @@ __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
     dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 // The fused update on pairs of column tiles (dense0_update.h, dense0_pair_body): one workgroup per (head, 32 rows)
+// (cache policy: TH_ST_NT = false keeps theta_new on chip; ALL_DEFAULT: one or two heads, every stream default-policy; qnet.hip d0_keep_heads.
+// A template parameter, not a branch on the head: with both bodies in one kernel hipcc spilled 300 bytes per lane.)
 template <bool ROWPAIR, bool TH_ST_NT = true, bool ALL_DEFAULT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_dense0_wgrad_pair(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
-    dense0_pair_body<ROWPAIR, 4, TH_ST_NT, ALL_DEFAULT>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
+    dense0_pair_body<ROWPAIR, 4, TH_ST_NT, ALL_DEFAULT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 #ifdef IDQN_VARIANTS
 // ... with whole tiles in flight and cross-tile refills (dense0_pair_body<.., 8>): two waves per SIMD

@@ -160,6 +160,7 @@ struct DenseWgradArgs {
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     int stagger;   // > 0: workgroup b < 3 * 256 of the stand-alone kernel waits (b / 256) * stagger ticks of the 100 MHz clock first (d0_stagger)
+    int keep_heads;  // heads [0, keep_heads) store theta_new with the default cache policy (pair / ALDS kernels), the others non-temporally
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
     int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
     // NQ = 4 (full 512-column rows) with FUSE_DG: the workgroup finishes dL/da3 itself -- what k_da3_finalize does otherwise

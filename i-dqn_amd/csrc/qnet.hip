@@ -381,12 +381,14 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
 // 256 MB memory-side cache beside the step's other traffic -- K * F * J * 4 <= 84 MB: K <= 5 at the Nature width -- the forward reads
 // them and the update stores them with the default policy, so that part of them is found on chip again; everything read or written
 // once per step (target nets, m, v) stays non-temporal.  More heads: every stream non-temporal, as in rounds 3-4 (the dirty lines
-// of a set that cannot stay only get in the way: K = 6 the same, K = 8 +13 us; profiles/r5_d0_keep_online_ab.txt).  IDQN_D0_KEEP=0 / 1 (variants build) forces the choice.
-bool d0_keep_online(const idqn_handle_s* h) {
+// of a set that cannot stay only get in the way: K = 6 the same, K = 8 +13 us; keeping only the 4-5 heads that would fit: no better
+// than none -- profiles/r5_d0_keep_online_ab.txt).  IDQN_D0_KEEP=n (variants build): the first n heads.
+int d0_keep_heads(const idqn_handle_s* h) {
     static const int forced = variant_int("IDQN_D0_KEEP", -1);
-    if (forced >= 0) return forced != 0;
-    return (long)h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20;
+    if (forced >= 0) return std::min(forced, h->cfg.n_heads);
+    return (long)h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20 ? h->cfg.n_heads : 0;
 }
+bool d0_keep_online(const idqn_handle_s* h) { return d0_keep_heads(h) >= h->cfg.n_heads; }  // every head's kernel fits
 
 // k-splits of the Dense_0 forward of `n_nets` nets x `nb` sample blocks: as many 4-wave workgroups as CUs, never more (a 257th
 // would stream alone after the others), with balanced splits of the F / 32 row units (cnn_setup has the reasoning)
@@ -1388,7 +1390,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     static const int nt_from = variant_int("IDQN_D0_FWD_NT_FROM", -1);  // experiment knob: 0 = every net non-temporally (round 3-4)
     // (K <= 2: the frozen target nets' kernels fit beside the online ones -- 2 K F J 4 <= 84 MB -- and are found on chip step after step: K = 2 -3 us)
     const bool keep_target = d0_keep_online(h) && 2L * h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20;
-    d.nt_from = s.n_in_sets > 1 ? (nt_from >= 0 ? std::min(nt_from, s.n_nets) : keep_target ? s.n_nets : d0_keep_online(h) ? s.n_nets / 2 : 0) : 0;
+    d.nt_from = s.n_in_sets > 1 ? (nt_from >= 0 ? std::min(nt_from, s.n_nets) : keep_target ? s.n_nets : d0_keep_heads(h)) : 0;
     d.G = h->planes ? s.G : 1;
     d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
     // IDQN_D0_FUSE_HIDDEN=1: the training set's head stage 1 (k_hidden) rides in this launch (DenseFwdArgs::arrive).  Opt-in:
@@ -1596,7 +1598,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     const bool alds = alds_mode != 0 && !tile64, tall = alds && alds_mode == 2 && h->F % 64 == 0;
     const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / ((tile64 || (bf3 && tall)) ? 64 : 32); dw.n_jt = h->J / (128 * nq);
-    dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1;
+    dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1; dw.keep_heads = d0_keep_heads(h);
     dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
@@ -1689,21 +1691,36 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         // other traffic -- every stream of the update default-policy (K = 1 -1.9 us, K = 2 -4 us; K = 3 +5, K = 5 +16: profiles/r5_d0_keep_online_ab.txt)
         static const int all_knob = variant_int("IDQN_D0_KEEP_ALL", -1);
         const bool keep_all = all_knob >= 0 ? all_knob != 0 : (d0_keep_online(h) && 4L * K * h->F * h->J * 4 <= 128L << 20);
-        if (keep_all) {
-            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, false, true>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-            else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, false, true>), pgrid, dim3(256), 0, q, dw);
-        } else if (d0_keep_online(h)) {  // theta_new stays on chip for the next step's forward and update
-            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-            else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, false>), pgrid, dim3(256), 0, q, dw);
-        } else if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_pair<false, true>), pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL((k_dense0_wgrad_pair<false, true>), pgrid, dim3(256), 0, q, dw);
+        // heads [0, keep) keep theta_new on chip, the others store it non-temporally: one launch per policy (a kernel with both bodies spills)
+        const int keep = keep_all ? K : std::min(dw.keep_heads, K);
+        for (int part = 0; part < 2; ++part) {
+            const int k0 = part == 0 ? 0 : keep, k1 = part == 0 ? keep : K;
+            if (k1 <= k0) continue;
+            DenseWgradArgs dp = dw;
+            dp.item0 = k0 * dw.n_ft;
+            const dim3 grid((unsigned)((k1 - k0) * dw.n_ft));
+            hipEvent_t s0 = (e0 && k0 == 0) ? e0 : nullptr, s1 = (e0 && k1 == K) ? e1 : nullptr;
+            const void* fn = keep_all ? (const void*)k_dense0_wgrad_pair<false, false, true>
+                             : part == 0 ? (const void*)k_dense0_wgrad_pair<false, false, false> : (const void*)k_dense0_wgrad_pair<false, true, false>;
+            void* args[] = {&dp};
+            if (s0 || s1) IDQN_HIP_CHECK(hipExtLaunchKernel(fn, grid, dim3(256), args, 0, q, s0, s1, 0));
+            else IDQN_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, 0, q));
+        }
     } else if (fuse_adam && nq == 2 && fuse_dg) D0W_LAUNCH(true, 2, true);
     else if (bf3) {  // the factored data-parallel update over >= 2 sample blocks: a3 fragments through LDS
-        if (d0_keep_online(h)) {
-            if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_alds<1, false>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-            else hipLaunchKernelGGL((k_dense0_wgrad_alds<1, false>), wgrid, dim3(256), 0, q, dw);
-        } else if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad_alds<1, true>), wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL((k_dense0_wgrad_alds<1, true>), wgrid, dim3(256), 0, q, dw);
+        const int keep = std::min(dw.keep_heads, K);
+        for (int part = 0; part < 2; ++part) {  // (one launch per cache policy of theta_new, as for the pair kernel)
+            const int k0 = part == 0 ? 0 : keep, k1 = part == 0 ? keep : K;
+            if (k1 <= k0) continue;
+            DenseWgradArgs dp = dw;
+            dp.item0 = k0 * dw.n_ft * dw.n_jt;
+            const dim3 grid((unsigned)((k1 - k0) * dw.n_ft * dw.n_jt));
+            hipEvent_t s0 = (e0 && k0 == 0) ? e0 : nullptr, s1 = (e0 && k1 == K) ? e1 : nullptr;
+            const void* fn = part == 0 ? (const void*)k_dense0_wgrad_alds<1, false> : (const void*)k_dense0_wgrad_alds<1, true>;
+            void* args[] = {&dp};
+            if (s0 || s1) IDQN_HIP_CHECK(hipExtLaunchKernel(fn, grid, dim3(256), args, 0, q, s0, s1, 0));
+            else IDQN_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, 0, q));
+        }
     }
     else if (fuse_adam && nq == 2) D0W_LAUNCH(true, 2);
     else if (fuse_adam) D0W_LAUNCH(true, 1);
