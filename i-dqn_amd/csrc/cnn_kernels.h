@@ -627,7 +627,7 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
 // Nets [0, nt_from) are read with default-policy loads, the others non-temporally.  The training set's online nets (the first K) are
 // read again 50 us later by the fused update: allocated in the memory-side cache by this launch, part of those 79 MB is still there
 // (update -3 ... -5 us); the target nets' 79 MB are read once per step and would only push the conv launches' working set out
-// (all 158 MB default-policy: every later conv launch +0.3 ... 1 us; profiles/r5_d0fwd_load_policy_ab.txt).  A workgroup's waves are the
+// (all 158 MB default-policy: every later conv launch +0.3 ... 1 us; profiles/r5_d0_keep_online_ab.txt).  A workgroup's waves are the
 // column tiles of one (net, split): the choice is workgroup-uniform.
 __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
     if (a.nt_from > 0 && a.G == 1 && !a.bb_inner) {

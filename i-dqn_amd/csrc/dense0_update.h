@@ -160,7 +160,7 @@ struct DenseWgradArgs {
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     int stagger;   // > 0: workgroup b < 3 * 256 of the stand-alone kernel waits (b / 256) * stagger ticks of the 100 MHz clock first (d0_stagger)
-    int keep_heads;  // heads [0, keep_heads) store theta_new with the default cache policy (pair / ALDS kernels), the others non-temporally
+    int keep_heads;  // host side only: heads [0, keep_heads) are launched with the kernel that stores theta_new with the default cache policy
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
     int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
     // NQ = 4 (full 512-column rows) with FUSE_DG: the workgroup finishes dL/da3 itself -- what k_da3_finalize does otherwise
@@ -686,10 +686,10 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 // tile's stream has consumed is re-filled with the SECOND tile's row group at once -- the workgroup's requests never stop across
 // the two MFMA phases between the tiles.
 // TH_ST_NT = false: theta_new is stored with the default policy instead of non-temporally -- the NEXT step reads it twice (forward,
-// update); while the online nets' Dense_0 kernels fit the memory-side cache
-// beside the step's other traffic (K = 5: 79 MB of 256) they are found there (forward -4 us, update -2 us per step; more heads: the
-// dirty lines only get in the way, K = 8 +8 us -- the host chooses, qnet.hip d0_keep_online).  m / v stay non-temporal both ways.
-template <bool ROWPAIR, int DEPTH = 4, bool TH_ST_NT = (D0_WG_NT & 2) != 0, bool ALL_DEFAULT = false>  // ALL_DEFAULT: every stream default-policy (K = 1: theta, m, v and the target net fit the memory-side cache together)
+// update); while the online nets' Dense_0 kernels fit the memory-side cache beside the step's other traffic (K = 5: 79 MB of 256)
+// they are found there (forward -4 us, update -2 ... -9 us per step; more heads: the dirty lines only get in the way, K = 8 +13 us
+// -- the host chooses, qnet.hip d0_keep_heads).  m / v stay non-temporal unless ALL_DEFAULT.
+template <bool ROWPAIR, int DEPTH = 4, bool TH_ST_NT = (D0_WG_NT & 2) != 0, bool ALL_DEFAULT = false>  // ALL_DEFAULT: every stream default-policy (K <= 2: theta, m, v and the target nets fit the memory-side cache together)
 __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int item, float* gs /* 32 * 256 + 4096 + 1024 floats */, const int t) {
     constexpr int JT = 256, RPI = 4, NIT = 8;
     constexpr bool XT = DEPTH == NIT;  // cross-tile refills
