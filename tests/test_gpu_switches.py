@@ -166,7 +166,9 @@ def test_dense0_cache_policy_changes_no_bit(default_run):
     default-policy loads and the fused update stores theta_new with the default policy (csrc/qnet.hip d0_keep_online).
     IDQN_D0_KEEP=0 is rounds 3-4's policy (every Dense_0 stream non-temporal), IDQN_D0_FWD_NT_FROM=10 every net default-policy:
     a cache policy changes no arithmetic -> bit-identical."""
-    for env in ({"IDQN_D0_KEEP": "0"}, {"IDQN_D0_FWD_NT_FROM": "10"}, {"IDQN_D0_NET_ROT": "0"}):
+    # (IDQN_D0_KEEP=3: the update as two launches, heads 0-2 with the default-policy store, heads 3-4 non-temporal; IDQN_D0_KEEP_ALL=1:
+    # every stream of the update default-policy, the K <= 2 default)
+    for env in ({"IDQN_D0_KEEP": "0"}, {"IDQN_D0_KEEP": "3"}, {"IDQN_D0_KEEP_ALL": "1"}, {"IDQN_D0_FWD_NT_FROM": "10"}, {"IDQN_D0_NET_ROT": "0"}):
         got = _run(**env)
         assert got["losses"] == default_run["losses"], env
         assert got["probe"] == default_run["probe"], env
