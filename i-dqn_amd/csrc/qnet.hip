@@ -1388,8 +1388,9 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.net_rot = s.n_in_sets > 1 ? (rot_knob >= 0 ? rot_knob : s.n_nets / 2) : 0;
     // the online nets' Dense_0 kernels (re-read by the fused update of the same step) with default-policy loads: k_dense0_fwd3
     static const int nt_from = variant_int("IDQN_D0_FWD_NT_FROM", -1);  // experiment knob: 0 = every net non-temporally (round 3-4)
-    // (K <= 2: the frozen target nets' kernels fit beside the online ones -- 2 K F J 4 <= 84 MB -- and are found on chip step after step: K = 2 -3 us)
-    const bool keep_target = d0_keep_online(h) && 2L * h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20;
+    // (K <= 3: the frozen target nets' kernels fit beside the online ones -- 2 K F J 4 <= 100 MB -- and are found on chip step after step:
+    // K = 2 -3 us, K = 3 -2 us, K = 4 the same)
+    const bool keep_target = d0_keep_online(h) && 2L * h->cfg.n_heads * h->F * h->J * 4 <= 100L << 20;
     d.nt_from = s.n_in_sets > 1 ? (nt_from >= 0 ? std::min(nt_from, s.n_nets) : keep_target ? s.n_nets : d0_keep_heads(h)) : 0;
     d.G = h->planes ? s.G : 1;
     d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
