@@ -257,6 +257,8 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
         par ^= 1;
     }
 
+    // (non-temporal, as k_adam's loads of them: the slabs are written once and read once -- 18 MB per step that need not take room in the
+    // memory-side cache from the online Dense_0 kernels; step -1.6 us over four interleaved rounds, profiles/r5_d0_keep_online_ab.txt)
     float* S = a.slab + ((long)it.chunk * a.K + k) * a.slab_stride;
     const long row_base = NPX == 3 ? (long)it.kh * a.KW * a.CI : 0;
 #pragma unroll
@@ -264,7 +266,7 @@ __device__ __forceinline__ void cwgrad_body(const CWgradArgs& a, unsigned stage_
         if (tm[i] < 0) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            S[(row_base + tm[i] * 32 + mfma_row(r, h)) * a.CO + ct * 32 + cl] = acc[i][r] / a.out_div;
+            __builtin_nontemporal_store(acc[i][r] / a.out_div, &S[(row_base + tm[i] * 32 + mfma_row(r, h)) * a.CO + ct * 32 + cl]);
     }
 }
 

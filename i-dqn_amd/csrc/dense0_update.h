@@ -124,7 +124,7 @@ __device__ __forceinline__ void adam_thread(const AdamArgs& a, const int k, cons
                 float4 x[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (pc0 + 4 * u < sg.npc) x[u] = *reinterpret_cast<const float4*>(sp + (pc0 + 4 * u) * pstride);
+                    if (pc0 + 4 * u < sg.npc) x[u] = ld4<true>(sp + (pc0 + 4 * u) * pstride);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (pc0 + 4 * u < sg.npc) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
