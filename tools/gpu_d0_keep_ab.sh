@@ -4,7 +4,7 @@
 mkdir -p gpurun_out/r5pol && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/r5pol
 V=$PWD/i-dqn_amd/libidqn_hip_variants.so
-for round in 1 2; do
+for round in ${ROUNDS:-1 2}; do
 for cfg in ${CFGS:-IDQN_NONE=1 IDQN_D0_FWD_NT_FROM=10 IDQN_D0_KEEP=0 IDQN_D0_KEEP=0,IDQN_D0_FWD_NT_FROM=5}; do
   env IDQN_HIP_LIB=$V $(echo $cfg | tr "," " ") timeout -k 10 200 python bench.py --steps 400 --warmup 30 --repeats 3 --no-cpu-baseline > $O/ab.json 2> $O/ab.err || { echo "[$cfg] failed"; tail -5 $O/ab.err; continue; }
   python - "$cfg" <<'PY'
