@@ -15,9 +15,10 @@ import bench
 from slimdqn.networks.idqn import iDQN
 
 role = int(os.environ["IDQN_CONV_PROF"])
-agent = iDQN(0, bench.OBS, bench.N_ACTIONS, bench.K_HEADS, bench.FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+KH_, B_ = int(os.environ.get("CPROF_HEADS", bench.K_HEADS)), int(os.environ.get("CPROF_BATCH", bench.BATCH))
+agent = iDQN(0, bench.OBS, bench.N_ACTIONS, KH_, bench.FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
 Batch = namedtuple("Batch", "state action reward next_state is_terminal")
-b = Batch(*(torch.from_numpy(x).cuda() for x in bench.synthetic(1)))
+b = Batch(*(torch.from_numpy(x).cuda() for x in bench.synthetic(1, batch=B_)))
 for _ in range(30):
     agent._learn(b)
 torch.cuda.synchronize()
