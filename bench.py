@@ -362,6 +362,10 @@ def main():
                     help="minibatch per GPU (default 32 = the headline; 256 = BASELINE config 4's per-step work on one device)")
     ap.add_argument("--dp-streams", choices=["side", "inline"], default=None,
                     help="data-parallel step (idqn_dp_step): collectives on the library's side stream (default) or on the compute stream")
+    ap.add_argument("--learner", action="store_true",
+                    help="the learner path the reference runs, end to end (idqn.py:65-72 = rb.sample() + learn_on_batch) on a 2^15-element "
+                         "HBM frame ring: uniform sampler, prioritized sampler (reference protocol, 2^20-leaf tree) and the prioritized "
+                         "learner with TD write-back (extension), B = 32 and 256, beside the bare step in the same run; its own JSON line")
     ap.add_argument("--algo", choices=["idqn", "iiqn"], default="idqn",
                     help="iiqn: BASELINE config 3 (i-IQN heads, 32 quantile fractions; a labelled extension -- the reference "
                          "has no quantile code), one GPU, its own JSON line")
@@ -442,6 +446,8 @@ def main():
         return iiqn_bench(args, json_fd, Batch)
     if args.emulate_ranks:
         return emulate_ranks_bench(args, json_fd, Batch)
+    if args.learner:
+        return learner_bench(args, json_fd, Batch)
     A = args.actions
     dp = world > 1 or args.force_dp
     # The CPU leg FIRST (the reference path is timed before the GPU runs), rank 0 of a single-GPU run only.
@@ -608,6 +614,103 @@ def main():
     if dp:
         agent._destroy_handle()  # (the library-side communicator goes before the process group)
         dist.destroy_process_group()
+
+
+def learner_bench(args, json_fd, Batch):
+    """`update_online_params` in a loop (idqn.py:65-72: `replay_buffer.sample()` + `learn_on_batch`, update_to_data = 1) against
+    the bare step on pre-resident batches, same process, same box, regions interleaved.  Buffers hold 2^15 elements of
+    Atari-shaped frames; the prioritized samplers' trees have 2^20 leaves (BASELINE config 4).  One JSON line."""
+    import torch
+
+    from slimdqn.networks.idqn import iDQN
+    from slimdqn.sample_collection.per import PrioritizedLearner, SlotPrioritizedSampler
+    from slimdqn.sample_collection.replay_buffer import ReplayBuffer, TransitionElement
+    from slimdqn.sample_collection.samplers import PrioritizedSamplingDistribution, UniformSamplingDistribution
+
+    A, K = args.actions, int(args.heads)
+    n_el, leaves = 1 << 15, 1 << 20
+    rng = np.random.default_rng(7)
+    frames = rng.integers(0, 256, (512, 84, 84), dtype=np.uint8)  # (cycled: the loop's cost does not depend on the pixels)
+    acts, rews = rng.integers(0, A, n_el + 8), rng.integers(-1, 2, n_el + 8)
+
+    def fill(rb, **kw):
+        for i in range(n_el + 4):
+            rb.add(TransitionElement(frames[i % 512], int(acts[i]), float(rews[i]), bool(i % 1000 == 999), False), **kw)
+        rb.reuse_sample_buffers = True  # as the trainer sets it (experiments/base/launch.py): a batch is consumed before the next is drawn
+
+    out = {"metric": f"i-DQN learner loop: replay_buffer.sample() + learn_on_batch, Nature-CNN K={K}", "unit": "grad-steps/s", "n_gpus": 1,
+           "data": "synthetic", "dtype": "f32", "higher_is_better": True,
+           "config": {"workload": f"update_online_params (idqn.py:65-72) on a 2^15-element HBM frame ring of 84x84 uint8 frames, stack 4, "
+                                  f"K={K} A={A}; prioritized trees 2^20 leaves", "replay_elements": n_el, "tree_leaves": leaves},
+           "legs": {"bare": "agent._learn on 8 pre-resident batches (what bench.py's headline times)",
+                    "uniform": "UniformSamplingDistribution: host PCG64 draw + index map, slots uploaded, stacked gather on the device",
+                    "prioritized": "PrioritizedSamplingDistribution (samplers.py:52-116), no write-back (the reference's ReplayBuffer.sample drops "
+                                   "the keys): query on the tree's own stream + polled mailbox, keys to the host, slots uploaded, gather",
+                    "prioritized_learner": "PrioritizedLearner (extension): device-side stratified sample, importance weights, gather, "
+                                           "step, |TD| -> priorities -> sumtree_set, no host read"}}
+    steps, reps = max(50, min(args.steps, 300)), 3
+    for B in (32, 256):
+        agent = iDQN(0, OBS, A, K, FEATURES, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+        batches = [Batch(*(torch.from_numpy(x).cuda() for x in synthetic(2000 + i, A, B))) for i in range(8)]
+        rb_u = ReplayBuffer(UniformSamplingDistribution(1), batch_size=B, max_capacity=n_el, stack_size=4, update_horizon=1, gamma=0.99)
+        fill(rb_u)
+        rb_p = ReplayBuffer(PrioritizedSamplingDistribution(2, leaves), batch_size=B, max_capacity=n_el, stack_size=4, update_horizon=1, gamma=0.99)
+        pri = rng.random(n_el + 8) + 0.01
+        for i in range(n_el + 4):
+            rb_p.add(TransitionElement(frames[i % 512], int(acts[i]), float(rews[i]), bool(i % 1000 == 999), False), priority=float(pri[i]))
+        rb_p.reuse_sample_buffers = True
+        rb_l = ReplayBuffer(SlotPrioritizedSampler(3, leaves, priority_exponent=0.6), batch_size=B, max_capacity=leaves, stack_size=4,
+                            update_horizon=1, gamma=0.99)
+        fill(rb_l)
+        learner = PrioritizedLearner(agent, rb_l, beta=0.4, eps=1e-3, reduce="mean")
+        it = [0]
+
+        def bare():
+            agent._learn(batches[it[0] % 8])
+            it[0] += 1
+
+        legs = {"bare": bare, "uniform": lambda: agent.update_online_params(0, rb_u),
+                "prioritized": lambda: agent.update_online_params(0, rb_p), "prioritized_learner": learner.step}
+        times = {n: [] for n in legs}
+        for fn in legs.values():
+            for _ in range(20):
+                fn()
+        torch.cuda.synchronize()
+        for _ in range(reps):  # interleaved regions: every leg sees the same clocks
+            for name, fn in legs.items():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+                times[name].append((time.perf_counter() - t0) / steps)
+        # host-side cost of one sample() alone (no step behind it): what has to hide under the step in flight
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            rb_p.sample()
+        host_p = (time.perf_counter() - t0) / 100
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            rb_u.sample()
+        host_u = (time.perf_counter() - t0) / 100
+        torch.cuda.synchronize()
+        res = {}
+        bare_ms = float(np.median(times["bare"])) * 1e3
+        for name in legs:
+            ms = float(np.median(times[name])) * 1e3
+            res[name] = {"ms_per_step": ms, "steps_per_s": 1e3 / ms, "vs_bare": bare_ms / ms, "regions_ms": [x * 1e3 for x in times[name]]}
+        res["sample_call_host_us"] = {"uniform": host_u * 1e6, "prioritized": host_p * 1e6,
+                                      "what": "wall clock of rb.sample() alone, issued back to back with nothing else queued"}
+        out[f"B{B}"] = res
+        assert np.isfinite(agent._losses.cpu().numpy()).all()
+        del agent, rb_u, rb_p, rb_l, learner
+        torch.cuda.empty_cache()
+    out["value"] = out["B32"]["uniform"]["steps_per_s"]
+    out["ms_per_step"] = out["B32"]["uniform"]["ms_per_step"]
+    out["steps"] = steps
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def iiqn_cpu_baseline(n_actions, n_quantiles, budget_s=12.0):

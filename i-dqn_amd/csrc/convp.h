@@ -66,6 +66,7 @@ struct CFwdArgs {
     int out_Wp, out_lo_h, out_lo_w, out_W, out_H;  // out_W x out_H: unpadded grid (pb indexing)
     int mask_Wp, mask_lo_h, mask_lo_w, mask_C;
     int f32_W;
+    int row_parts;  // persistent kernel (convp_pp.hip) only: > 0 = every output row is cut into this many items (ranges never cross rows)
     int tune;  // experiment bits (IDQN_CONV_TUNE, variants build; 0 in the shipped library): 1 early kernel copies, 2 nt epilogue stores, 4 loader priority
     CVar var[4];
 };
@@ -247,6 +248,12 @@ struct CChainArgs {
 bool convp_chain_fwd_built(const int NT[3]);
 int convp_launch_chain_fwd(const CChainArgs& c, const int NT[3], int n_wg, size_t lds_bytes, hipStream_t q);
 int convp_fwd_max_nt(int CT);
+// persistent form for launches with several items per CU (convp_pp.hip): n_wg workgroups walk n_items items
+bool convp_pp_built(int NPA, int CT, int NQ, int NT);
+size_t convp_pp_epi_bytes(int NT, int epilogue, bool planes_out, bool f32_out);
+// items: device table of the n_items work items in launch order (row-aligned: pad0 = output row, pad1 = first column)
+int convp_launch_fwd_pp(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_items, int n_wg, size_t stage_bytes, int ring,
+                        size_t lds_bytes, hipStream_t q, const CItem* items, long long* prof = nullptr);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: the launchers keep one high-water mark per device and
 // kernel instantiation (a process that creates handles on a second GPU must set it there too).

@@ -218,7 +218,8 @@ struct NetSet {
 
 // host-side plans of the plane conv launches: the work items of a launch depend only on geometry, net count and batch
 // blocks, so they are built once and kept on the device
-struct FwdPlan { int n_items = 0, NT = 0, ring = 2, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0; };
+struct FwdPlan { int n_items = 0, NT = 0, ring = 2, items_per_slot = 0, r_begin[4] = {0, 0, 0, 0}, r_cnt[4] = {1, 1, 1, 1}; size_t stage = 0, lds = 0;
+                 int row_parts = 0, n_wg = 0; CItem* items_dev = nullptr; };  // row_parts > 0: a plan of the persistent kernel (convp_pp.hip), n_wg workgroups
 struct WgradPlan { int n_items = 0, n_chunks = 0, chunk_major = 0, MT = 0, PG = 0; size_t lds = 0; };
 
 // workspace of the i-IQN heads (iqn_kernels.h): V = 3K virtual nets x N fraction blocks
@@ -1022,6 +1023,101 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     return IDQN_OK;
 }
 
+
+// The persistent form of a forward / data-gradient role (convp_pp.hip) for launches with several items per CU: every
+// output row of every variant is cut into `parts` column ranges (items never cross rows: one strip per stage), as few as
+// the tile count per wave (<= convp_pp_max_nt) and the LDS (ring x stage + the epilogue slots <= 160 KB) allow.  Candidates
+// are ranked by a per-item cost model -- supersteps x max(matrix cycles + ramp, staged bytes / fill rate), the rates read
+// off profiles/r6_cprof_b256.txt -- summed over the items and divided over the CUs; IDQN_PP_PARTS<role> (variants build)
+// overrides the choice for sweeps.  Returns IDQN_E_INVALID when no candidate fits (the caller keeps the one-item launch).
+int plan_fwd_pp(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
+    auto key = std::make_tuple(role + 16, n_nets, nb, 0);
+    (void)0;
+    auto itp = h->fwd_plans.find(key);
+    if (itp != h->fwd_plans.end()) { *out = &itp->second; return itp->second.n_items > 0 ? IDQN_OK : IDQN_E_INVALID; }
+    char nm[32];
+    role &= 7;  // (bit 3 marks the acting set's plans)
+    snprintf(nm, sizeof nm, "IDQN_PP_PARTS%d", role);
+    const int forced = variant_int(nm, 0), forced_ring = variant_int("IDQN_PP_RING", 0);
+    const int NSS = g.KH * g.NCC, nm_prod = g.NPA == 3 ? 6 : 3, cus = cu_budget();
+    const bool epi1 = role >= 3, planes_out = role != 2, f32_out = role == 2;
+    int ow_max = 0;
+    for (int v = 0; v < g.n_var; ++v) ow_max = std::max(ow_max, g.var[v].OW);
+    FwdPlan best;
+    double best_cost = 0;
+    for (int parts = 1; parts <= ow_max; ++parts) {
+        if (forced && parts != forced) continue;
+        FwdPlan pl;
+        int np_max = 0;
+        double work = 0;  // cycles of all items of one slot
+        bool ok = true;
+        pl.row_parts = parts;
+        for (int v = 0; v < g.n_var && ok; ++v) {
+            const int OW = g.var[v].OW, OH = g.var[v].OH;
+            if (parts > OW) { ok = false; break; }
+            np_max = std::max(np_max, (OW + parts - 1) / parts);
+            pl.r_begin[v] = pl.items_per_slot;
+            pl.r_cnt[v] = OH * parts;
+            pl.items_per_slot += OH * parts;
+        }
+        if (!ok) continue;
+        pl.NT = (np_max * g.CT + 3) / 4;
+        if (pl.NT < 2) pl.NT = 2;  // (the smallest kernel built)
+        if (!convp_pp_built(g.NPA, g.CT, g.NQ, pl.NT) || NSS - 1 < pl.NT) continue;
+        pl.stage = (size_t)(g.NQ * g.CT * 3 + ((np_max - 1) * g.SX + g.NQ) * g.NPA) * 1024;
+        const size_t epi = convp_pp_epi_bytes(pl.NT, epi1 ? 1 : 0, planes_out, f32_out);
+        pl.ring = (forced_ring != 2 && 3 * pl.stage + epi <= 160 * 1024) ? 3 : 2;
+        pl.lds = pl.ring * pl.stage + epi;
+        if (pl.lds > 160 * 1024) continue;
+        for (int v = 0; v < g.n_var; ++v) {
+            const int OW = g.var[v].OW, OH = g.var[v].OH;
+            for (int part = 0; part < parts; ++part) {
+                const int np = OW / parts + (part < OW % parts ? 1 : 0);
+                const double mfma = (double)((np * g.CT + 3) / 4) * g.NQ * nm_prod * 32 + 450;
+                const double fill = (double)(g.NQ * g.CT * 3 + ((np - 1) * g.SX + g.NQ) * g.NPA) * 1024 / (pl.ring == 3 ? 30.0 : 26.0);
+                work += OH * (NSS * std::max(mfma, fill) + 600);
+            }
+        }
+        pl.n_items = pl.items_per_slot * n_nets * nb;
+        pl.n_wg = std::min(pl.n_items, cus);
+        const int rounds = (pl.n_items + pl.n_wg - 1) / pl.n_wg;
+        // whole launch: the slots' work over the CUs, stretched by the last round's idle CUs
+        const double cost = work * n_nets * nb / pl.n_wg * ((double)rounds * pl.n_wg / pl.n_items);
+        if (plan_print())
+            fprintf(stderr, "[plan] pp role %d parts %d: %d items, NT %d, ring %d, stage %zu B, lds %zu B, model %.0f k cycles\n", role, parts,
+                    pl.n_items, pl.NT, pl.ring, pl.stage, pl.lds, cost / 1e3);
+        if (best.n_items == 0 || cost < best_cost) { best = pl; best_cost = cost; }
+    }
+    if (best.n_items > 0) {
+        // the item table, in launch order: index b -> (slot, range) as the one-item kernels derive it (net-major, or range-major
+        // where the nets share their input), range -> (variant, output row, column part)
+        std::vector<CItem> tab((size_t)best.n_items);
+        const int n_slots = n_nets * nb;
+        for (int b = 0; b < best.n_items; ++b) {
+            const bool range_major = role == 0;
+            const int rr = range_major ? b / n_slots : b % best.items_per_slot, slot = range_major ? b % n_slots : b / best.items_per_slot;
+            int vi = 0;
+            for (int i = 1; i < g.n_var; ++i) if (rr >= best.r_begin[i]) vi = i;
+            const int r = rr - best.r_begin[vi], OW = g.var[vi].OW;
+            const int row = r / best.row_parts, part = r % best.row_parts, base = OW / best.row_parts, rem = OW % best.row_parts;
+            CItem& it = tab[b];
+            memset(&it, 0, sizeof(it));
+            it.net = slot / nb; it.bb = slot % nb; it.var = vi;
+            it.pad0 = row; it.pad1 = part * base + std::min(part, rem);
+            it.p0 = row * OW + it.pad1; it.np = base + (part < rem ? 1 : 0);
+        }
+        IDQN_HIP_CHECK(hipMalloc((void**)&best.items_dev, tab.size() * sizeof(CItem)));
+        h->owned.push_back((void*)best.items_dev);
+        IDQN_HIP_CHECK(hipMemcpy(best.items_dev, tab.data(), tab.size() * sizeof(CItem), hipMemcpyHostToDevice));
+    }
+    *out = &(h->fwd_plans[key] = best);
+    if (best.n_items == 0) return IDQN_E_INVALID;
+    if (plan_print())
+        fprintf(stderr, "[plan] pp role %d nets %d nb %d: parts %d -> %d items on %d workgroups, NT %d, ring %d, stage %zu B, lds %zu B\n", role, n_nets,
+                nb, best.row_parts, best.n_items, best.n_wg, best.NT, best.ring, best.stage, best.lds);
+    return IDQN_OK;
+}
+
 int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunks = 0) {
     if (n_chunks <= 0) n_chunks = h->npc[layer];
     auto key = std::make_tuple(layer, nb, n_chunks);
@@ -1167,6 +1263,20 @@ int planes_conv(idqn_handle_s* h, NetSet& s, int role, int nb, hipStream_t q) {
     FwdPlan* pl;
     int rc = conv_args(h, s, role, nb, cu_budget(), a, g, pl);
     if (rc) return rc;
+    // several items per CU (many sample blocks or heads): the persistent form, where the first fill, the table arithmetic
+    // and the epilogue of an item run beside another item's matrix loop (convp_pp.hip).  IDQN_CONV_PP=0: one item per workgroup.
+    static const int pp_roles = getenv("IDQN_CONV_PP") ? atoi(getenv("IDQN_CONV_PP")) : 15;  // bit r: role r (role 4, the Conv_1 data gradient, measured flat: profiles/r6_pp_ab.txt)
+    if (((pp_roles >> role) & 1) && pl->n_items > cu_budget()) {
+        FwdPlan* pp;
+        const bool fwd = role <= 2;
+        if (plan_fwd_pp(h, role + (fwd && &s == &h->infer ? 8 : 0), fwd ? s.n_nets : h->cfg.n_heads, nb, g, &pp) == IDQN_OK) {
+            a.items_per_slot = pp->items_per_slot;
+            for (int v = 0; v < 4; ++v) { a.r_begin[v] = pp->r_begin[v]; a.r_cnt[v] = pp->r_cnt[v]; }
+            a.row_parts = pp->row_parts;
+            return convp_launch_fwd_pp(a, g.NPA, g.CT, g.NQ, pp->NT, pp->n_items, pp->n_wg, pp->stage, pp->ring, pp->lds, q, pp->items_dev,
+                                       conv_prof(h, s, role, pl));
+        }
+    }
     return convp_launch_fwd(a, g.NPA, g.CT, g.NQ, pl->NT, pl->n_items, pl->stage, pl->ring, pl->lds, q, conv_prof(h, s, role, pl));
 }
 

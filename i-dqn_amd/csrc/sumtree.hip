@@ -567,15 +567,24 @@ extern "C" int sumtree_query_host(const double* nodes_dev, int32_t depth, const 
     IDQN_HIP_CHECK(hipGetLastError());
     volatile unsigned* seqp = reinterpret_cast<volatile unsigned*>(mb->host + 12);
     bool seen = false;
+    hipError_t qe = hipSuccess;
     for (long spin = 0; spin < (1L << 34); ++spin) {  // (far longer than anything queued in front of the launch)
         if (*seqp == want) { seen = true; break; }
         __builtin_ia32_pause();
-        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(q) != hipErrorNotReady) { seen = *seqp == want; break; }
+        if ((spin & 0xfffff) == 0xfffff && (qe = hipStreamQuery(q)) != hipErrorNotReady) {
+            // the stream has drained (or reports an error): the results were written before the kernel ended
+            (void)hipStreamSynchronize(q);
+            seen = *seqp == want;
+            break;
+        }
     }
     if (!seen) {
         (void)hipStreamSynchronize(q);
+        unsigned ctl_now[2] = {0, 0};
+        (void)hipMemcpy(ctl_now, mb->ctl, 8, hipMemcpyDeviceToHost);
         (void)hipMemset(mb->ctl, 0, 64);
-        IDQN_REQUIRE(false, "sumtree_query_host: the launch finished without delivering its results");
+        IDQN_REQUIRE(false, "sumtree_query_host: the launch finished without delivering its results (stream query: %s, mailbox seq %u, wanted %u, "
+                            "arrivals %u of %d)", hipGetErrorName(qe), *seqp, want, ctl_now[0], n);
     }
     *root_out_host = *reinterpret_cast<const double*>(mb->host);
     *status_out_host = *reinterpret_cast<const int32_t*>(mb->host + 8);

@@ -108,6 +108,10 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         self._priority_exponent = priority_exponent
         self._sum_tree = sum_tree.SumTree(self._max_capacity)
         self._i2k_dev = torch.zeros(self._max_capacity, dtype=torch.int32, device="cuda")  # index -> key, device copy
+        # add / remove / update / sample all launch on the tree's own stream: `sample` (one launch + a polled host mailbox,
+        # samplers.py:105-116) then returns in ~15 us whatever the learner has queued on its stream, instead of waiting for
+        # the gradient step in flight -- the same operations in the same order on the same tree, so the same keys
+        self._sum_tree.use_own_stream()
         super().__init__(seed=seed)
 
     def add(self, key: ReplayItemID, priority: float) -> None:
@@ -122,7 +126,7 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         tree.max_recorded_priority = max(tree.max_recorded_priority, value)
         # one launch: index_to_key[index] = key and tree.set(index, value)   (samplers.py:62-66)
         _hip.check(_hip.lib().sampler_prioritized_add(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._i2k_dev), int(index),
-                                                      int(key), float(value), _hip.current_stream()), "sampler_prioritized_add")
+                                                      int(key), float(value), tree._q()), "sampler_prioritized_add")
 
     def update(self, keys, priorities) -> None:
         if not isinstance(keys, np.ndarray):
@@ -138,7 +142,7 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         # {hole: leaf[last], last: 0} (samplers.py:98-102; hole == last: {hole: 0}), its key in the device map
         tree = self._sum_tree
         _hip.check(_hip.lib().sampler_prioritized_remove(_hip.ptr(tree._nodes_dev), tree._depth, _hip.ptr(self._i2k_dev), int(hole),
-                                                         int(last), _hip.current_stream()), "sampler_prioritized_remove")
+                                                         int(last), tree._q()), "sampler_prioritized_remove")
         self._map.remove(key)
 
     def sample(self, size: int):
@@ -169,6 +173,7 @@ class PrioritizedSamplingDistribution(UniformSamplingDistribution):
         made on the device (clamped below the root where the reference would raise), leaves mapped by ``sampler_map_indices``."""
         assert self._map.index_to_key, ValueError("No keys to sample from.")
         tree = self._sum_tree
+        tree._sync_to_current()  # (this variant runs on the caller's stream, behind everything the tree's stream has done)
         u = torch.from_numpy(self._rng_key.random(size)).cuda()
         leaves = torch.empty(int(u.numel()), dtype=torch.int32, device="cuda")
         keys = torch.empty_like(leaves)

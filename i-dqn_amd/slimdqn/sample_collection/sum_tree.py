@@ -31,6 +31,24 @@ class SumTree:
         self.max_recorded_priority = 1.0
         self._mailbox = None   # host mailbox of query / sample (created on first use)
         self._pins = None      # pinned staging of `set`: two (indices, values) sets used in turn
+        self._stream = None    # a stream of its own for every launch that touches the tree (use_own_stream), or None: torch's current
+
+    def use_own_stream(self) -> None:
+        """Every launch that reads or writes the tree goes to ONE high-priority stream owned by the tree instead of torch's
+        current stream.  Tree operations stay ordered among themselves (that order is all their results depend on: they take
+        kernel arguments and host vectors, nothing computed on another stream), but a ``query_host`` no longer queues behind
+        whatever the caller has in flight -- the learner's gradient step of 0.27 ms -- before the host can read its mailbox."""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(priority=-1)
+            self._stream.wait_stream(torch.cuda.current_stream())  # the zero-fill of the node array
+
+    def _q(self):
+        return _hip.current_stream() if self._stream is None else C.c_void_p(self._stream.cuda_stream)
+
+    def _sync_to_current(self) -> None:
+        """Before the caller's stream reads tree memory with its own operations (tests, ``sample_device``)."""
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
 
     def __del__(self):
         mb, self._mailbox = getattr(self, "_mailbox", None), None
@@ -43,6 +61,7 @@ class SumTree:
     # the reference's tests read ``_nodes`` directly (tests/test_sum_tree.py:34-37)
     @property
     def _nodes(self) -> np.ndarray:
+        self._sync_to_current()
         return self._nodes_dev.cpu().numpy()
 
     def _launch_set(self, idx: np.ndarray, val: np.ndarray) -> None:
@@ -60,14 +79,15 @@ class SumTree:
         n = int(idx.size)
         pi.numpy()[:n] = idx
         pv.numpy()[:n] = val
-        i_dev[:n].copy_(pi[:n], non_blocking=True)
-        v_dev[:n].copy_(pv[:n], non_blocking=True)
-        _hip.check(
-            _hip.lib().sumtree_set(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(i_dev), _hip.ptr(v_dev),
-                                   int(idx.size), _hip.ptr(self._scratch), _hip.current_stream()),
-            "sumtree_set")
-        ent[4] = ent[4] or torch.cuda.Event()
-        ent[4].record()
+        with torch.cuda.stream(self._stream):  # (None: the current stream)
+            i_dev[:n].copy_(pi[:n], non_blocking=True)
+            v_dev[:n].copy_(pv[:n], non_blocking=True)
+            _hip.check(
+                _hip.lib().sumtree_set(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(i_dev), _hip.ptr(v_dev),
+                                       int(idx.size), _hip.ptr(self._scratch), self._q()),
+                "sumtree_set")
+            ent[4] = ent[4] or torch.cuda.Event()
+            ent[4].record()
 
     def set(self, indices, values) -> None:
         if isinstance(indices, (int, np.integer)) and isinstance(values, (int, float, np.floating)):
@@ -78,7 +98,7 @@ class SumTree:
                 raise IndexError("sum tree index out of range")
             self.max_recorded_priority = max(self.max_recorded_priority, values)
             _hip.check(_hip.lib().sumtree_set_one(_hip.ptr(self._nodes_dev), self._depth, int(indices), float(values), None,
-                                                  _hip.current_stream()), "sumtree_set_one")
+                                                  self._q()), "sumtree_set_one")
             return
         if isinstance(indices, (int, np.integer)):
             indices = np.asarray([indices], np.int32)
@@ -104,6 +124,7 @@ class SumTree:
             self._launch_set(uniq[lo : lo + _MAX_SET], val[first[lo : lo + _MAX_SET]])
 
     def get(self, index):
+        self._sync_to_current()
         if isinstance(index, (int, np.integer)):
             return float(self._nodes_dev[self._first_leaf_offset + int(index)].item())
         idx = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32).reshape(-1)).cuda()
@@ -114,10 +135,12 @@ class SumTree:
 
     @property
     def root(self) -> float:
+        self._sync_to_current()
         return float(self._nodes_dev[0].item())
 
     def query_device(self, targets_dev: torch.Tensor) -> torch.Tensor:
         """Device-to-device query (no host sync): int32 leaf indices; status bits land in ``_status``."""
+        self._sync_to_current()
         out = torch.empty(targets_dev.numel(), dtype=torch.int32, device="cuda")
         _hip.check(_hip.lib().sumtree_query(_hip.ptr(self._nodes_dev), self._depth, _hip.ptr(targets_dev),
                                             targets_dev.numel(), _hip.ptr(out), _hip.ptr(self._status),
@@ -144,7 +167,7 @@ class SumTree:
                 _hip.ptr(self._nodes_dev), self._depth, C.c_void_p(vals[lo:].ctypes.data), n, 1 if scale_by_root else 0,
                 _hip.ptr(index_to_key), int(n_live), self._mailbox, C.c_void_p(leaves[lo:].ctypes.data),
                 C.c_void_p(keys[lo:].ctypes.data) if keys is not None else None, C.byref(root), C.byref(status),
-                _hip.current_stream()), "sumtree_query_host")
+                self._q()), "sumtree_query_host")
             st_all |= status.value
         return leaves, keys, root.value, st_all
 

@@ -367,3 +367,45 @@ def test_replay_gather_of_whole_pair_stores(n, obs_bytes):
     np.testing.assert_array_equal(a_out.cpu().numpy(), act.cpu().numpy()[slots_h])
     np.testing.assert_array_equal(r_out.cpu().numpy().view(np.uint32), rew.cpu().numpy()[slots_h].view(np.uint32))
     np.testing.assert_array_equal(t_out.cpu().numpy(), term.cpu().numpy()[slots_h])
+
+
+@pytest.mark.parametrize("pi", range(3))
+def test_prioritized_traces_with_a_gradient_step_in_flight(pi):
+    """The prioritized sampler launches on the tree's own stream so that `sample` does not wait for the learner's step
+    (samplers.py:105-116 behind idqn.py:65-72).  Pinned here: with gradient steps queued on the caller's stream all the
+    time, the reference-captured add / update / remove / sample traces still come out key for key -- and a sample returns
+    while that work is still running (the query did not queue behind it)."""
+    import time
+
+    import torch
+
+    from collections import namedtuple
+
+    from oracle import qnet_ref as Q
+    from slimdqn.networks.idqn import iDQN
+
+    obs, A, feats, K, B = (84, 84, 4), 6, [32, 64, 64, 512], 5, 32
+    agent = iDQN(0, obs, A, K, feats, "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4)
+    Batch = namedtuple("Batch", "state action reward next_state is_terminal")
+    batch = Batch(*(torch.from_numpy(x).cuda() for x in Q.synthetic_batch(3, B, obs, A, "cnn")))
+    Prioritized = _classes()[2]
+    overlapped = [0, 0]
+
+    class Busy(Prioritized):  # every sample is issued with ~10 gradient steps (~3 ms) queued in front of it on the caller's stream
+        def sample(self, size):
+            for _ in range(10):
+                agent._learn(batch)
+            ev = torch.cuda.Event()
+            ev.record()
+            t0 = time.perf_counter()
+            keys = super().sample(size)
+            overlapped[0] += int(not ev.query())  # the steps were still running when the keys arrived
+            overlapped[1] += 1
+            self.last_wait = time.perf_counter() - t0
+            return keys
+
+    z, meta = kat.load_sampler_traces()
+    kat.replay_prioritized_trace(Busy, z, meta, pi)
+    torch.cuda.synchronize()
+    assert np.isfinite(agent._losses.cpu().numpy()).all()
+    assert overlapped[1] > 0 and overlapped[0] >= 0.8 * overlapped[1], overlapped
