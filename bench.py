@@ -643,9 +643,12 @@ def learner_bench(args, json_fd, Batch):
            "config": {"workload": f"update_online_params (idqn.py:65-72) on a 2^15-element HBM frame ring of 84x84 uint8 frames, stack 4, "
                                   f"K={K} A={A}; prioritized trees 2^20 leaves", "replay_elements": n_el, "tree_leaves": leaves},
            "legs": {"bare": "agent._learn on 8 pre-resident batches (what bench.py's headline times)",
-                    "uniform": "UniformSamplingDistribution: host PCG64 draw + index map, slots uploaded, stacked gather on the device",
+                    "uniform": "UniformSamplingDistribution: host PCG64 draw + index map, then ONE C call (idqn_learn_on_replay: slots as "
+                               "kernel arguments, the stacked gather inside the step's staging launch)",
                     "prioritized": "PrioritizedSamplingDistribution (samplers.py:52-116), no write-back (the reference's ReplayBuffer.sample drops "
-                                   "the keys): query on the tree's own stream + polled mailbox, keys to the host, slots uploaded, gather",
+                                   "the keys): query on the tree's own stream + polled mailbox, keys to the host, then idqn_learn_on_replay",
+                    "uniform_two_calls / prioritized_two_calls": "the same with sample() and learn_on_batch as two calls: slots uploaded, "
+                                                                 "replay_gather_stacked launch, idqn_learn_on_batch on its outputs",
                     "prioritized_learner": "PrioritizedLearner (extension): device-side stratified sample, importance weights, gather, "
                                            "step, |TD| -> priorities -> sumtree_set, no host read"}}
     steps, reps = max(50, min(args.steps, 300)), 3
@@ -669,8 +672,16 @@ def learner_bench(args, json_fd, Batch):
             agent._learn(batches[it[0] % 8])
             it[0] += 1
 
+        def two_calls(rb):  # sample() then learn_on_batch, as two calls (what the fused call replaces)
+            def fn():
+                agent.fuse_replay_sampling = False
+                agent.update_online_params(0, rb)
+                agent.fuse_replay_sampling = True
+            return fn
+
         legs = {"bare": bare, "uniform": lambda: agent.update_online_params(0, rb_u),
-                "prioritized": lambda: agent.update_online_params(0, rb_p), "prioritized_learner": learner.step}
+                "prioritized": lambda: agent.update_online_params(0, rb_p),
+                "uniform_two_calls": two_calls(rb_u), "prioritized_two_calls": two_calls(rb_p), "prioritized_learner": learner.step}
         times = {n: [] for n in legs}
         for fn in legs.values():
             for _ in range(20):

@@ -136,8 +136,18 @@ struct StageArgs {
     float* bcinv;
     float b1, b2;
     unsigned* epoch;        // chained conv launches: += 1 once per step (first pack block), or nullptr
+    // replay-sourced step (idqn_learn_on_replay): the stacked gather happens here.  frames != nullptr: sample b of set
+    // (0 state / 1 next_state), channel c = frame ((rows[slot_b][2 set] - (3 - c)) mod n_frames) of the ring, zero where
+    // 3 - c >= rows[slot_b][2 set + 1] (frames before the episode start); the scalars of the rows go to act / rew / term
+    const uint8_t* frames;
+    const int32_t* rows;
+    long n_frames, frame_bytes;
+    int32_t* act_out;
+    float* rew_out;
+    uint8_t* term_out;
     PackJob job[8];
 };
+struct StageSlots { int32_t slot[256]; };  // the sampled element slots of a replay-sourced step, as kernel arguments
 
 // exact three-way bf16 split of two f32 values, round-to-nearest-even at every level (a plain cast: v_cvt_pk_bf16_f32,
 // which keeps a NaN a NaN).  Returns the pair packed (v0 in the low half) per plane.
@@ -235,7 +245,7 @@ int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_
                       const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof,
                       const D0Stream* ds = nullptr);
 bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
-int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q);
+int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q, const StageSlots* slots = nullptr);
 // the three forward convs of a net set as ONE launch with per-item hand-offs (convp_chain.hip)
 struct CChainArgs {
     CFwdArgs a[3];

@@ -11,7 +11,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_stage(StageArgs a) {
+struct NoSlots { int32_t slot[1]; };
+template <bool REPLAY, typename SL>
+__global__ __launch_bounds__(256) void k_stage(StageArgs a, SL sl) {
     // [element][sample], 80-byte rows keep the 16-byte reads aligned.  The four 8-sample groups of a row are XOR-swizzled
     // by (row >> 3) & 3: a wave's transposing 2-byte stores go to 8 rows that are 8 apart (640 bytes = 0 mod 32 banks) --
     // 8-way conflicts unswizzled (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.81 in round 3), 2-way with the groups spread
@@ -26,7 +28,31 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
         const int bb = b % a.nb, set = b / a.nb;
         const uint8_t* src = a.src[set];
         const long e0 = (long)et * 64;
-        {
+        if (REPLAY) {
+            // the 64 elements of this tile = 16 pixels x 4 stacked frames: thread (sample s, channel c8 < 4) reads the 16
+            // pixels of ITS frame as one 16-byte load (replay_buffer.py:223-229 stacks along the last axis)
+            const int s = t >> 3, c8 = t & 7, bg = bb * 32 + s;
+            if (c8 < 4) {
+                uint4 w = make_uint4(0u, 0u, 0u, 0u);
+                if (bg < a.B) {
+                    const int32_t* m = a.rows + (long)sl.slot[bg] * 8;
+                    const long newest = m[2 * set], valid = m[2 * set + 1], back = 3 - c8;
+                    if (back < valid)
+                        w = *reinterpret_cast<const uint4*>(a.frames + ((newest - back + a.n_frames) % a.n_frames) * a.frame_bytes + (long)et * 16);
+                    if (et == 0 && set == 0 && c8 == 0) {
+                        a.act_out[bg] = m[4];
+                        a.rew_out[bg] = __int_as_float(m[5]);
+                        a.term_out[bg] = (uint8_t)m[6];
+                    }
+                }
+                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {  // pixel i, channel c8: tile row 4 i + c8, (row >> 3) & 3 = (i >> 1) & 3
+                    const unsigned u = (ww[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    tile[4 * i + c8][(((s >> 3) ^ ((i >> 1) & 3)) << 3) | (s & 7)] = (unsigned short)(__float_as_uint((float)u) >> 16);  // exact
+                }
+            }
+        } else {
             const int s = t >> 3, c8 = t & 7, bg = bb * 32 + s;
             const long e8 = e0 + c8 * 8;
             unsigned u[8];
@@ -110,8 +136,9 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a) {
 
 }  // namespace
 
-int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q) {
-    hipLaunchKernelGGL(k_stage, dim3((unsigned)n_blocks), dim3(256), 0, q, a);
+int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q, const StageSlots* slots) {
+    if (a.frames && slots) hipLaunchKernelGGL((k_stage<true, StageSlots>), dim3((unsigned)n_blocks), dim3(256), 0, q, a, *slots);
+    else hipLaunchKernelGGL((k_stage<false, NoSlots>), dim3((unsigned)n_blocks), dim3(256), 0, q, a, NoSlots{{0}});
     IDQN_HIP_CHECK(hipGetLastError());
     return IDQN_OK;
 }

@@ -329,6 +329,12 @@ struct idqn_handle_s {
     // stride gP = P - w0n), 64 floats reserved for the caller (losses), then [K][w0n] Dense_0/kernel gradients.
     // Two contiguous regions = two collectives in the data-parallel step.  fc: w0n = 0, gP = P.
     long gP = 0, g_w0_begin = 0, g_w0_end = 0, g_w0_base = 0;
+    // replay-sourced step (idqn_learn_on_replay): set for the duration of the call, the staging launch gathers from the ring
+    struct ReplaySrc { const uint8_t* frames; const int32_t* rows; long n_frames, frame_bytes; StageSlots slots; };
+    const ReplaySrc* rp = nullptr;
+    int32_t* rp_action = nullptr;   // [max_batch] scalars of the sampled rows, written by the staging launch
+    float* rp_reward = nullptr;
+    uint8_t* rp_terminal = nullptr;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
     // Overlap of the fused Dense_0 update with the conv backward (cnn_backward): the last n_def update items are deferred
@@ -1192,6 +1198,11 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
     }
     a.n_jobs = nj;
     if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; a.epoch = h->chain_ws; }
+    if (train && h->rp) {
+        a.frames = h->rp->frames; a.rows = h->rp->rows; a.n_frames = h->rp->n_frames; a.frame_bytes = h->rp->frame_bytes;
+        a.act_out = h->rp_action; a.rew_out = h->rp_reward; a.term_out = h->rp_terminal;
+        return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q, &h->rp->slots);
+    }
     static const int part = variant_int("IDQN_STAGE_PART", 0);  // timing experiments only
     if (part == 1) return convp_launch_stage(a, a.n_prep_blocks, q);
     if (part == 2) { const int np = a.n_prep_blocks; a.n_prep_blocks = 0; (void)np; return convp_launch_stage(a, (int)blocks, q); }
@@ -2244,7 +2255,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         // can be replayed as ONE hipGraph (opt-in).  The first call of a key runs eagerly (it builds the launch plans, which
         // allocate), the second is captured on the handle's private stream, every call from then on is one graph launch.
         static const bool step_graph = getenv("IDQN_STEP_GRAPH") && atoi(getenv("IDQN_STEP_GRAPH")) != 0;
-        if (step_graph && flags == 0) {
+        if (step_graph && flags == 0 && !h->rp) {  // (a replay-sourced step carries its slots as kernel arguments: not replayable)
             auto key = std::make_tuple(state_dev, next_state_dev, (const void*)action_dev, (const void*)reward_dev,
                                        (const void*)terminal_dev, (int)batch, (int)batch_mean_divisor,
                                        (const void*)h->is_weight, (const void*)h->td_abs);
@@ -2376,6 +2387,39 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     return IDQN_OK;
 }
 }  // namespace
+
+// iDQN.update_online_params (idqn.py:65-72) on the HBM frame ring: replay_buffer.py:215-230's sample() fused into the step
+extern "C" int idqn_learn_on_replay(idqn_handle_t h, const uint8_t* frame_ring_dev, int64_t n_frames, int64_t frame_bytes,
+                                    const int32_t* rows_dev, const int32_t* slots_host, int32_t batch, int32_t stack,
+                                    int32_t batch_mean_divisor, uint32_t flags, void* stream) {
+    IDQN_REQUIRE(h && frame_ring_dev && rows_dev && slots_host, "idqn_learn_on_replay: null pointer");
+    IDQN_REQUIRE(h->cfg.arch == IDQN_ARCH_CNN && h->planes && !h->gc.on, "idqn_learn_on_replay: needs the cnn arch on the plane conv path");
+    IDQN_REQUIRE(batch >= 1 && batch <= 256 && batch <= h->cfg.max_batch, "idqn_learn_on_replay: batch %d not in [1, min(256, %d)]", batch,
+                 h->cfg.max_batch);
+    IDQN_REQUIRE(stack == 4 && h->cfg.obs_c == 4 && frame_bytes == (int64_t)h->cfg.obs_h * h->cfg.obs_w && frame_bytes % 16 == 0 &&
+                     n_frames >= 1 && ((uintptr_t)frame_ring_dev & 15) == 0,
+                 "idqn_learn_on_replay: built for uint8 frames of obs_h x obs_w bytes (a multiple of 16), stack 4 == obs_c (got stack %d, "
+                 "frame_bytes %ld, obs %d x %d x %d)", stack, (long)frame_bytes, h->cfg.obs_h, h->cfg.obs_w, h->cfg.obs_c);
+    IDQN_REQUIRE(!(flags & (IDQN_F_STOP_AFTER_DENSE0 | IDQN_F_STOP_BEFORE_DENSE0_WGRAD)), "idqn_learn_on_replay: the IDQN_F_STOP_* flags are not supported");
+    if (!h->rp_action) {
+        const int mb = h->cfg.max_batch;
+        float* f = nullptr;
+        int rc = alloc_zero(&f, 3L * mb + 64, h, "replay scalars");
+        if (rc) return rc;
+        IDQN_HIP_CHECK(hipStreamSynchronize(nullptr));  // (the zero-fill runs on the null stream)
+        h->rp_action = (int32_t*)f; h->rp_reward = f + mb; h->rp_terminal = (uint8_t*)(f + 2L * mb);
+    }
+    idqn_handle_s::ReplaySrc src;
+    src.frames = frame_ring_dev; src.rows = rows_dev; src.n_frames = n_frames; src.frame_bytes = frame_bytes;
+    memset(&src.slots, 0, sizeof(src.slots));
+    memcpy(src.slots.slot, slots_host, (size_t)batch * 4);
+    h->rp = &src;
+    // (the state pointers only select the staging path; the replay source replaces them)
+    const int rc = idqn_learn_on_batch(h, frame_ring_dev, frame_ring_dev, h->rp_action, h->rp_reward, h->rp_terminal, batch, batch_mean_divisor,
+                                       flags, stream);
+    h->rp = nullptr;
+    return rc;
+}
 
 extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
                                        const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
@@ -2785,6 +2829,7 @@ static int act_host_impl(idqn_handle_t h, int32_t which, int32_t head, const voi
         IDQN_HIP_CHECK(hipHostGetDevicePointer((void**)&h->act_mail_dev, h->act_mail, 0));
         IDQN_HIP_CHECK(hipMalloc((void**)&h->act_seq, 4));
         IDQN_HIP_CHECK(hipMemset(h->act_seq, 0, 4));
+        IDQN_HIP_CHECK(hipStreamSynchronize(nullptr));  // (the memset runs on the null stream, which does not order against qs)
         h->owned.push_back((void*)h->act_seq);
     }
     auto issue = [&](hipStream_t qs) -> int {

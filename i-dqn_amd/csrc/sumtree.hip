@@ -22,7 +22,7 @@ void idqn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* idqn_last_error(void) { return g_err; }
-extern "C" int idqn_abi_version(void) { return 3; }  // 2: idqn_config_t.n_quantiles, the i-IQN entry points; 3: sumtree_query_host(n_live), the idqn_dp_* family
+extern "C" int idqn_abi_version(void) { return 4; }  // 2: idqn_config_t.n_quantiles, the i-IQN entry points; 3: sumtree_query_host(n_live), the idqn_dp_* family; 4: idqn_learn_on_replay
 
 #define ST_THREADS 1024
 #define ST_MAX_N 4096
@@ -532,6 +532,9 @@ extern "C" int sampler_mailbox_create(int32_t max_n, void** mailbox_out) {
     if (e == hipSuccess) { memset(mb->host, 0, bytes); e = hipHostGetDevicePointer((void**)&mb->dev, mb->host, 0); }
     if (e == hipSuccess) e = hipMalloc((void**)&mb->ctl, 64);
     if (e == hipSuccess) e = hipMemset(mb->ctl, 0, 64);
+    // hipMemset of device memory returns before it has run, and the null stream does not order against the (non-blocking)
+    // stream of the first query: on an idle stream of its own that launch started before the counters were zero
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         if (mb->ctl) (void)hipFree(mb->ctl);
         if (mb->host) (void)hipHostFree(mb->host);
@@ -583,6 +586,7 @@ extern "C" int sumtree_query_host(const double* nodes_dev, int32_t depth, const 
         unsigned ctl_now[2] = {0, 0};
         (void)hipMemcpy(ctl_now, mb->ctl, 8, hipMemcpyDeviceToHost);
         (void)hipMemset(mb->ctl, 0, 64);
+        (void)hipStreamSynchronize(nullptr);
         IDQN_REQUIRE(false, "sumtree_query_host: the launch finished without delivering its results (stream query: %s, mailbox seq %u, wanted %u, "
                             "arrivals %u of %d)", hipGetErrorName(qe), *seqp, want, ctl_now[0], n);
     }

@@ -47,6 +47,7 @@ SYMBOLS = {
     "idqn_create": (C.c_int, [C.POINTER(Config), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "idqn_destroy": (C.c_int, [_P]),
     "idqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "idqn_learn_on_replay": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _P]),
     "idqn_iqn_learn_on_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_uint32, _P]),
     "idqn_iqn_q_values": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
     "idqn_backward_rest": (C.c_int, [_P, _P]),

@@ -7,6 +7,8 @@ pytrees of VIEWS into them with the flax leaf names of the reference
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -200,6 +202,35 @@ class DeviceAgent:
         B, ptrs = self._prepare(batch)
         _hip.check(_hip.lib().idqn_learn_on_batch(self._handle, *ptrs, B, int(mean_divisor or B), int(flags),
                                                   _hip.current_stream()), "idqn_learn_on_batch")
+        return self._losses
+
+    # ``update_online_params`` = ``replay_buffer.sample()`` + ``learn_on_batch`` (idqn.py:65-72, dqn.py:41-47).  On this package's
+    # ReplayBuffer with Atari-shaped uint8 frames the two halves are ONE C call (``idqn_learn_on_replay``): the sampler draws the
+    # same keys from the same generator, the stacked gather happens inside the step's staging launch and the minibatch is never
+    # materialised.  Anything else (other buffers, shapes, the f32 conv mode) samples, gathers and learns as two calls.
+    fuse_replay_sampling = True
+
+    def _sample_and_learn(self, replay_buffer):
+        rb = replay_buffer
+        if not (self.fuse_replay_sampling and type(self)._learn is DeviceAgent._learn and self._arch == "cnn" and hasattr(rb, "sample_slots") and hasattr(rb, "ring_view")
+                and getattr(self, "_replay_fused_ok", True) and rb._batch_size <= 256 and os.environ.get("IDQN_LEARN_ON_REPLAY", "1") != "0"):
+            return self._learn(rb.sample())
+        slots = rb.sample_slots()
+        frames, n_frames, frame_bytes, rows, stack, fshape, fdt = rb.ring_view()
+        if not (stack == 4 and self._obs[2] == 4 and tuple(fshape) == tuple(self._obs[:2]) and np.dtype(fdt) == np.uint8 and frame_bytes % 16 == 0):
+            self._replay_fused_ok = False
+            return self._learn(rb._gather(slots))
+        B = int(slots.size)
+        self._ensure_handle(B)
+        slots = np.ascontiguousarray(slots, np.int32)
+        rc = _hip.lib().idqn_learn_on_replay(self._handle, _hip.ptr(frames), int(n_frames), int(frame_bytes), _hip.ptr(rows),
+                                             slots.ctypes.data, B, int(stack), B, 0, _hip.current_stream())
+        if rc == _hip.E_INVALID and self.__dict__.get("_replay_fused_ok") is None:
+            # this handle runs another conv path (IDQN_CONV=f32 / the general shapes): same slots, two calls, from now on
+            self._replay_fused_ok = False
+            return self._learn(rb._gather(slots))
+        _hip.check(rc, "idqn_learn_on_replay")
+        self._replay_fused_ok = True
         return self._losses
 
     def _local_target_update(self):

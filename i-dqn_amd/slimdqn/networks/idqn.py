@@ -40,7 +40,7 @@ class iDQN(DeviceAgent):
 
     def update_online_params(self, step: int, replay_buffer) -> None:
         if step % self.update_to_data == 0:
-            self.learn_on_batch(self.params, self.target_params, self.optimizer_state, replay_buffer.sample())
+            self._sample_and_learn(replay_buffer)  # = learn_on_batch(.., replay_buffer.sample()), one C call where it can be
 
     def learn_on_batch(self, params, params_target, optimizer_state, batch_samples):
         """idqn.py:96-109.  The three state arguments must be this agent's own (in-place update)."""

@@ -443,12 +443,23 @@ class ReplayBuffer:
                              is_terminal=DevArray(e.is_terminal.tensor.clone()), episode_end=DevArray(e.episode_end.tensor.clone()))
 
     def sample(self, size=None) -> ReplayElement:
+        return self._gather(self.sample_slots(size))
+
+    def sample_slots(self, size=None) -> np.ndarray:
+        """The first half of ``sample()`` (``:215-222``): the sampler's draw, as element slots (int32, host).  ``_gather(slots)``
+        is the second half; an agent that fuses the gather into its gradient step (``idqn_learn_on_replay``) takes the slots and
+        ``ring_view()`` instead -- same keys from the same generator stream either way."""
         self.flush_deferred()
         assert self.add_count, ValueError("No samples in replay buffer!")
         if size is None:
             size = self._batch_size
         keys = self._sampling_distribution.sample(size)
-        return self._gather((np.asarray(keys, np.int64) % self._max_capacity).astype(np.int32))
+        return (np.asarray(keys, np.int64) % self._max_capacity).astype(np.int32)
+
+    def ring_view(self):
+        """``(frames, n_frames, frame_bytes, rows, stack, frame_shape, dtype)`` of the device store, element rows flushed."""
+        self._flush_meta()
+        return self._frames, self._n_frames, self._frame_bytes, self._meta_dev, self._stack_size, self._frame_shape, self._obs_dtype
 
     def update(self, keys, **kwargs: Any) -> None:
         self.flush_deferred()

@@ -119,6 +119,19 @@ int idqn_iqn_q_values(idqn_handle_t h, int32_t which, int32_t head, const void* 
 int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const void* next_state_dev,
                         const int32_t* action_dev, const float* reward_dev, const uint8_t* terminal_dev,
                         int32_t batch, int32_t batch_mean_divisor, uint32_t flags, void* stream);
+/* iDQN.update_online_params (idqn.py:65-72) = ReplayBuffer.sample() (replay_buffer.py:215-230) + learn_on_batch, as ONE call on
+ * the HBM frame ring: the stacked gather of replay_gather_stacked (frames of `stack` consecutive transitions, zero frames before
+ * an episode start, replay_buffer.py:119-137,223-229) happens inside the step's staging launch, so the sampled minibatch is
+ * never materialised and the slots travel as kernel arguments -- no upload, no gather launch.  Same arithmetic and the same
+ * results, bit for bit, as replay_gather_stacked followed by idqn_learn_on_batch on its outputs.
+ *   frame_ring_dev  uint8 [n_frames][frame_bytes]          (replay_add_frame)
+ *   rows_dev        int32 [capacity][8] element rows       (replay_gather_stacked documents the row)
+ *   slots_host      int32 [batch] sampled element slots (= key % capacity), HOST memory, read before the call returns
+ * Restrictions (IDQN_ERR_INVALID otherwise; callers then gather and call idqn_learn_on_batch): cnn arch on the plane conv
+ * path, uint8 frames with frame_bytes == obs_h * obs_w and a multiple of 16, stack == obs_c == 4, batch <= 256.            */
+int idqn_learn_on_replay(idqn_handle_t h, const uint8_t* frame_ring_dev, int64_t n_frames, int64_t frame_bytes,
+                         const int32_t* rows_dev, const int32_t* slots_host, int32_t batch, int32_t stack,
+                         int32_t batch_mean_divisor, uint32_t flags, void* stream);
 /* Data-parallel overlap: with IDQN_F_STOP_AFTER_DENSE0 (implies gradients only) idqn_learn_on_batch returns
  * once the Dense_0 weight gradient -- 98 % of the gradient bytes, produced first in the backward pass -- is queued;
  * the caller starts all-reducing that slice (RCCL, async) and calls idqn_backward_rest for the conv backward,

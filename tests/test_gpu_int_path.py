@@ -409,3 +409,40 @@ def test_prioritized_traces_with_a_gradient_step_in_flight(pi):
     torch.cuda.synchronize()
     assert np.isfinite(agent._losses.cpu().numpy()).all()
     assert overlapped[1] > 0 and overlapped[0] >= 0.8 * overlapped[1], overlapped
+
+
+@pytest.mark.parametrize("sampler_kind,B", [("uniform", 32), ("uniform", 96), ("prioritized", 32)])
+def test_learn_on_replay_is_sample_then_learn(sampler_kind, B):
+    """`update_online_params` (idqn.py:65-72) as ONE call on the frame ring (idqn_learn_on_replay: the stacked gather inside the
+    step's staging launch, slots as kernel arguments) against its two halves -- `replay_buffer.sample()` then
+    `learn_on_batch`: the same keys from the same generator, and parameters, optimizer state and losses equal BIT for bit
+    after several steps, episode starts (zero frames) and ring wrap included."""
+    import torch
+
+    from slimdqn.networks.idqn import iDQN
+
+    SumTree, Uniform, Prioritized, ReplayBuffer, Transition = _classes()
+    obs, A, K, feats = (84, 84, 4), 6, 2, [32, 64, 64, 512]
+
+    def make():
+        sampler = Uniform(5) if sampler_kind == "uniform" else Prioritized(5, 4096, 0.7)
+        rb = ReplayBuffer(sampler, batch_size=B, max_capacity=300, stack_size=4, update_horizon=2, gamma=0.99)
+        rng = np.random.default_rng(9)
+        for i in range(700):  # more transitions than the ring holds: slots and frames have wrapped
+            tr = Transition(rng.integers(0, 256, (84, 84), dtype=np.uint8), int(rng.integers(A)), float(rng.normal()),
+                            bool(i % 37 == 36), bool(i % 91 == 90))
+            rb.add(tr, **({"priority": float(rng.random() + 0.1)} if sampler_kind == "prioritized" else {}))
+        rb.reuse_sample_buffers = True
+        return rb, iDQN(0, obs, A, K, feats, "cnn", 6.25e-5, 0.99, 2, 1, 10**9, 10**9, adam_eps=1.5e-4)
+
+    rb_a, agent_a = make()
+    rb_b, agent_b = make()
+    agent_b.fuse_replay_sampling = False
+    for step in range(4):
+        agent_a.update_online_params(step, rb_a)
+        agent_b.update_online_params(step, rb_b)
+    torch.cuda.synchronize()
+    assert agent_a.__dict__.get("_replay_fused_ok") is True, "the fused path did not run"
+    for name in ("_online", "_mu", "_nu", "_losses", "_cum"):
+        np.testing.assert_array_equal(getattr(agent_a, name).cpu().numpy(), getattr(agent_b, name).cpu().numpy(), err_msg=name)
+    assert rb_a._sampling_distribution._rng_key.bit_generator.state == rb_b._sampling_distribution._rng_key.bit_generator.state
