@@ -52,6 +52,18 @@ def synthetic(seed, n_actions=N_ACTIONS, batch=BATCH):
     return s, a, r, s2, t
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (i-dqn_amd/csrc/*, include/*.h: names and contents, sorted): what a PMC summary is valid for."""
+    import glob
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "i-dqn_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()
+
+
 def step_work(K, B, A):
     """Whole-step algorithmic work: FLOPs = K B (2 F_fwd + F_bwd), bytes = K 7 4 P + 2 B 28224 + 9 B."""
     macs = 3612672 + 3964928 + 4460544 + 3964928 + 512 * A
@@ -473,13 +485,31 @@ def main():
         else:
             data_parallel_step(agent, batch, global_batch, extra_flags=flags, mode=dp_mode, streams=args.dp_streams)
 
-    for _ in range(args.warmup):
-        step()
-
     def barrier():
         if dp:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # data-parallel runs: the SAME rank's plain single-GPU step (no collective, no factor exchange) timed first, so that the line
+    # can say what N ranks cost relative to one -- t(1) / t(N) at fixed per-rank work -- instead of leaving it to a second run
+    single_ms = None
+    if dp:
+        for _ in range(20):
+            agent._learn(batches[0])
+        t1s = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(100):
+                agent._learn(batches[i % len(batches)])
+            torch.cuda.synchronize()
+            t1s.append((time.perf_counter() - t0) / 100)
+        t1 = torch.tensor([float(np.median(t1s))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        single_ms = float(t1.item()) * 1e3
+
+    for _ in range(args.warmup):
+        step()
 
     # `repeats` timed regions of EXACTLY `steps` steps each, barrier + synchronize on both sides, max over ranks;
     # the reported region is the median one.  Short regions (the driver's --steps 20 is 5.6 ms of GPU time) are repeated until
@@ -546,11 +576,18 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
             if headline and not dp:
-                traffic = pmc["hbm_bytes_per_launch"]
-                step_traffic = pmc.get("step_hbm_bytes")
-                traffic_source = f"profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes, library {pmc.get('git', '?')}; not this run)"
-        except Exception:
-            pass
+                # the passes are a separate run (counters cannot ride on the timed run): their figures stand only for the kernel
+                # sources they were collected on -- any other csrc/ digest and the line says so instead of quoting them
+                if pmc.get("csrc_sha256") == csrc_digest():
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    step_traffic = pmc.get("step_hbm_bytes")
+                    traffic_source = (f"profiles/pmc_traffic_latest.json (separate rocprofv3 --pmc passes on these kernel sources, csrc digest "
+                                      f"{pmc['csrc_sha256'][:12]}, library {pmc.get('git', '?')}; not this run)")
+                else:
+                    traffic_source = (f"null: profiles/pmc_traffic_latest.json was collected on other kernel sources (csrc digest "
+                                      f"{str(pmc.get('csrc_sha256'))[:12]} vs {csrc_digest()[:12]} here): re-run tools/gpu_pmc.sh + tools/pmc_summarise.py")
+        except Exception as e:  # noqa: BLE001
+            traffic_source = f"null: {type(e).__name__}: {e}"
         step_flops, step_bytes = step_work(K, B, A)
         ms_step = elapsed / args.steps * 1e3
         out = {
@@ -598,6 +635,17 @@ def main():
         }
         if dp:
             out["rccl"] = rccl_report(dp_mode, world, agent, args.dp_streams or os.environ.get("IDQN_DP_STREAMS", "side"))
+            # `value` counts every rank's 32-sample step (weak scaling: N ranks = N x the samples per global step), so it grows
+            # with N by definition.  What N ranks buy is in these four, none of which does:
+            out["data_parallel"] = {
+                "per_rank_ms_per_step": ms_step,                       # one global step = one step on every rank, max over ranks
+                "global_steps_per_s": 1e3 / ms_step,                   # optimizer updates per second (global batch B x N each)
+                "samples_per_s": global_batch * 1e3 / ms_step,
+                "rank_steps_per_s": args.steps * world / elapsed,      # = value
+                "single_gpu_ms_per_step": single_ms,                   # the plain step on the same ranks, same run (max over ranks)
+                "scaling_efficiency": (single_ms / ms_step) if single_ms else None,  # t(1) / t(N) at fixed per-rank work
+                "what": "weak scaling: per-rank batch fixed at %d, global batch %d; efficiency 1.0 = the N-rank step costs what the "
+                        "single-GPU step costs" % (B, global_batch)}
         if headline and not dp and not args.no_side_legs:
             try:
                 out["sampling"] = sampling_leg()

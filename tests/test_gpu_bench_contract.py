@@ -41,6 +41,8 @@ def test_default_line_has_the_contract_fields_and_consistent_arithmetic():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
     assert 0.2 < r["frac"] < 1.0  # an HBM-bound kernel on an MI355X, whatever the box
     assert r["launch_ms"] < d["ms_per_step"]
+    # PMC traffic comes from separate passes: quoted only for the kernel sources it was collected on, else null with the reason
+    assert (r["traffic"] is None and r["traffic_source"].startswith("null:")) or (r["traffic"] > 0 and "csrc digest" in r["traffic_source"])
     assert {"gather_B32", "sumtree_B32", "prioritized_protocol"} <= set(d["sampling"])
     names = [k["launch"] for k in d["kernels"]]
     assert any("dense0 wgrad" in n for n in names) and not any("finalize" in n for n in names)  # the pair kernel finishes dL/da3 itself
@@ -70,3 +72,19 @@ def test_cpu_baseline_object():
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["gpu_over_cpu"] > 10
+
+
+def test_data_parallel_line_separates_rank_steps_from_global_steps():
+    """The N > 1 line (rehearsed with one rank over RCCL): `value` counts rank-steps, so the line also carries the global step rate,
+    the per-rank step time and t(1) / t(N) measured in the same run -- and RCCL's own log excerpt."""
+    d = _bench("--gpus", "1", "--force-dp", "--steps", "8", "--warmup", "2", "--repeats", "3")
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp1"
+    p = d["data_parallel"]
+    assert abs(p["per_rank_ms_per_step"] - d["ms_per_step"]) <= 1e-9
+    assert abs(p["global_steps_per_s"] - 1e3 / d["ms_per_step"]) <= 1e-6 * p["global_steps_per_s"]
+    assert abs(p["rank_steps_per_s"] - d["value"]) <= 1e-9 and abs(p["rank_steps_per_s"] - d["n_gpus"] * p["global_steps_per_s"]) <= 1e-6 * d["value"]
+    assert abs(p["samples_per_s"] - d["config"]["global_batch"] * p["global_steps_per_s"]) <= 1e-6 * p["samples_per_s"]
+    assert p["single_gpu_ms_per_step"] > 0 and abs(p["scaling_efficiency"] - p["single_gpu_ms_per_step"] / d["ms_per_step"]) <= 1e-9
+    assert 0.5 < p["scaling_efficiency"] <= 1.05  # one rank: the data-parallel schedule costs its factor exchange, nothing else
+    assert "debug_excerpt" in d["rccl"]
+    assert "cpu_baseline" not in d  # rank 0 of a single-GPU run only

@@ -47,7 +47,10 @@ if dom:
     steps = out[dom[0]]["launches"]
     step_kernels = {k: e for k, e in out.items() if "hbm_bytes" in e and not any(x in k for x in ("k_act_", "k_sumtree", "k_replay", "k_per_", "k_sampler", "k_argmax"))}
     step_bytes = sum(e["hbm_bytes"] * e["launches"] / steps for e in step_kernels.values())
-    json.dump({"kernel": dom[0], "git": git, "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    json.dump({"kernel": dom[0], "git": git, "csrc_sha256": bench.csrc_digest(), "hbm_bytes_per_launch": out[dom[0]]["hbm_bytes"],
                "step_hbm_bytes": step_bytes, "step_kernels": {k: round(e["hbm_bytes"] * e["launches"] / steps) for k, e in sorted(step_kernels.items())},
                "read": out[dom[0]]["hbm_read_bytes"], "write": out[dom[0]]["hbm_write_bytes"],
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
