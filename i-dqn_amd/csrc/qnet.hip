@@ -21,6 +21,7 @@
 #include "act_kernels.h"
 #include "cnn_kernels.h"
 #include "fc_kernels.h"
+#include "fc_par_kernels.h"
 #include "iqn_kernels.h"
 #include "gcnn_kernels.h"
 #include "dp_internal.h"
@@ -316,6 +317,7 @@ struct idqn_handle_s {
     FcPlan fc_plan_;  // LDS plan of k_fc_step_lds (BS = 0: the net does not fit and the generic kernel runs)
     FcMfmaPlan fcm_plan_;  // LDS plan of k_fc_step_mfma (floats = 0: neither the staged-weights nor the global-weights layout fits)
     bool fcm_global_ = false;  // the plan is fc_mfma_plan_g: weight operands from global memory
+    FcParPlan fcp_plan_;  // LDS plan of k_fc_step_par (floats = 0: does not fit); batches of <= 32 samples run it
     // timeline of a whole step (IDQN_F_PROFILE_ALL): one event after every launch; idqn_profile_table averages per name
     std::vector<hipEvent_t> tl_ev;
     std::vector<const char*> tl_name;
@@ -816,6 +818,13 @@ int fc_setup(idqn_handle_s* h) {
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
+    h->fcp_plan_ = fc_par_plan(n, h->L.head_stride);
+    // IDQN_FC_PAR=0: the two-launch path (k_fc_step_mfma / k_fc_step_lds + k_adam) for every batch size
+    if ((getenv("IDQN_FC_PAR") && atoi(getenv("IDQN_FC_PAR")) == 0) || variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") ||
+        n.dmax > FC_MAX_WIDTH)
+        h->fcp_plan_.floats = 0;
+    if (h->fcp_plan_.floats)
+        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->fcp_plan_.floats * 4)));
     h->fcm_plan_ = fc_mfma_plan(n);
     if (variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
     h->fcm_global_ = false;
@@ -2304,7 +2313,10 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         const FcPlan& fp = h->fc_plan_;
         const size_t lds = (size_t)fp.floats * 4;
         const FcMfmaPlan& fm = h->fcm_plan_;
-        if (fm.floats && h->fcm_global_) hipLaunchKernelGGL(k_fc_step_mfma<true>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
+        const bool par = h->fcp_plan_.floats && batch <= 32;  // one launch: forwards side by side, Adam in the gradient epilogues
+        if (par) hipLaunchKernelGGL(k_fc_step_par, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)h->fcp_plan_.floats * 4, q, a, h->fcp_plan_, h->ad,
+                                    h->online, h->mu, h->nu, grads_only ? 0 : 1, variant_on("IDQN_FC_PROF") ? 1 : 0);
+        else if (fm.floats && h->fcm_global_) hipLaunchKernelGGL(k_fc_step_mfma<true>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
         else if (fm.floats) hipLaunchKernelGGL(k_fc_step_mfma<false>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
         else if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
         else if (fp.BS == 16) hipLaunchKernelGGL(k_fc_step_lds<16>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
@@ -2315,7 +2327,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             h->ev_used += 2;
         }
         IDQN_HIP_CHECK(hipGetLastError());
-        if (!grads_only && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
+        if (!grads_only && !par && (rc = launch_adam(h, 0, h->L.head_stride, 0, 0, false, q))) return rc;
     }
     return IDQN_OK;  // count += 1 and cum_losses += losses already happened in k_td_dh / k_fc_step (fused path)
 }
