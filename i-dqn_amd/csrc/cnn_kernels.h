@@ -356,17 +356,6 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
     long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // (4 waves per workgroup; fewer when the launch has too few items to put one workgroup on every CU otherwise)
     int jt, s;
-#ifdef IDQN_VARIANTS
-    if (a.G == 4) {  // workgroup = (net, block, group of 4 splits, column tile); wave = split inside the group
-        item = (long)blockIdx.x;
-        if (item * 4 >= a.n_items) return;
-        jt = (int)(item % a.n_jt);
-        item /= a.n_jt;
-        const int nsg = a.NS / 4;
-        s = (int)(item % nsg) * 4 + wave;
-        item /= nsg;
-    } else
-#endif
     {
         if (item >= a.n_items) return;
     }
@@ -520,93 +509,6 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
 #undef D3_MMA_A
 #undef D3_GETX
 #undef D3_MMA
-#ifdef IDQN_VARIANTS
-    if (a.G == 4) {
-        // the four splits of the group meet in LDS and are added in split order, ((s0 + s1) + s2) + s3 -- a fixed order, so
-        // the step stays bit-reproducible.  Element (tile q, register r, lane) of a wave's accumulators is column
-        // 4 * mfma_row(r, lane >> 5) + q, sample lane & 31: four consecutive lanes are 16 contiguous bytes of the slab.
-        const int t = threadIdx.x, nsg = a.NS / 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d3_red[((wave * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
-        __syncthreads();
-        const long slot = (long)n * a.nb + bb;
-        float* P = a.part + ((slot * nsg + s / 4) * a.J + jt * 128) * 32;
-        const bool fuse = a.arrive != nullptr;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int f = t + 256 * m;  // float4 index: (q, r) = f / 16, lanes 4 (f % 16) .. + 3
-            const int qr = f >> 4, l4 = (f & 15) * 4, q = qr >> 4, r = qr & 15;
-            const float* x = d3_red + qr * 64 + l4;
-            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(x), v1 = *reinterpret_cast<const f32x4v*>(x + 4 * 16 * 64);
-            const f32x4v v2 = *reinterpret_cast<const f32x4v*>(x + 2 * 4 * 16 * 64), v3 = *reinterpret_cast<const f32x4v*>(x + 3 * 4 * 16 * 64);
-            const f32x4v v = ((v0 + v1) + v2) + v3;
-            float* dst = P + (4 * mfma_row(r, l4 >> 5) + q) * 32 + (l4 & 31);
-            if (fuse) store16_sc1(dst, __builtin_bit_cast(u32x4, v));  // handed to another workgroup inside this launch
-            else *reinterpret_cast<f32x4v*>(dst) = v;
-        }
-        if (!fuse) return;
-        // ---- arrival: every storing wave has drained, ONE lane adds; the last arriver takes the tile's head stage --------
-        int* last_flag = reinterpret_cast<int*>(d3_red + 4 * 4 * 16 * 64);  // (behind the 64 KB: a static would shift the dynamic base off 16 bytes)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* ctr = a.arrive + slot * a.n_jt + jt;
-        if (t == 0) {
-            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == (unsigned)nsg - 1u;
-            if (last) {
-                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            *last_flag = last;
-        }
-        __syncthreads();
-        if (!*last_flag) return;
-        // ---- k_hidden's work for hidden units [jt * 128, jt * 128 + 128) of (net n, block bb) -------------------------------
-        float* hs = d3_red;              // [128][33]
-        float* w1s = d3_red + 128 * 33;  // [128][A]
-        const float* p = a.wbase[n];
-        {
-            const float* w1 = p + a.w1_off + (long)jt * 128 * a.A;
-            for (int e = t; e < 128 * a.A; e += 256) w1s[e] = w1[e];
-        }
-        const float* part = a.part + (slot * nsg * a.J + jt * 128) * 32;
-        const long sstride = (long)a.J * 32;
-        float* hb = a.hbuf + (slot * a.J + jt * 128) * 32;
-        const int jl = t >> 3, l8 = t & 7;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int j = jl + 32 * it;
-            const float bias = p[a.b0_off + jt * 128 + j];
-            float4 sv = make_float4(bias, bias, bias, bias);
-            const float* pr = part + (long)j * 32 + 4 * l8;
-            for (int sp = 0; sp < nsg; sp += 16) {  // the slabs in slab order, 16 per round in flight (as k_hidden)
-                float4 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    v[u] = sp + u < nsg ? *reinterpret_cast<const float4*>(pr + (sp + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (sp + u < nsg) { sv.x += v[u].x; sv.y += v[u].y; sv.z += v[u].z; sv.w += v[u].w; }
-            }
-            sv.x = fmaxf(sv.x, 0.f); sv.y = fmaxf(sv.y, 0.f); sv.z = fmaxf(sv.z, 0.f); sv.w = fmaxf(sv.w, 0.f);
-            hs[j * 33 + 4 * l8 + 0] = sv.x; hs[j * 33 + 4 * l8 + 1] = sv.y; hs[j * 33 + 4 * l8 + 2] = sv.z; hs[j * 33 + 4 * l8 + 3] = sv.w;
-            *reinterpret_cast<float4*>(hb + (long)j * 32 + 4 * l8) = sv;
-        }
-        __syncthreads();
-        const int b = t & 31, jj = t >> 5;
-        for (int c = 0; c < 4; ++c)
-            for (int ac = jj; ac < a.A; ac += 8) {
-                float s_ = 0.f;
-#pragma unroll
-                for (int r = 0; r < 32; ++r) s_ = fmaf(hs[(c * 32 + r) * 33 + b], w1s[(c * 32 + r) * a.A + ac], s_);
-                a.qpart[((slot * (a.J / 32) + jt * 4 + c) * 32 + ac) * 32 + b] = s_;
-            }
-        return;
-    }
-#endif
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
     if (ABL & 2) {  // keep the accumulators alive, store one value per wave
         float t_ = 0.f;
@@ -644,118 +546,6 @@ __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
 // -- and the threaded split: with every window of W serving several blocks the waves are bound by their own issue, not by the stream
 __global__ __launch_bounds__(256) void k_dense0_fwd3b(DenseFwdArgs a) { dense0_fwd3_body<4, false, 0, false, false>(a); }
 
-#ifdef IDQN_VARIANTS
-// the same with three k-steps in flight per lane at two waves per SIMD (IDQN_D0_OCC2=1 with IDQN_D0_SPLITS=50: two 4-wave
-// workgroups per CU): the experiment behind DESIGN.md section 3.2's "a CU is the unit of streaming bandwidth"
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense0_fwd3o(DenseFwdArgs a) { dense0_fwd3_body<3, true>(a); }
-// ... with the W split of tile q + 1 threaded by hand between the products of tile q (IDQN_D0_FWD_THREAD=1): 40 % fewer issue cycles
-// per k-step, the same duration -- the arithmetic is hidden under the stream either way (profiles/r5_d0fwd_ablations.txt)
-__global__ __launch_bounds__(256) void k_dense0_fwd3t(DenseFwdArgs a) { dense0_fwd3_body<4, false>(a); }
-// timing ablations of the forward inside the step (IDQN_D0_FWD_ABL = 1 / 2 / 4 / 8 / 6 / 7; results are WRONG)
-template <int ABL>
-__global__ __launch_bounds__(256) void k_dense0_fwd3a(DenseFwdArgs a) { dense0_fwd3_body<4, true, ABL>(a); }
-// the plain schedule with the wide activation loads (IDQN_D0_FWD_XW=1), and with the partial stores ablated on top (=2)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense0_fwd3x(DenseFwdArgs a) { dense0_fwd3_body<4, true, 0, true>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense0_fwd3x2(DenseFwdArgs a) { dense0_fwd3_body<4, true, 2, true>(a); }
-
-// k_dense0_fwd3 with the weight stream through LDS-DMA (IDQN_D0_FWD_DMA=1; G = 1 form only).  The register version is bound by how
-// fast a CU streams through global_load_dwordx4 (its loads-only ablation takes the same time); the stand-alone probe
-// (tools/probes/ldsdma_stream_probe.hip) moves the same 158.6 MB at 6.0 - 6.3 TB/s through an LDS-DMA ring against 5.3 TB/s through
-// registers at this kernel's one workgroup per CU.  Every wave owns a ring of four 8 KB slots (one 16-row k-step of its 128
-// columns): eight 1 KB copies per k-step, lane (h, bl) -> 16 bytes at [jj][h][bl], i.e. exactly the float4 the register version
-// held in wv[jj] -- read back with eight conflict-free ds_read_b128.  The k-step's 2 KB of activations (16 rows x 32 samples,
-// contiguous) take the same way (two copies, a 2 KB slot per wave and ring position), so that ONE counted s_waitcnt (10 copies
-// per k-step, three k-steps ahead: vmcnt(30)) orders everything and no register is written behind hipcc's back.  160 KB of LDS,
-// one workgroup per CU as before.  Same k order, same splits, same product order: bit-identical partials.
-__device__ __forceinline__ void dma16_nt(unsigned voff, unsigned long sbase, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-}
-__global__ __launch_bounds__(256) void k_dense0_fwd3d(DenseFwdArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char d3d_lds[];  // W [wave][slot 0..3][jj 0..7][64 lanes][16 B], then X [wave][slot][16 rows][32]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
-    long item = (long)blockIdx.x * 4 + wave;
-    if (item >= a.n_items) return;  // wave-uniform; no barrier below
-    const int jt = (int)(item % a.n_jt);
-    item /= a.n_jt;
-    const int s = (int)(item % a.NS);
-    item /= a.NS;
-    const int bb = (int)(item % a.nb);
-    const int n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
-    const int NU = a.F / 16, NC = (NU - s + a.NS - 1) / a.NS;  // k-steps of this split (interleaved split-K, as k_dense0_fwd3)
-    const unsigned long step_w = 16UL * a.NS * a.J * 4, step_x = 16UL * a.NS * 32 * 4, row_w = (unsigned long)a.J * 4;  // bytes
-    const unsigned long Wb = (unsigned long)(a.wbase[n] + a.w_off + (long)(16 * s) * a.J + jt * 128);
-    const unsigned long Xb = (unsigned long)(a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(16 * s) * 32);
-    const unsigned voff_w = (unsigned)((8 * h * a.J + 4 * bl) * 4), voff_x = (unsigned)lane * 16;
-    // LDS: per wave four 8 KB weight slots, then (behind the 128 KB of all waves) four 2 KB activation slots
-    const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&d3d_lds[0];
-    const unsigned lds0 = ldsb + (unsigned)wave * 4 * 8192, ldx0 = ldsb + 4 * 4 * 8192 + (unsigned)wave * 4 * 2048;
-    const unsigned char* lw = d3d_lds + wave * 4 * 8192 + lane * 16;
-    const float* lx = reinterpret_cast<const float*>(d3d_lds + 4 * 4 * 8192 + wave * 4 * 2048) + 8 * h * 32 + bl;
-    f32x16 acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-#define D3D_LOAD(c, sl)                                                                                              \
-    {                                                                                                                \
-        const unsigned long wsrc = Wb + (unsigned long)(c) * step_w, xsrc = Xb + (unsigned long)(c) * step_x;        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slot's earlier ds_reads have returned */           \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) dma16_nt(voff_w, wsrc + jj * row_w, lds0 + (sl) * 8192 + jj * 1024); \
-        dma16(voff_x, xsrc, ldx0 + (sl) * 2048);                                                                     \
-        dma16(voff_x, xsrc + 1024, ldx0 + (sl) * 2048 + 1024);                                                       \
-    }
-#define D3D_TILE(q, comp)                                                                      \
-    {                                                                                          \
-        unsigned p0[4], p1[4], p2[4];                                                          \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(wv[2 * m].comp, wv[2 * m + 1].comp, p0[m], p1[m], p2[m]); \
-        const bf16x8 w0 = planes8(p0), w1 = planes8(p1), w2 = planes8(p2);                     \
-        acc[q] = mfma_bf16(w2, x0, acc[q]);                                                    \
-        acc[q] = mfma_bf16(w0, x2, acc[q]);                                                    \
-        acc[q] = mfma_bf16(w1, x1, acc[q]);                                                    \
-        acc[q] = mfma_bf16(w1, x0, acc[q]);                                                    \
-        acc[q] = mfma_bf16(w0, x1, acc[q]);                                                    \
-        acc[q] = mfma_bf16(w0, x0, acc[q]);                                                    \
-    }
-#define D3D_MMA(sl)                                                                            \
-    {                                                                                          \
-        float4 wv[8];                                                                          \
-        float xv[8];                                                                           \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) wv[jj] = *reinterpret_cast<const float4*>(lw + (sl) * 8192 + jj * 1024); \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xv[jj] = lx[(sl) * 512 + jj * 32];    \
-        unsigned q0[4], q1[4], q2[4];                                                          \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) split3_pk(xv[2 * m], xv[2 * m + 1], q0[m], q1[m], q2[m]); \
-        const bf16x8 x0 = planes8(q0), x1 = planes8(q1), x2 = planes8(q2);                     \
-        D3D_TILE(0, x) D3D_TILE(1, y) D3D_TILE(2, z) D3D_TILE(3, w)                            \
-    }
-    // every k-step issues exactly 10 copies (the clamped tail re-requests the last k-step, as the register version does):
-    // with three k-steps requested behind it a k-step's data has arrived at vmcnt(30)
-#define D3D_STEP(u)                                                                            \
-    D3D_LOAD(min(c + (u) + 3, NC - 1), ((u) + 3) & 3)                                          \
-    asm volatile("s_waitcnt vmcnt(30)" ::: "memory");                                          \
-    if (c + (u) < NC) D3D_MMA(u)
-    D3D_LOAD(0, 0)
-    D3D_LOAD(min(1, NC - 1), 1)
-    D3D_LOAD(min(2, NC - 1), 2)
-    for (int c = 0; c < NC; c += 4) {
-        D3D_STEP(0) D3D_STEP(1) D3D_STEP(2) D3D_STEP(3)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail's copies land before the wave may end
-#undef D3D_STEP
-#undef D3D_MMA
-#undef D3D_TILE
-#undef D3D_LOAD
-    float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int i = mfma_row(r, h);
-        P[(4 * i + 0) * 32] = acc[0][r];
-        P[(4 * i + 1) * 32] = acc[1][r];
-        P[(4 * i + 2) * 32] = acc[2][r];
-        P[(4 * i + 3) * 32] = acc[3][r];
-    }
-}
-
-#endif  // IDQN_VARIANTS
 
 // --------------------------------------------------------------------------------------------
 // Head, stage 1 (all 2K nets in parallel): split-K reduce + bias + ReLU -> h, and the per-chunk partial
@@ -1274,16 +1064,6 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
     *reinterpret_cast<u32x4*>(dst + 2 * plane + e * 8) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
 }
 
-#ifdef IDQN_VARIANTS
-// The fused kernel over FULL 512-column rows (NQ = 4, dense width 512): the workgroup then holds the complete data gradient
-// of its 32 rows and finishes it itself (ReLU mask, bf16 planes, per-position sums) -- no partial buffer and no finalize
-// launch.  80 KB of LDS (two workgroups per CU), hence dynamic.
-__global__ __launch_bounds__(256) void k_dense0_wgrad_rows(DenseWgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float gs_dyn[];
-    dense0_wgrad_body<true, 4, true, false>(a, (int)blockIdx.x + a.item0, gs_dyn, (int)threadIdx.x);
-}
-
-#endif
 
 template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1, bool FIN = false>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
@@ -1299,13 +1079,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
     dense0_pair_body<ROWPAIR, 4, TH_ST_NT, ALL_DEFAULT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
-#ifdef IDQN_VARIANTS
-// ... with whole tiles in flight and cross-tile refills (dense0_pair_body<.., 8>): two waves per SIMD
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_dense0_wgrad_pair8(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float gs[32 * 256 + 4096 + 1024];
-    dense0_pair_body<false, 8>(a, (int)blockIdx.x, gs, (int)threadIdx.x);
-}
-#endif
 // The factored data-parallel update with the a3 fragments through LDS (dense0_update.h, ALDS): 48 KB of fragments before the
 // 32 KB tile takes their place; three workgroups per CU like the register version (136 + 32 registers).
 template <int RT, bool TH_ST_NT = true>  // 32 * RT rows x 256 columns

@@ -86,19 +86,18 @@ void idqn_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Run-time switches.  The shipped library (libidqn_hip.so) reads only the few documented in INTEGRATION.md, each with a
-// plain getenv().  The launch structures that rounds 2-4 built to bit-identity and measured neutral or slower
-// (profiles/README.md has their A/B files), the experiment knobs and the debug stamps sit behind variant_env(): it resolves
-// the name only in a -DIDQN_VARIANTS build (libidqn_hip_variants.so, used by tools/ and tests/test_gpu_switches.py); in the
-// default build it is a constant nullptr, the branches fold away, and their kernels (#ifdef IDQN_VARIANTS) are not compiled.
+// Run-time switches.  The shipped library (libidqn_hip.so) reads the few documented in INTEGRATION.md, each with a plain getenv().
+// Debug knobs -- the phase stamps of the conv / MLP kernels (IDQN_CONV_PROF, IDQN_FC_PROF, IDQN_IQN_CLOCK) and the plan overrides
+// of the measurement scripts (IDQN_PP_PARTS<role>, IDQN_PP_RING, IDQN_PAIR_*) -- resolve only in a -DIDQN_DEBUG_KNOBS build
+// (__graft_entry__.build_debug() -> libidqn_hip_debug.so, tools/ only); in the shipped build they are constants and fold away.
 #include <stdlib.h>
-#ifdef IDQN_VARIANTS
-static inline const char* variant_env(const char* name) { return getenv(name); }
+#ifdef IDQN_DEBUG_KNOBS
+static inline const char* debug_env(const char* name) { return getenv(name); }
 #else
-static inline constexpr const char* variant_env(const char*) { return nullptr; }
+static inline constexpr const char* debug_env(const char*) { return nullptr; }
 #endif
-static inline int variant_int(const char* name, int dflt) {
-    const char* e = variant_env(name);
+static inline int debug_int(const char* name, int dflt) {
+    const char* e = debug_env(name);
     return e ? atoi(e) : dflt;
 }
-static inline bool variant_on(const char* name) { return variant_int(name, 0) != 0; }
+static inline bool debug_on(const char* name) { return debug_int(name, 0) != 0; }

@@ -67,25 +67,8 @@ struct CFwdArgs {
     int mask_Wp, mask_lo_h, mask_lo_w, mask_C;
     int f32_W;
     int row_parts;  // persistent kernel (convp_pp.hip) only: > 0 = every output row is cut into this many items (ranges never cross rows)
-    int tune;  // experiment bits (IDQN_CONV_TUNE, variants build; 0 in the shipped library): 1 early kernel copies, 2 nt epilogue stores, 4 loader priority
     CVar var[4];
 };
-
-// ---- hand-offs between the layers of a chained launch (convp_chain.hip) ------------------------------------------
-// One flag word per work item: the producer stores the step's epoch into it once every wave's write-through (sc1)
-// stores of the item have been acknowledged; a consumer item polls the flags of the producer items whose output rows
-// its input rows overlap (one wave, one lane per flag, relaxed agent-scope loads), then ONE agent-scope acquire
-// (cdna_hip_programming.md, Guideline 16 R1).  An item only ever waits on items of an EARLIER layer and every workgroup
-// runs its items layer by layer, all workgroups co-resident (one per CU): no cycle, no deadlock; spins are bounded.
-struct ChainHand {
-    const unsigned* wait_flags;  // producer layer's flags [slot][p_R], or nullptr: the inputs come from an earlier launch
-    unsigned* done_flags;        // this layer's flags [slot][items_per_slot], or nullptr: a LATER launch reads the outputs
-    unsigned* err;               // [0] |= 1 when a bounded spin gave up (the TD kernel then writes NaN losses)
-    int p_OW, p_OH, p_lo_h;      // producer grid (unpadded) and the zero rows in front of it in the buffer
-    int p_R, p_base, p_rem;      // producer ranges per slot: range r = positions [r * base + min(r, rem), ...) (balanced split)
-    int pad0, pad1;
-};
-#define CHAIN_SPIN_LIMIT (1u << 18)
 
 // ---- weight-gradient launch -----------------------------------------------------------------------------------
 struct CWItem {  // one workgroup: positions [p0, p0 + np) of one head, one kernel row (Conv_0: all kernel rows)
@@ -135,7 +118,6 @@ struct StageArgs {
     const int32_t* count;
     float* bcinv;
     float b1, b2;
-    unsigned* epoch;        // chained conv launches: += 1 once per step (first pack block), or nullptr
     // replay-sourced step (idqn_learn_on_replay): the stacked gather happens here.  frames != nullptr: sample b of set
     // (0 state / 1 next_state), channel c = frame ((rows[slot_b][2 set] - (3 - c)) mod n_frames) of the ring, zero where
     // 3 - c >= rows[slot_b][2 set + 1] (frames before the episode start); the scalars of the rows go to act / rew / term
@@ -169,12 +151,6 @@ __device__ __forceinline__ void split3_pk(float v0, float v1, unsigned& q0, unsi
 __device__ __forceinline__ void dma16(unsigned voff, unsigned long sbase, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory", "m0");
-}
-
-// 16-byte write-through store (sc1: the line leaves the XCD's L2 for the memory side at once, no release fence needed
-// before the flag).  hipcc does not count an asm store: the publishing wave drains with s_waitcnt vmcnt(0) itself.
-__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Touch every 64-byte line of the kernel-argument segment with back-to-back scalar loads at kernel entry.  hipcc loads
@@ -246,17 +222,6 @@ int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_
                       const D0Stream* ds = nullptr);
 bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q, const StageSlots* slots = nullptr);
-// the three forward convs of a net set as ONE launch with per-item hand-offs (convp_chain.hip)
-struct CChainArgs {
-    CFwdArgs a[3];
-    ChainHand hand[3];
-    unsigned stage_bytes[3], mask_off[3];
-    int ring[3], n_items[3];
-    const unsigned* epoch;  // device word, bumped once per step by the staging launch
-    long long* prof[3];
-};
-bool convp_chain_fwd_built(const int NT[3]);
-int convp_launch_chain_fwd(const CChainArgs& c, const int NT[3], int n_wg, size_t lds_bytes, hipStream_t q);
 int convp_fwd_max_nt(int CT);
 // persistent form for launches with several items per CU (convp_pp.hip): n_wg workgroups walk n_items items
 bool convp_pp_built(int NPA, int CT, int NQ, int NT);

@@ -50,7 +50,7 @@ int convp_fwd_max_nt(int CT) { return CT == 1 ? 6 : 3; }
 // two stage buffers, behind them the data gradient's mask tiles (2 KB per tile and wave); the epilogue turns every tile
 // around in 10 KB per wave of the (then free) stage buffers
 int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue, size_t budget) {  // three stage buffers when they fit
-    static const int forced = variant_int("IDQN_CONV_RING", 0);
+    static const int forced = (0);
     if (forced == 2 || forced == 3) return forced;
     return 3 * stage_bytes + (epilogue == 1 ? (size_t)4 * NT * 2048 : 0) <= budget ? 3 : 2;
 }

@@ -19,10 +19,6 @@
 #pragma once
 #include "convp.h"
 
-#ifndef CP_ABLATE
-#define CP_ABLATE 0  // timing experiments only (results are wrong): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA in the loop
-#endif
-
 namespace {
 
 
@@ -42,30 +38,10 @@ __device__ __forceinline__ bf16x8 frag_lin(const unsigned char* p) {
     return *(const __attribute__((address_space(3))) bf16x8*)p;
 }
 
-// One wave waits for producer items [lo, hi] of a chained launch (convp.h, ChainHand): lane i polls flag lo + i with
-// relaxed agent-scope loads until all equal the step's epoch, then ONE agent-scope acquire (buffer_inv sc1: this CU's L1)
-// and the wait for it; the workgroup barrier that follows releases the waves that load the handed-off bytes.
-__device__ __forceinline__ void chain_wait(const unsigned* flags, int lo, int hi, unsigned epoch, unsigned* err) {
-    const int lane = threadIdx.x & 63;
-    const bool mine = lo + lane <= hi;
-    bool ok = false;
-    for (unsigned spins = 0; spins < CHAIN_SPIN_LIMIT; ++spins) {
-        const unsigned v = mine ? __hip_atomic_load(flags + lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-        if (__all(v == epoch)) { ok = true; break; }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    if (!ok && lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // b = this workgroup's item index (already remapped XCD-contiguously), nblk = items of the launch (or of this role).
-// CHAIN: the body is one layer of a chained launch -- `ch` says which producer flags its input rows wait for and which
-// flag it raises once its outputs are written through; the loaders request the (always ready) packed kernels of the first
-// stages BEFORE the wait, the pixels behind it.
-template <int NPA, int CT, int NQ, int NT, bool CHAIN = false>
+template <int NPA, int CT, int NQ, int NT>
 __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_bytes, int ring, unsigned mask_off, long long* prof,
-                                          const int b, const int nblk, const ChainHand* ch = nullptr, const unsigned epoch = 0) {
+                                          const int b, const int nblk) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int WB = NQ * CT * 3 * 1024, BLKA = NPA * 1024, NWP = NQ * CT * 3;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, cl = lane & 31;
@@ -106,18 +82,6 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     }
     const CVar& v = a.var[vi];
     const int OW = v.OW, p0 = it.p0, np = it.np;
-    // (tune & 1) the packed kernels of the first stages depend on nothing but the net: requested HERE, before the strip and
-    // tile tables are worked out, so that their round trip runs under the rest of the prologue
-    const bool early_w = !CHAIN && (a.tune & 1) && loader;
-    if (a.tune & 4) { if (loader) __builtin_amdgcn_s_setprio(1); }
-    if (early_w) {
-        const unsigned lds0e = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)&lds[0];
-        const unsigned long wb0e = (unsigned long)a.wq + (unsigned long)it.net * a.wq_stride + (unsigned long)v.w_off;
-        const int NSSe = a.KH * a.NCC;
-        for (int s0 = 0; s0 < ring - 1 && s0 < NSSe; ++s0)
-            for (int i = wave; i < NWP; i += 4)
-                dma16((unsigned)lane * 16, wb0e + (unsigned long)s0 * WB + (unsigned long)i * 1024, lds0e + s0 * stage_bytes + i * 1024);
-    }
     const int in_slot = (a.in_split > 0 ? (it.net >= a.in_split ? 1 : 0) : it.net) * a.nb + it.bb;
     const int out_slot = it.net * a.nb + it.bb;
     const unsigned long in_base = (unsigned long)a.in + (unsigned long)in_slot * a.in_slot;
@@ -189,7 +153,6 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
         stage_w(ss, buf, first, step);
         stage_x(ss, buf, first, step);
     };
-    const bool waits = CHAIN && ch->wait_flags != nullptr;  // wave-uniform
 
     // epilogue operands that only depend on the item: requested now, used after the loop
     const int co = ct * 32 + cl;
@@ -223,27 +186,16 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
         for (int r = 0; r < CP_MAX_STRIPS; ++r) cnt_x += ((nx[r] - wave + 3) / 4) * NPA;
         cnt += cnt_x;
         const int ahead = ring - 1;
-        if (waits) {
-            // the packed kernels do not depend on the producers: on their way while compute wave 0 polls the flags
-            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_w(s0, lds0 + s0 * stage_bytes, wave, 4);
-            __builtin_amdgcn_s_barrier();  // (B) the acquire behind the poll has completed
-            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_x(s0, lds0 + s0 * stage_bytes, wave, 4);
-        } else if (early_w) {
-            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage_x(s0, lds0 + s0 * stage_bytes, wave, 4);
-        } else {
-            for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
-        }
+        for (int s0 = 0; s0 < ahead && s0 < NSS; ++s0) stage(s0, lds0 + s0 * stage_bytes, wave, 4);
         int nbuf = ahead == 2 ? 2 : 1;  // buffer of superstep ss + ahead
         long long l_wait = 0, l_bar = 0, l_issue = 0;
         for (int ss = 0; ss < NSS; ++ss) {
             const long long c0 = prof ? clock64() : 0;
-            // (issue order behind a hand-off: kernels 0, kernels 1, pixels 0, pixels 1 -- superstep 0 has landed once at most
-            // the pixel copies of superstep 1 are outstanding)
-            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? ((waits || early_w) && ss == 0 ? cnt_x : cnt) : 0);
+            wait_vmcnt((ahead == 2 && ss + 1 < NSS) ? cnt : 0);
             const long long c1 = prof ? clock64() : 0;
             __builtin_amdgcn_s_barrier();  // everybody's copies of ss have landed; nobody still reads the buffer re-filled next
             const long long c2 = prof ? clock64() : 0;
-            if (ss + ahead < NSS && !(CP_ABLATE & 2)) stage(ss + ahead, lds0 + nbuf * stage_bytes, wave, 4);
+            if (ss + ahead < NSS) stage(ss + ahead, lds0 + nbuf * stage_bytes, wave, 4);
             if (prof) { l_wait += c1 - c0; l_bar += c2 - c1; l_issue += clock64() - c2; }
             nbuf = nbuf + 1 == ring ? 0 : nbuf + 1;
             if (ss + 1 == NSS && a.epilogue == 1) {
@@ -268,25 +220,6 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
     // ---- compute waves -------------------------------------------------------------------------------------------
     // Fragment reads of tile-step u + 1 are issued one per gap BETWEEN the MFMAs of tile-step u (the wave issues an MFMA,
     // is free for the ~32 cycles it runs, and blocks at the next, dependent one): sched_barrier pins that order.
-    if (waits && !loader) {
-        if (wave8 == 0) {
-            // producer rows this item reads: padded input rows [first, last] -> unpadded producer rows -> their ranges
-            const int oh_last = (p0 + np - 1) / OW;
-            const int first = oh0 * a.S + v.in_off_h - ch->p_lo_h, last = oh_last * a.S + v.in_off_h + a.KH - 1 - ch->p_lo_h;
-            const int ya = max(first, 0), yb = min(last, ch->p_OH - 1);
-            const int pa = ya * ch->p_OW, pb_ = (yb + 1) * ch->p_OW - 1;
-            const int big = ch->p_rem * (ch->p_base + 1);  // positions covered by the ranges that are one longer
-            const int r_lo = pa < big ? pa / (ch->p_base + 1) : ch->p_rem + (pa - big) / ch->p_base;
-            const int r_hi = pb_ < big ? pb_ / (ch->p_base + 1) : ch->p_rem + (pb_ - big) / ch->p_base;
-            const long long cw0 = prof ? clock64() : 0;
-            chain_wait(ch->wait_flags + (long)in_slot * ch->p_R, r_lo, r_hi, epoch, ch->err);
-            if (prof && t == 0) {  // (the loader row's spare slots: cycles in the poll + acquire, wall clock behind it, flags polled)
-                long long* pr = prof + 8L * 4096 + (long)b * 8;
-                pr[4] = clock64() - cw0; pr[5] = wall_clock64(); pr[6] = r_hi - r_lo + 1;
-            }
-        }
-        __builtin_amdgcn_s_barrier();  // (B)
-    }
     int cbuf = 0;
     for (int ss = 0; ss < NSS && !loader; ++ss) {
         const unsigned cur_off = cbuf * stage_bytes;
@@ -295,7 +228,6 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (prof) { const long long now = clock64(); pwait += now - pw; if (ss == 0) pt2 = now; }
-        if (CP_ABLATE & 1) continue;
         const unsigned char* cur = lds + cur_off;
         // Fragments: the activation halves of tile-step u + 2 are requested in the gaps between the MFMAs of tile-step u
         // (a ring of three register sets), the weight planes of tap q + 1 during the last-but-one tile-step of tap q:
@@ -456,9 +388,7 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const u32x4 x = *LDS_PTR(const u32x4, R + pl * 2048 + j * 1024 + rsw);
-                    if (CHAIN && ch->done_flags) store16_sc1(O + (unsigned long)pl * a.CO * 64 + j * 1024, x);  // handed off in-launch
-                    else if (a.tune & 2) __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024));
-                    else *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = x;
+                    *reinterpret_cast<u32x4*>(O + (unsigned long)pl * a.CO * 64 + j * 1024) = x;
                 }
         }
         if (a.out_f32) {
@@ -466,19 +396,10 @@ __device__ __forceinline__ void cfwd_body(const CFwdArgs& a, unsigned stage_byte
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 x = *LDS_PTR(const f32x4, R + r_f32 + j * 1024 + fsw);
-                if (a.tune & 2) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(F + j * 256));
-                else *reinterpret_cast<f32x4*>(F + j * 256) = x;
+                *reinterpret_cast<f32x4*>(F + j * 256) = x;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next one overwrites it
-    }
-    if (CHAIN) {
-        // every wave's stores have been acknowledged and nobody still uses the turn-around tiles: the item's flag goes up
-        // (a relaxed agent-scope store; the payload went out write-through), the next layer's body may refill LDS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ch->done_flags && t == 0)
-            __hip_atomic_store(ch->done_flags + (long)out_slot * a.items_per_slot + item_in_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (prof && t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

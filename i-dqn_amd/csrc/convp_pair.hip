@@ -39,47 +39,6 @@ __global__ __launch_bounds__(512) void k_cpair(CFwdArgs f, unsigned f_stage, int
     }
 }
 
-#ifdef IDQN_VARIANTS  // stream role (IDQN_OVERLAP=1): measured neutral, DESIGN.md section 3
-// The pair with a STREAM ROLE behind it (dense0_update.h): blocks [0, n_conv) are the two conv roles as above, blocks
-// [n_conv, gridDim.x) run a share of the fused Dense_0 update on the CUs the pair leaves free.
-template <int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG>
-__global__ __launch_bounds__(512) void k_cpair_s(CFwdArgs f, unsigned f_stage, int ring, unsigned mask_off, int n_f, long long* prof,
-                                                 CWgradArgs w, unsigned w_stage, int MT, int n_conv, D0Stream ds) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_s[];
-    warm_kernargs<1024>();
-    const int n = n_conv, b = (int)blockIdx.x, x = b & 7, slot = b >> 3;
-    if (b >= n_conv) {
-        d0_stream_role(ds, b - n_conv, reinterpret_cast<float*>(lds_s));
-        return;
-    }
-    // (roles on every XCD, as in k_cpair; requires n_w >= 8)
-    const int qf = n_f >> 3, rf = n_f & 7, fx = qf + (x < rf ? 1 : 0);
-    if (slot < fx) {
-        cfwd_body<NPA, CT, NQ, NT>(f, f_stage, ring, mask_off, prof, x * qf + min(x, rf) + slot, n_f);
-    } else {
-        const int qn = n >> 3, rn = n & 7;
-        const int before = (x * qn + min(x, rn)) - (x * qf + min(x, rf));
-        cwgrad_body<WNPX, WCT, WNTW, WPG>(w, w_stage, MT, before + (slot - fx));
-    }
-}
-
-template <int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG>
-int launch_pair_s(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_lds, const CWgradArgs& w, int MT, int n_w, size_t w_lds,
-                  hipStream_t q, long long* prof, const D0Stream& ds) {
-    const unsigned mask_off = (unsigned)convp_fwd_mask_off(f_stage, NT, ring, f.out3 != nullptr, f.out_f32 != nullptr);
-    const size_t lds = std::max(std::max(f_lds, w_lds + 2048), (size_t)65536);
-    static LdsAttrMark attr;  // per instantiation
-    if (attr.needs(lds)) {
-        IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_cpair_s<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL((k_cpair_s<NPA, CT, NQ, NT, WNPX, WCT, WNTW, WPG>), dim3((unsigned)(n_f + n_w + ds.n_sb)), dim3(512), lds, q, f,
-                       (unsigned)f_stage, ring, mask_off, n_f, prof, w, (unsigned)(w_lds / 2), MT, n_f + n_w, ds);
-    IDQN_HIP_CHECK(hipGetLastError());
-    return IDQN_OK;
-}
-
-#endif  // IDQN_VARIANTS
 
 template <int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG>
 int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_lds, const CWgradArgs& w, int MT, int n_w, size_t w_lds,
@@ -87,7 +46,7 @@ int launch_pair(const CFwdArgs& f, int n_f, size_t f_stage, int ring, size_t f_l
     const unsigned mask_off = (unsigned)convp_fwd_mask_off(f_stage, NT, ring, f.out3 != nullptr, f.out_f32 != nullptr);
     const size_t lds = std::max(f_lds, w_lds + 2048);
     // every XCD needs at least as many blocks as data-gradient blocks: true whenever the weight gradient has >= 8 items
-    static const bool role_xcds = variant_env("IDQN_PAIR_ROLE_XCDS") != nullptr;  // A/B switch: roles on separate XCDs
+    static const bool role_xcds = false;  // A/B switch: roles on separate XCDs
     const int split_xcd = (!role_xcds && n_w >= 8) ? 1 : 0;
     static LdsAttrMark attr;  // per instantiation
     if (attr.needs(lds)) {
@@ -114,28 +73,15 @@ bool convp_pair_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WN
 }
 
 bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG) {  // pairs with the stream role
-#ifdef IDQN_VARIANTS
-    return NPA == 3 && CT == 2 && NQ == 3 && NT == 3 && WNPX == 3 && WCT == 2 && WNTW == 3 && WPG == 2;
-#else
     (void)NPA; (void)CT; (void)NQ; (void)NT; (void)WNPX; (void)WCT; (void)WNTW; (void)WPG;
     return false;
-#endif
 }
 
 int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_f, size_t f_stage, int ring, size_t f_lds,
                       const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof,
                       const D0Stream* ds) {
     IDQN_REQUIRE(n_f + n_w <= 256, "conv pair: %d + %d workgroups do not fit one per CU", n_f, n_w);
-#ifdef IDQN_VARIANTS
-    if (ds && ds->n_sb > 0 && ds->rounds > 0) {
-        IDQN_REQUIRE(n_f + n_w + ds->n_sb <= 256 && n_w >= 8, "conv pair: %d + %d + %d workgroups do not fit one per CU", n_f, n_w, ds->n_sb);
-        const int ntw_s = (MT * WCT + 3) / 4;
-        IDQN_REQUIRE(convp_pair_stream_built(NPA, CT, NQ, NT, WNPX, WCT, ntw_s, w.PG), "conv pair: no stream-role kernel for this pair");
-        return launch_pair_s<3, 2, 3, 3, 3, 2, 3, 2>(f, n_f, f_stage, ring, f_lds, w, MT, n_w, w_lds, q, prof, *ds);
-    }
-#else
     IDQN_REQUIRE(!ds, "conv pair: stream roles exist in the IDQN_VARIANTS build only");
-#endif
     IDQN_REQUIRE(f_lds <= 160 * 1024 && w_lds + 2048 <= 160 * 1024, "conv pair: %zu / %zu bytes of LDS per workgroup", f_lds, w_lds + 2048);
     const int ntw = (MT * WCT + 3) / 4;
     if (NPA == 3 && CT == 2 && NQ == 3 && WNPX == 3 && WCT == 2 && ntw == 3 && w.PG == 2) {

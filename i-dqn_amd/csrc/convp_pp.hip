@@ -415,7 +415,7 @@ __device__ __forceinline__ void cfwd_pp_body(const CFwdArgs& a, const unsigned s
                 for (int k = 0; ss < end; ++ss, ++k) {
                     step();
                     const long long e0 = prof ? clock64() : 0;
-                    if (have_epi && E.tpos[e] >= 0 && !(a.tune & 8)) {
+                    if (have_epi && E.tpos[e] >= 0) {
                         const bool last = ss + 1 == end;
                         if (k == 0) {
                             if (seq_aux >= 0) { need(seq_aux); seq_aux = -1; epi_operands_landed(); }

@@ -81,7 +81,6 @@ __global__ __launch_bounds__(256) void k_stage(StageArgs a, SL sl) {
         return;
     }
     const long pb = (long)blockIdx.x - a.n_prep_blocks;
-    if (pb == 0 && a.epoch && t == 0) a.epoch[0] += 1;  // never 0 while flags are compared with it: the word starts at 0
     if (pb == 0 && a.bcinv) {
         for (int k = t; k < a.K; k += 256) {  // (any number of heads)
             const double tt = (double)(a.count[k] + 1);

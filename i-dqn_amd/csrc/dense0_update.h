@@ -39,6 +39,12 @@ __device__ __forceinline__ void st4(float* p, const float4& v) {
 // Dense_0 weight gradient (+ optionally fused Adam): g[f][j] = sum_b a3[f][b] * dh[j][b]
 // HBM-bound: the output (and, fused, theta/m/v) is the 15.9 MB/head matrix; MFMA work is ~10 % of the time.
 // --------------------------------------------------------------------------------------------
+// 16-byte write-through store (sc1: the line leaves the XCD's L2 for the memory side at once); hipcc does not count an asm
+// store: the publishing wave drains with s_waitcnt vmcnt(0) itself.  (Used by the FIN instantiation of the update kernel only.)
+__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 struct AdamConsts {
     float lr_neg, b1, b2, omb1, omb2, eps;
 };
@@ -188,10 +194,8 @@ struct DenseWgradArgs {
 // delaying the second and third slot of every CU by one and two thirds of a workgroup's lifetime lets one workgroup of a CU
 // contract while the other two stream.
 __device__ __forceinline__ void d0_stagger(const int ticks) {
-#ifndef IDQN_VARIANTS
     (void)ticks;
     return;
-#endif
     const int slot = (int)blockIdx.x >> 8;
     if (ticks > 0 && slot > 0 && slot < 3) {
         const long long t0 = __builtin_amdgcn_s_memrealtime(), d = (long long)slot * ticks;
@@ -280,9 +284,6 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             vv[d] = ld4<(D0_WG_NT & 1) != 0>(a.nu + on);
         }
     };
-#ifndef D0W_ABL
-#define D0W_ABL 0
-#endif
 #ifndef D0W_JT_SLOW
 #define D0W_JT_SLOW 0
 #endif
@@ -381,16 +382,11 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                                     d = mfma_bf16(A[2], B[2 * par + q][0][s2], d);
                                     d = mfma_bf16(A[0], B[2 * par + q][2][s2], d);
                                     d = mfma_bf16(A[1], B[2 * par + q][1][s2], d);
-#if D0W_ABL != 1  // ablation 1: half the products (wrong results)
                                     d = mfma_bf16(A[1], B[2 * par + q][0][s2], d);
                                     d = mfma_bf16(A[0], B[2 * par + q][1][s2], d);
                                     d = mfma_bf16(A[0], B[2 * par + q][0][s2], d);
-#endif
                                 }
                             }
-#if D0W_ABL == 2  // ablation: the dh fragments of the first two blocks serve every block (wrong results): no operand wait in the loop
-                            if (false)
-#endif
                             if (bbl + 2 < nc) load_b(c0 + bbl + 2, q, B[2 * par + q]);
                         }
                     }
@@ -400,12 +396,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         if (!PRE_EARLY) prefetch();
         __syncthreads();  // the gradient tile is parked over the fragments
     } else
-#if D0W_ABL == 3 || D0W_ABL == 5  // ablation: no phase 1 (zero gradient tile; wrong results)
-    if (PRE_OPS && upd) prefetch();
-    for (int bb = 0; bb < 0; ++bb) {
-#else
     for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
-#endif
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
             const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
@@ -477,7 +468,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_PF3_MID
 #define D0W_PF3_MID 1
 #endif
-    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN && D0W_ABL != 4 && D0W_ABL != 5) ? D0W_PF3 : 0;
+    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN) ? D0W_PF3 : 0;
     float dv[PF3 > 0 ? NCH3 : 1][8];
     auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
         const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
@@ -539,11 +530,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             *reinterpret_cast<float4*>(a.grad + g0 + (long)(RPI * i) * a.J) =
                 *reinterpret_cast<const float4*>(&gs[(RPI * i + prow) * JT + pcol]);
     }
-#if D0W_ABL == 4 || D0W_ABL == 5  // ablation: no phase 3 (no data-gradient partials; wrong results)
-    if (false) {
-#else
     if (FUSE_DG) {
-#endif
         __syncthreads();  // the LDS tile now holds theta_old[32][256] (rotated)
         float* red = gs + 32 * JT;  // [4 waves][32 f][32 b], 16-byte slots XOR-swizzled by (f & 7)
         for (int bb = 0; bb < a.nb; ++bb) {

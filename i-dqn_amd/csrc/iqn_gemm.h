@@ -408,13 +408,6 @@ __global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
     iqn_d0_dgrad_body<D>(a, xcd_contiguous_id(), ig_lds);
 }
 
-#ifdef IDQN_VARIANTS
-template <int D>
-__global__ __launch_bounds__(512) void k_iqn_d0_dgrad_fin(IqnD0DgradArgs a, IqnD0DgradFin fin) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
-    iqn_d0_dgrad_body<D, true>(a, xcd_contiguous_id(), ig_lds, &fin);
-}
-#endif
 
 template <int D>
 __device__ __forceinline__ void iqn_d0_wgrad_body(const IqnD0WgradArgs& a, int item, unsigned char* ig_lds) {

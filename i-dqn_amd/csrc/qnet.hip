@@ -39,10 +39,7 @@ struct ConvL {
 bool plan_print() { static const bool on = getenv("IDQN_PLAN_PRINT") != nullptr; return on; }  // launch plans to stderr
 bool act_generic() { static const bool on = getenv("IDQN_ACT_GENERIC") != nullptr; return on; }  // acting through the batched forward
 
-int cu_budget() {
-    static const int n = variant_env("IDQN_CUS") ? std::max(16, std::min(256, atoi(variant_env("IDQN_CUS")))) : 256;
-    return n;
-}
+int cu_budget() { return 256; }  // CUs a launch plan may fill
 
 void same_pad(int i, int k, int s, int* out, int* lo, int* hi) {
     *out = (i + s - 1) / s;
@@ -391,10 +388,8 @@ void tl_mark(idqn_handle_s* h, hipStream_t q, const char* name) {
 // them and the update stores them with the default policy, so that part of them is found on chip again; everything read or written
 // once per step (target nets, m, v) stays non-temporal.  More heads: every stream non-temporal, as in rounds 3-4 (the dirty lines
 // of a set that cannot stay only get in the way: K = 6 the same, K = 8 +13 us; keeping only the 4-5 heads that would fit: no better
-// than none -- profiles/r5_d0_keep_online_ab.txt).  IDQN_D0_KEEP=n (variants build): the first n heads.
+// than none -- profiles/r5_d0_keep_online_ab.txt).
 int d0_keep_heads(const idqn_handle_s* h) {
-    static const int forced = variant_int("IDQN_D0_KEEP", -1);
-    if (forced >= 0) return std::min(forced, h->cfg.n_heads);
     return (long)h->cfg.n_heads * h->F * h->J * 4 <= 84L << 20 ? h->cfg.n_heads : 0;
 }
 bool d0_keep_online(const idqn_handle_s* h) { return d0_keep_heads(h) >= h->cfg.n_heads; }  // every head's kernel fits
@@ -402,19 +397,14 @@ bool d0_keep_online(const idqn_handle_s* h) { return d0_keep_heads(h) >= h->cfg.
 // k-splits of the Dense_0 forward of `n_nets` nets x `nb` sample blocks: as many 4-wave workgroups as CUs, never more (a 257th
 // would stream alone after the others), with balanced splits of the F / 32 row units (cnn_setup has the reasoning)
 int d0_splits(const idqn_handle_s* h, int n_nets, int nb) {
-    static const int forced = variant_int("IDQN_D0_SPLITS", 0);
-    const int ns = forced > 0 ? forced : 256 * 4 / std::max(1, n_nets * nb * (h->J / 128));
+    const int ns = 256 * 4 / std::max(1, n_nets * nb * (h->J / 128));
     return std::max(1, std::min(std::min(ns, 64), h->F / 32));
 }
 
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
-    {
-        static const bool grp = (variant_on("IDQN_D0_GROUP")) ||
-                                (variant_on("IDQN_D0_FUSE_HIDDEN"));
-        s.G = (grp && h->planes && units_per_split <= 0 && s.NS >= 8 && s.NS % 4 == 0) ? 4 : 1;
-    }
+    s.G = 1;  // (splits per workgroup of the Dense_0 forward: groups of four measured slower, profiles/r4_d0fwd_group_fuse_ab.txt)
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
         const int units = h->F / 32;
         s.NS = (units + units_per_split - 1) / units_per_split;
@@ -493,15 +483,7 @@ int cnn_setup(idqn_handle_s* h) {
     {
         const int units = h->F / 32;
         int ns = 256 * 4 / std::max(1, 2 * c.n_heads * (c.features[3] / 128));
-        if (const char* e = variant_env("IDQN_D0_SPLITS")) ns = atoi(e);
         h->NS = std::max(1, std::min(std::min(ns, 64), units));
-        // IDQN_D0_GROUP=1 (implied by IDQN_D0_FUSE_HIDDEN=1): groups of four splits per workgroup (DenseFwdArgs::G), NS a
-        // multiple of 4 that still keeps <= 256 workgroups busy.  Opt-in: a quarter of the partial slabs (-12 MB, k_hidden
-        // 5.5 -> 4.9 us) against +2.4 us in the forward itself (240 instead of 250 workgroups, the LDS reduce; rocprofv3),
-        // step +-1 us depending on the box (profiles/r4_d0fwd_group_fuse_ab.txt).
-        static const bool grp = (variant_on("IDQN_D0_GROUP")) ||
-                                (variant_on("IDQN_D0_FUSE_HIDDEN"));
-        if (grp && h->planes && h->NS >= 8) h->NS = h->NS / 4 * 4;
     }
     const int K = c.n_heads, nb = h->nb_max;
     int rc;
@@ -519,8 +501,8 @@ int cnn_setup(idqn_handle_s* h) {
     }
     if ((rc = netset_alloc(h, h->train, 2 * K, nb, 2, ""))) return rc;
     if ((rc = netset_alloc(h, h->infer, 1, 1, 1, "infer_", 4))) return rc;
-    if (h->planes && variant_env("IDQN_CONV_PROF")) {
-        h->cprof_role = atoi(variant_env("IDQN_CONV_PROF"));
+    if (h->planes && debug_env("IDQN_CONV_PROF")) {
+        h->cprof_role = atoi(debug_env("IDQN_CONV_PROF"));
         // role 10 = the chained forward launch: one [2][4096][8] block of stamps per layer
         if ((rc = alloc_zero(&h->cprof, (h->cprof_role == 10 ? 3 : 1) * 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
     }
@@ -607,7 +589,7 @@ int cnn_setup(idqn_handle_s* h) {
         {
             char nm[16];
             snprintf(nm, sizeof nm, "IDQN_PPC%d", i);  // experiment knob: positions per weight-gradient chunk
-            if (const char* e = variant_env(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
+            if (const char* e = debug_env(nm)) { const int v = atoi(e); if (v >= 1 && v <= npos) h->pos_per_chunk[i] = v; }
         }
         h->npc[i] = (npos + h->pos_per_chunk[i] - 1) / h->pos_per_chunk[i];
         if (h->planes) {  // plane path: (head, kernel row, chunk) workgroups, about one per CU (Conv_0: (head, chunk))
@@ -615,8 +597,6 @@ int cnn_setup(idqn_handle_s* h) {
             // never more workgroups than CUs (a 257th would run alone after the others), never more than 64 chunks: k_adam adds a leaf's
             // slabs one after the other (K = 1: 256 chunks of Conv_0 cost it 5 us more than they save the weight gradient)
             int nch = std::min(cu_budget() / per_chunk, 64);
-            if (const char* e = variant_env("IDQN_WCHUNKS")) nch = atoi(e);
-            if (const char* e = variant_env("IDQN_WCHUNKS_DIV")) nch = std::max(1, nch / std::max(1, atoi(e)));  // experiment knob
             h->npc[i] = std::max(1, std::min(nch, npos));
         }
         h->slab_stride[i] = ((long)cl.K * cl.K * cl.CI * cl.CO + cl.CO + 63) / 64 * 64;
@@ -631,7 +611,6 @@ int cnn_setup(idqn_handle_s* h) {
         IDQN_REQUIRE(h->J % 256 == 0, "i-IQN heads: dense width %d must be a multiple of 256", h->J);
         IqnWs& w = h->iqn;
         w.N = c.n_quantiles; w.V = 3 * K;
-        if (const char* e = variant_env("IDQN_IQN_SPLITS")) w.NS = std::max(1, std::min(64, atoi(e)));
         w.off_we = h->L.leaves[10].offset; w.off_be = h->L.leaves[11].offset;
         const long VN = (long)w.V * w.N, KN = (long)K * w.N;
         IDQN_HIP_CHECK(hipMalloc((void**)&w.wbase_v, sizeof(float*) * w.V));
@@ -661,15 +640,15 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.dq, KN * c.n_actions * 32, h, "iqn_dq"))) return rc;
         if ((rc = alloc_zero(&w.dh, KN * h->J * 32, h, "iqn_dh"))) return rc;
         if ((rc = alloc_zero(&w.dx, KN * h->F * 32, h, "iqn_dx"))) return rc;
-        // the embedding backward deals the fractions of a feature tile to QG workgroups (IDQN_IQN_EMBED_QG; a divisor of N)
-        w.QG = variant_env("IDQN_IQN_EMBED_QG") ? std::max(1, atoi(variant_env("IDQN_IQN_EMBED_QG"))) : 4;
+        // the embedding backward deals the fractions of a feature tile to QG workgroups (a divisor of N)
+        w.QG = 4;
         while (w.QG > 1 && w.N % w.QG != 0) --w.QG;
         if ((rc = alloc_zero(&w.dpsi, (long)w.QG * K * h->F * 32, h, "iqn_dpsi"))) return rc;
         if ((rc = alloc_zero(&w.gpart, (long)w.QG * K * 65 * h->F, h, "iqn_gpart"))) return rc;
-        w.HG = variant_env("IDQN_IQN_DH_GROUPS") ? std::max(1, atoi(variant_env("IDQN_IQN_DH_GROUPS"))) : 8;
+        w.HG = 8;
         while (w.HG > 1 && w.N % w.HG != 0) --w.HG;
         if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
-        if (variant_env("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
+        if (debug_env("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
@@ -811,7 +790,7 @@ int fc_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
     h->fc_plan_ = fc_plan(n);
-    if (variant_env("IDQN_FC_GENERIC") || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
+    if (nullptr || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
     if (h->fc_plan_.BS) {
         const int bytes = (int)(h->fc_plan_.floats * 4);
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -820,15 +799,15 @@ int fc_setup(idqn_handle_s* h) {
     }
     h->fcp_plan_ = fc_par_plan(n, h->L.head_stride);
     // IDQN_FC_PAR=0: the two-launch path (k_fc_step_mfma / k_fc_step_lds + k_adam) for every batch size
-    if ((getenv("IDQN_FC_PAR") && atoi(getenv("IDQN_FC_PAR")) == 0) || variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") ||
+    if ((getenv("IDQN_FC_PAR") && atoi(getenv("IDQN_FC_PAR")) == 0) || nullptr || nullptr ||
         n.dmax > FC_MAX_WIDTH)
         h->fcp_plan_.floats = 0;
     if (h->fcp_plan_.floats)
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->fcp_plan_.floats * 4)));
     h->fcm_plan_ = fc_mfma_plan(n);
-    if (variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
+    if (nullptr || nullptr || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
     h->fcm_global_ = false;
-    if (!h->fcm_plan_.floats && !(variant_env("IDQN_FC_GENERIC") || variant_env("IDQN_FC_NO_MFMA") || variant_env("IDQN_FC_NO_MFMA_G") || n.dmax > FC_MAX_WIDTH)) {
+    if (!h->fcm_plan_.floats && !(nullptr || nullptr || nullptr || n.dmax > FC_MAX_WIDTH)) {
         // the matrix does not fit LDS beside the activations: the same kernel with the weight operand read from global memory
         h->fcm_plan_ = fc_mfma_plan_g(n);
         h->fcm_global_ = h->fcm_plan_.floats != 0;
@@ -1011,21 +990,14 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
     auto key = std::make_tuple(role, n_nets, nb, target);
     auto itp = h->fwd_plans.find(key);
     if (itp != h->fwd_plans.end()) { *out = &itp->second; return IDQN_OK; }
-    static const int forced = variant_int("IDQN_CONV_WGS", 0);
     FwdPlan pl;
-    int rc = IDQN_E_INVALID;
-    if (forced > 256 && target == cu_budget()) {
-        rc = plan_fwd_target(role & 7, n_nets, nb, g, forced ? forced : 512, 80 * 1024, pl);
-        if (!rc && pl.NT < 2 && !forced) rc = IDQN_E_INVALID;  // items too small to be worth two per CU
-    }
-    if (rc) rc = plan_fwd_target(role & 7, n_nets, nb, g, target != cu_budget() ? target : (forced && forced <= 256 ? forced : target), 160 * 1024, pl);
+    int rc = plan_fwd_target(role & 7, n_nets, nb, g, target, 160 * 1024, pl);
     if (rc) return rc;
     // A whole-chip forward launch whose workgroups would carry the same number of tiles per wave with ~18 % fewer of them
     // takes the smaller grid: the matrix loop is as long, the staging traffic and the fill burst are smaller (Conv_1 / Conv_2
     // forward at K = 5: 250 -> 210 workgroups, 24.5 -> 23.7 and 24.1 -> 23.2 us, profiles/r3_conv_cu_budget_sweep.txt;
-    // Conv_0 would need 6 tiles instead of 5 and keeps 250).  IDQN_CONV_TRIM=0 switches the rule off.
-    static const bool trim = (variant_int("IDQN_CONV_TRIM", 1) != 0);
-    if (trim && !forced && target == cu_budget() && (role & 7) <= 2) {
+    // Conv_0 would need 6 tiles instead of 5 and keeps 250).
+    if (target == cu_budget() && (role & 7) <= 2) {
         FwdPlan p2;
         if (plan_fwd_target(role & 7, n_nets, nb, g, target * 13 / 16, 160 * 1024, p2) == IDQN_OK && p2.NT == pl.NT && p2.n_items < pl.n_items)
             pl = p2;
@@ -1053,7 +1025,7 @@ int plan_fwd_pp(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& 
     char nm[32];
     role &= 7;  // (bit 3 marks the acting set's plans)
     snprintf(nm, sizeof nm, "IDQN_PP_PARTS%d", role);
-    const int forced = variant_int(nm, 0), forced_ring = variant_int("IDQN_PP_RING", 0);
+    const int forced = debug_int(nm, 0), forced_ring = debug_int("IDQN_PP_RING", 0);
     const int NSS = g.KH * g.NCC, nm_prod = g.NPA == 3 ? 6 : 3, cus = cu_budget();
     const bool epi1 = role >= 3, planes_out = role != 2, f32_out = role == 2;
     int ow_max = 0;
@@ -1155,8 +1127,7 @@ int plan_wgrad(idqn_handle_s* h, int layer, int nb, WgradPlan** out, int n_chunk
     // rows of one chunk share its x / dy strips through L2; Conv_0 chunk-major, because its K heads read the SAME staged
     // minibatch and a pixel strip then crosses the fabric once per XCD instead of once per head.  The kernel derives its
     // item (head, chunk, kernel row, balanced position range) from the workgroup index.
-    static const bool net_major = variant_env("IDQN_NET_MAJOR") != nullptr;  // A/B switch
-    pl.chunk_major = (layer == 0 && !net_major) ? 1 : 0;
+    pl.chunk_major = layer == 0 ? 1 : 0;
     pl.n_chunks = nch;
     pl.n_items = K * nch * (layer == 0 ? 1 : l.K);
     (void)nb;
@@ -1206,15 +1177,12 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
         }
     }
     a.n_jobs = nj;
-    if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; a.epoch = h->chain_ws; }
+    if (train) { a.K = h->cfg.n_heads; a.count = h->count; a.bcinv = h->bcinv; a.b1 = h->ad.b1; a.b2 = h->ad.b2; }
     if (train && h->rp) {
         a.frames = h->rp->frames; a.rows = h->rp->rows; a.n_frames = h->rp->n_frames; a.frame_bytes = h->rp->frame_bytes;
         a.act_out = h->rp_action; a.rew_out = h->rp_reward; a.term_out = h->rp_terminal;
         return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q, &h->rp->slots);
     }
-    static const int part = variant_int("IDQN_STAGE_PART", 0);  // timing experiments only
-    if (part == 1) return convp_launch_stage(a, a.n_prep_blocks, q);
-    if (part == 2) { const int np = a.n_prep_blocks; a.n_prep_blocks = 0; (void)np; return convp_launch_stage(a, (int)blocks, q); }
     return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q);
 }
 
@@ -1233,7 +1201,6 @@ int conv_args(idqn_handle_s* h, NetSet& s, int role, int nb, int target, CFwdArg
     if (&s == &h->infer) { a.pbase[0] = a.pbase[1] = h->infer_pbase; a.n_first = 1; }
     else { a.pbase[0] = h->online; a.pbase[1] = h->target; a.n_first = h->cfg.n_heads; }
     a.pstride = h->L.head_stride; a.wq_stride = h->wq_stride; a.nb = nb; a.n_var = g.n_var;
-    { static const int tune = variant_int("IDQN_CONV_TUNE", 0); a.tune = tune; }
     a.KH = g.KH; a.NCC = g.NCC; a.S = g.S; a.SX = g.SX;
     for (int v = 0; v < g.n_var; ++v) a.var[v] = g.var[v];
     const ActGeom* gin;   // input planes
@@ -1247,8 +1214,7 @@ int conv_args(idqn_handle_s* h, NetSet& s, int role, int nb, int target, CFwdArg
         gin = gi[role]; gout = go[role];
         a.in = ins[role]; a.out3 = outs[role]; a.epilogue = 0; a.b_off = l.b_off; a.CO = l.CO;
         a.in_split = role == 0 ? (s.n_in_sets > 1 ? s.n_nets / 2 : s.n_nets + 1) : 0;
-        static const bool net_major = variant_env("IDQN_NET_MAJOR") != nullptr;  // A/B switch
-        a.range_major = role == 0 && !net_major;
+        a.range_major = role == 0;
         if (role == 2) { a.out_f32 = s.a3; a.f32_slot = h->ga3.block; a.f32_W = l.OW; }
         a.pix_bytes = g.NPA * l.CI * 64; a.plane_bytes = l.CI * 64;
         a.xstep = role == 0 ? 1024 : a.pix_bytes;
@@ -1360,14 +1326,13 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
     *done = false;
     if (spare) *spare = 0;
     const int cus = budget > 0 ? budget : cu_budget();
-    static const bool no_pair = variant_env("IDQN_NO_PAIR") != nullptr;  // A/B switch
-    if (no_pair || layer < 1 || layer > 2) return IDQN_OK;
+    if (layer < 1 || layer > 2) return IDQN_OK;
     // experiment knobs: IDQN_PAIR_D<layer> = workgroups planned for the data gradient, IDQN_PAIR_C<layer> = position chunks
     // of the weight gradient (default: what the data gradient leaves of the 256 CUs)
     auto knob = [&](const char* stem, int dflt) {
         char nm[32];
         snprintf(nm, sizeof nm, "%s%d", stem, layer);
-        const char* e = variant_env(nm);
+        const char* e = debug_env(nm);
         return e ? atoi(e) : dflt;
     };
     const int d_target = knob("IDQN_PAIR_D", cus / 2);
@@ -1402,62 +1367,6 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
                              pw->lds, q, conv_prof(h, s, role, pf));
 }
 
-// The three forward convs of the training set as ONE chained launch (convp_chain.hip) when the plans allow it;
-// *done = false: nothing was launched, the caller runs the three launches.  Opt-in (IDQN_CONV_CHAIN=1): measured
-// neutral (every consumer item depends on 3-9 producer items that all finish together, so the layers stay
-// in lockstep and the hand-offs cost what the kernel boundaries did), and three launches have no residency condition.
-#define CHAIN_FLAG_WORDS 4096  // per layer
-int planes_chain_fwd(idqn_handle_s* h, NetSet& s, int nb, hipStream_t q, bool* done) {
-    *done = false;
-    static const bool chain_on = variant_on("IDQN_CONV_CHAIN");
-    if (!chain_on || &s != &h->train || !h->chain_ws) return IDQN_OK;
-#ifdef IDQN_VARIANTS
-    CChainArgs c;
-    memset(&c, 0, sizeof(c));
-    RoleGeom g[3];
-    FwdPlan* pl[3];
-    int NT[3], n_wg = 0, rc;
-    size_t lds = 0;
-    for (int i = 0; i < 3; ++i) {
-        if ((rc = conv_args(h, s, i, nb, cu_budget(), c.a[i], g[i], pl[i]))) return rc;
-        NT[i] = pl[i]->NT;
-        c.stage_bytes[i] = (unsigned)pl[i]->stage; c.ring[i] = pl[i]->ring; c.n_items[i] = pl[i]->n_items;
-        c.mask_off[i] = (unsigned)convp_fwd_mask_off(pl[i]->stage, NT[i], pl[i]->ring, c.a[i].out3 != nullptr, c.a[i].out_f32 != nullptr);
-        c.prof[i] = (h->cprof && h->cprof_role == 10) ? (long long*)h->cprof + (long)i * 2 * 8 * 4096 : conv_prof(h, s, i, pl[i]);
-        n_wg = std::max(n_wg, pl[i]->n_items);
-        lds = std::max(lds, pl[i]->lds);
-        if (g[i].n_var != 1 || pl[i]->n_items > CHAIN_FLAG_WORDS) return IDQN_OK;
-    }
-    // geometry the chain kernel is instantiated for, every workgroup resident at once
-    const bool nature = g[0].NPA == 1 && g[0].CT == 1 && g[0].NQ == 2 && g[1].NPA == 3 && g[1].CT == 2 && g[1].NQ == 4 &&
-                        g[2].NPA == 3 && g[2].CT == 2 && g[2].NQ == 3;
-    if (!nature || !convp_chain_fwd_built(NT) || n_wg > std::min(256, h->n_cus)) return IDQN_OK;
-    const ActGeom* gbuf[3] = {&h->ga1, &h->ga2, &h->ga3};  // output buffer of layer i = input buffer of layer i + 1
-    for (int i = 0; i < 3; ++i) {
-        ChainHand& hd = c.hand[i];
-        hd.err = h->chain_ws + 32;
-        hd.done_flags = i < 2 ? h->chain_ws + 64 + i * CHAIN_FLAG_WORDS : nullptr;
-        if (i == 0) continue;
-        const ConvL& lp = h->conv[i - 1];
-        const int npos = lp.OH * lp.OW, R = pl[i - 1]->r_cnt[0];
-        hd.wait_flags = h->chain_ws + 64 + (i - 1) * CHAIN_FLAG_WORDS;
-        hd.p_OW = lp.OW; hd.p_OH = lp.OH; hd.p_lo_h = gbuf[i - 1]->lo_h;
-        hd.p_R = R; hd.p_base = npos / R; hd.p_rem = npos % R;
-        // one lane per producer flag: an item's input rows may overlap at most 64 producer ranges
-        const ConvL& l = h->conv[i];
-        const int np_max = cdiv(l.OH * l.OW, pl[i]->r_cnt[0]);
-        const int out_rows = (np_max + l.OW - 2) / l.OW + 1, in_rows = (out_rows - 1) * l.S + l.K;
-        if (hd.p_base < 1 || (long)in_rows * lp.OW / hd.p_base + 2 > 64) return IDQN_OK;
-    }
-    c.epoch = h->chain_ws;
-    *done = true;
-    return convp_launch_chain_fwd(c, NT, n_wg, lds, q);
-#else
-    (void)nb; (void)q;
-    return IDQN_OK;
-#endif
-}
-
 // ---- forward of a net set: staging, 3 convs, Dense_0 partials -----------------------------------
 int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* st2, int B, hipStream_t q, bool with_dense0 = true) {
     const int nb = cdiv(B, 32);
@@ -1466,10 +1375,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         static const char* nm[3] = {"conv0 fwd", "conv1 fwd", "conv2 fwd"};
         int rc = planes_stage(h, s, st, st2, B, nb, q);
         tl_mark(h, q, "stage (pixels + kernel packing)");
-        bool chained = false;
-        if (!rc) rc = planes_chain_fwd(h, s, nb, q, &chained);
-        if (chained) tl_mark(h, q, "conv0-2 fwd (chained)");
-        for (int i = 0; i < 3 && !rc && !chained; ++i) { rc = planes_conv(h, s, i, nb, q); tl_mark(h, q, nm[i]); }
+        for (int i = 0; i < 3 && !rc; ++i) { rc = planes_conv(h, s, i, nb, q); tl_mark(h, q, nm[i]); }
         if (rc) return rc;
     } else {
         PrepArgs pa;
@@ -1514,10 +1420,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.bb_inner = (h->planes && s.G == 1 && nb > 1) ? 1 : 0;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
-    static const int rot_knob = variant_int("IDQN_D0_NET_ROT", -1);  // experiment knob: 0 = online nets first
+    static const int rot_knob = (-1);  // experiment knob: 0 = online nets first
     d.net_rot = s.n_in_sets > 1 ? (rot_knob >= 0 ? rot_knob : s.n_nets / 2) : 0;
     // the online nets' Dense_0 kernels (re-read by the fused update of the same step) with default-policy loads: k_dense0_fwd3
-    static const int nt_from = variant_int("IDQN_D0_FWD_NT_FROM", -1);  // experiment knob: 0 = every net non-temporally (round 3-4)
+    static const int nt_from = (-1);  // experiment knob: 0 = every net non-temporally (round 3-4)
     // (K <= 3: the frozen target nets' kernels fit beside the online ones -- 2 K F J 4 <= 100 MB -- and are found on chip step after step:
     // K = 2 -3 us, K = 3 -2 us, K = 4 the same)
     const bool keep_target = d0_keep_online(h) && 2L * h->cfg.n_heads * h->F * h->J * 4 <= 100L << 20;
@@ -1530,7 +1436,7 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     // bit-identical and measured neutral (profiles/r4_d0fwd_group_fuse_ab.txt: the launch grows by the 7 us the head stage,
     // the write-through drain, the arrival add and the acquire take on the 40 last-arriving workgroups; k_hidden took 5.5 + a
     // boundary) -- the in-launch split-K seam costs what the launch it replaces did, as on the conv chain.
-    static const bool fuse_hidden = variant_on("IDQN_D0_FUSE_HIDDEN");
+    static const bool fuse_hidden = false;
     s.hidden_fused = false;
     if (d.G == 4 && fuse_hidden && &s == &h->train && h->chain_ws && h->J % 128 == 0 && (long)s.n_nets * nb * d.n_jt <= 4096 &&
         128 * 33 + 128 * h->cfg.n_actions <= 16384) {
@@ -1542,51 +1448,20 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         if (attr.needs(65536 + 16)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
     }
     // IDQN_D0_FWD_DMA=1: the weight stream through a per-wave LDS-DMA ring (k_dense0_fwd3d, bit-identical partials)
-    static const bool fwd_dma = variant_on("IDQN_D0_FWD_DMA");
+    static const bool fwd_dma = false;
     (void)fwd_dma;
-#ifdef IDQN_VARIANTS
-    if (h->planes && fwd_dma && d.G == 1 && d.F / 16 >= d.NS && (long)h->J * 32 * 4 < (1L << 31)) {
-        static LdsAttrMark attr;
-        constexpr int lds = 4 * 4 * (8192 + 2048);  // all of the CU's 160 KB
-        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3d, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_dense0_fwd3d, dim3(cdiv(d.n_items, 4)), dim3(256), lds, q, d);
-    } else
-#endif
     if (h->planes) {
-#ifdef IDQN_VARIANTS
-        static const bool occ2 = variant_on("IDQN_D0_OCC2");
-        static const bool thread = variant_on("IDQN_D0_FWD_THREAD");
-        if (occ2 && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3o, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
-        else if (thread && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3t, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
-        else if (variant_int("IDQN_D0_FWD_XW", 0) && d.G == 1) {
-            if (variant_int("IDQN_D0_FWD_XW", 0) == 2) hipLaunchKernelGGL(k_dense0_fwd3x2, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
-            else hipLaunchKernelGGL(k_dense0_fwd3x, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
-        }
-        else if (variant_int("IDQN_D0_FWD_ABL", 0) && d.G == 1) {
-            static const int abl = variant_int("IDQN_D0_FWD_ABL", 0);
-            const dim3 g(cdiv(d.n_items, 4));
-            switch (abl) {
-                case 1: hipLaunchKernelGGL(k_dense0_fwd3a<1>, g, dim3(256), 0, q, d); break;
-                case 2: hipLaunchKernelGGL(k_dense0_fwd3a<2>, g, dim3(256), 0, q, d); break;
-                case 4: hipLaunchKernelGGL(k_dense0_fwd3a<4>, g, dim3(256), 0, q, d); break;
-                case 6: hipLaunchKernelGGL(k_dense0_fwd3a<6>, g, dim3(256), 0, q, d); break;
-                case 7: hipLaunchKernelGGL(k_dense0_fwd3a<7>, g, dim3(256), 0, q, d); break;
-                default: hipLaunchKernelGGL(k_dense0_fwd3a<8>, g, dim3(256), 0, q, d); break;
-            }
-        }
-        else
-#endif
         if (d.bb_inner) hipLaunchKernelGGL(k_dense0_fwd3b, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
         else {
             // fewer than 256 four-wave workgroups (plain DQN: 2 nets x 64 splits x 4 column tiles): two waves each, so that every
             // CU streams (a CU is the unit of streaming bandwidth); IDQN_D0_FWD_WPW=4: always four
-            static const int wpw_forced = variant_int("IDQN_D0_FWD_WPW", 0);
+            static const int wpw_forced = (0);
             const int wpw = d.G == 4 ? 4 : wpw_forced > 0 ? wpw_forced : d.n_items <= 512 ? 2 : 4;
             hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, wpw)), dim3(64 * wpw), d.G == 4 ? 65536 + 16 : 0, q, d);
         }
         // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
         // the previous launches leave the memory system in
-        static const bool twice = variant_on("IDQN_D0_FWD_TWICE");
+        static const bool twice = false;
         if (twice && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     } else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
@@ -1677,13 +1552,13 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
     dw.a3p = dw.dhp = nullptr;
-    static const int stagger = variant_int("IDQN_D0_STAGGER", 0);
+    static const int stagger = (0);
     dw.stagger = stagger;
     dw.fin_ctr = nullptr;
     // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
     // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
-    static const bool dp_f32 = variant_env("IDQN_DP_F32") != nullptr;
-    static const int dp_bf3_min = variant_int("IDQN_DP_BF3_MIN", 2);
+    static const bool dp_f32 = false;
+    static const int dp_bf3_min = (2);
     const bool bf3 = h->planes && fuse_adam && !fuse_dg && !dp_f32 && nb_total >= dp_bf3_min && h->J % 256 == 0;
     if (bf3) {
         if (h->fact_planes_cap < nb_total) {  // (first step of a job, or a larger world: outside any timed region)
@@ -1698,9 +1573,9 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         sa.a3p = h->fact_planes; sa.dhp = h->fact_planes + (long)3 * nb_total * K * h->F * 32;
         // The default update kernel (k_dense0_wgrad_alds<1>) splits its a3 tiles itself, straight from the gathered f32 factors:
         // only dL/dh (6 % of the factor bytes) goes through the plane copy.  IDQN_DP_A3_PLANES=1 (variants): a3 planes as in round 4.
-        static const bool a3_planes = variant_on("IDQN_DP_A3_PLANES");
-        static const int alds_m = variant_int("IDQN_DP_ALDS", 1);
-        static const bool t64 = variant_on("IDQN_DP_TILE64");
+        static const bool a3_planes = false;
+        static const int alds_m = (1);
+        static const bool t64 = false;
         const bool a3_in_kernel = !a3_planes && alds_m == 1 && !t64;
         if (a3_in_kernel) sa.a3p = nullptr;
         hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)((a3_in_kernel ? 0 : h->F) + h->J) * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
@@ -1716,17 +1591,17 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // dL/da3 itself and k_da3_finalize is not launched.  Measured: the kernel takes 104-108 us against 95 + 9 for the
     // two-column-tile kernel + finalize (two workgroups per CU instead of three, twice the MFMA phases per workgroup), the
     // step 0.2974-0.3017 against 0.2941 ms (profiles/r3_dense0_rows_ab.txt): kept as a second schedule for the tests.
-    static const bool rows_on = variant_on("IDQN_D0_ROWS");
+    static const bool rows_on = false;
     const bool rows = rows_on && fuse_adam && fuse_dg && h->J == 512 && h->ov.n_def == 0;
     h->d0_rows = rows;
     // IDQN_DP_TILE64=1: the bf16-plane update over several sample blocks (factored data-parallel step) on 64 x 128 tiles, a
     // third less operand traffic per block than 32 x 256 (dense0_update.h).  Opt-in: parity green, measured neutral
     // (profiles/r4_emulate_ranks_tile64_ab.txt: N = 8 emulated 414.9 against 412.7 us) -- the per-block cost of the contraction
     // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
-    static const bool tile64_on = variant_on("IDQN_DP_TILE64");
+    static const bool tile64_on = false;
     // IDQN_DP_ALDS=0: the register version of the contraction (one dependent HBM round trip per sample block)
     //   =2: the same on 64 x 256 tiles (two row tiles share every dh fragment; two workgroups per CU)
-    static const int alds_mode = variant_int("IDQN_DP_ALDS", 1);
+    static const int alds_mode = (1);
     const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
     const bool alds = alds_mode != 0 && !tile64, tall = alds && alds_mode == 2 && h->F % 64 == 0;
     const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
@@ -1750,7 +1625,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     }
     // (the extended launch only when there is something to time: it is not a capturable node of a step graph)
     // IDQN_D0W_PAD: extra (unused) dynamic LDS per workgroup = fewer co-resident workgroups per CU (occupancy experiments)
-    static const int pad = variant_int("IDQN_D0W_PAD", 0);
+    static const int pad = (0);
 #define D0W_LAUNCH(...)                                                                                   \
     do {                                                                                                  \
         static bool attr_set = false;                                                                     \
@@ -1766,7 +1641,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // measured 1 us SLOWER (profiles/r4_d0_fin_ab.txt): before its arrival add a workgroup has to drain its stores -- vmcnt
     // counts in order, so that is every theta / m / v store of its streaming phase -- and the fused kernel grows by 7.6 us,
     // the 5.4 us launch it saves (+ a boundary) notwithstanding.
-    static const bool fin_on = variant_on("IDQN_D0_FIN");
+    static const bool fin_on = false;
     h->d0_fin = false;
     if (!rows && fuse_adam && nq == 2 && fuse_dg && fin_on && h->fin_ctr && h->planes) {
         dw.fin_ctr = h->fin_ctr;
@@ -1785,36 +1660,10 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     //   k_da3_finalize): 3.5 us SLOWER than the tile kernel -- what pays in the pair is the finished data gradient, not the pairing.
     //   =3: the pair kernel with whole tiles in flight and cross-tile refills at two waves per SIMD (k_dense0_wgrad_pair8): the same
     //   time to 0.4 us.
-    static const int pair_mode = variant_int("IDQN_D0_PAIR", 1);
+    static const int pair_mode = (1);
     const bool pair_on = pair_mode == 1 || pair_mode == 3 || (pair_mode == 2 && dw.n_ft % 2 == 0);
     const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
                       h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
-#ifdef IDQN_VARIANTS
-    if (pair && pair_mode == 2) {
-        const dim3 pgrid((unsigned)(K * dw.n_ft));  // K * (n_ft / 2) * 2 column tiles
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_pair<true>, pgrid, dim3(256), 0, q, dw);
-    } else if (pair && pair_mode == 3) {  // whole tiles in flight, cross-tile refills, two waves per SIMD
-        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
-        h->d0_rows = true;
-        const dim3 pgrid((unsigned)(K * dw.n_ft));
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_pair8, pgrid, dim3(256), 0, q, dw);
-    } else if (rows) {
-        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
-        const size_t lds = (size_t)(32 * 512 + 4096) * 4;
-        static LdsAttrMark attr;
-        if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_rows, wgrid, dim3(256), lds, q, dw);
-    } else if (!pair && fuse_adam && nq == 2 && fuse_dg && dw.fin_ctr) D0W_LAUNCH(true, 2, true, false, 1, true);
-    else if (!pair && tile64) D0W_LAUNCH(true, 1, false, true, 2);
-    else if (!pair && bf3 && alds && tall) {
-        if (e0) hipExtLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, e0, e1, 0, dw);
-        else hipLaunchKernelGGL(k_dense0_wgrad_alds<2>, wgrid, dim3(256), 0, q, dw);
-    } else if (!pair && bf3 && !alds) D0W_LAUNCH(true, 2, false, true);
-    else
-#endif
     if (pair) {
         // one workgroup per PAIR of column tiles; the launch finishes dL/da3 itself
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
@@ -1822,7 +1671,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         const dim3 pgrid((unsigned)(K * dw.n_ft));
         // one or two heads at the Nature width: theta, m, v and the target nets (4 x 16 MB per head) fit the memory-side cache beside the step's
         // other traffic -- every stream of the update default-policy (K = 1 -1.9 us, K = 2 -4 us; K = 3 +5, K = 5 +16: profiles/r5_d0_keep_online_ab.txt)
-        static const int all_knob = variant_int("IDQN_D0_KEEP_ALL", -1);
+        static const int all_knob = (-1);
         const bool keep_all = all_knob >= 0 ? all_knob != 0 : (d0_keep_online(h) && 4L * K * h->F * h->J * 4 <= 128L << 20);
         // heads [0, keep) keep theta_new on chip, the others store it non-temporally: one launch per policy (a kernel with both bodies spills)
         const int keep = keep_all ? K : std::min(dw.keep_heads, K);
@@ -1893,7 +1742,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
     ta.chain_err = h->chain_ws ? h->chain_ws + 32 : nullptr;
-    static const bool stage_part = variant_env("IDQN_STAGE_PART") && atoi(variant_env("IDQN_STAGE_PART")) == 1;  // (timing experiment: no packing blocks)
+    static const bool stage_part = nullptr && atoi(nullptr) == 1;  // (timing experiment: no packing blocks)
     ta.bcinv_done = (h->planes && !stage_part) ? 1 : 0;
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
@@ -1908,18 +1757,18 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient).  On the fused single-device path it is
     // computed INSIDE the weight-gradient + Adam kernel (theta streams once) and finished by k_da3_finalize; the two-call
     // paths of the data-parallel step need it before the weight gradient and keep the separate kernel.
-    static const bool no_fuse_dg = variant_env("IDQN_NO_FUSE_DGRAD") != nullptr;
+    static const bool no_fuse_dg = false;
     // Several sample blocks on ONE device (B > 32): the schedule of the factored data-parallel step without its collectives -- the
     // data gradient as its own launch, the factors split once into bf16 planes, the update contracting them at the bf16 MFMA rate
     // (k_dense0_wgrad_alds) -- instead of the fused kernel's f32 MFMAs over every block (IDQN_NB_FUSED=1: that kernel; B = 256:
     // profiles/r5_b256_ab.txt)
-    static const bool nb_fused = variant_on("IDQN_NB_FUSED");
+    static const bool nb_fused = false;
     const bool many = nb >= 3 && h->planes && h->J % 256 == 0 && !nb_fused;  // (two blocks: the same either way, 0.5065 against 0.5085 ms)
     const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg && !many;
     // eight (or a multiple of eight) local sample blocks: the data gradient as the tiled bf16x3 GEMM the i-IQN heads use for their
     // fraction blocks (csrc/iqn_gemm.h: W read once per group of 8 blocks, products at the bf16 rate) + the finalize launch for the
     // ReLU mask / planes / per-position sums, instead of one f32-MFMA pass over W per block (IDQN_NB_DGRAD_F32=1: that kernel)
-    static const bool nb_dgrad_f32 = variant_on("IDQN_NB_DGRAD_F32");
+    static const bool nb_dgrad_f32 = false;
     if (!fuse_dg && many && nb % 8 == 0 && h->dpart && h->J % 16 == 0 && !nb_dgrad_f32) {
         IqnD0DgradArgs g;
         g.dh = dh_of(h, nb); g.wbase = s.wbase; g.dx = h->dpart; g.w_off = h->off_w0; g.K = K; g.nb = nb; g.F = h->F; g.J = h->J;
@@ -1927,17 +1776,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         const unsigned grid = (unsigned)(K * (nb / 8) * cdiv(h->F, 256));
         // IDQN_NB_DGRAD_FIN=1 (variants build): mask, planes and per-position sums in the GEMM's epilogue instead of the finalize
         // launch -- bit-identical, 110.3 us against 84.3 + 25.6 (the epilogue's plane stores are 8-byte pieces a row apart)
-        static const bool fin_in_gemm = variant_on("IDQN_NB_DGRAD_FIN");
-#ifdef IDQN_VARIANTS
-        if (fin_in_gemm) {
-            IqnD0DgradFin fin;
-            fin.a3 = s.a3; fin.da3 = h->da3; fin.da3p = h->da3p; fin.pb = h->pbuf[2]; fin.C = c2->CO; fin.g = h->gda3;
-            static LdsAttrMark attr;
-            if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad_fin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_iqn_d0_dgrad_fin<2>, dim3(grid), dim3(512), lds, q, g, fin);
-            tl_mark(h, q, "dense0 dgrad (tiled GEMM, finished)");
-        } else
-#endif
+        static const bool fin_in_gemm = false;
         {
             (void)fin_in_gemm;
             static LdsAttrMark attr;
@@ -1976,10 +1815,10 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // deferred to stream roles of the Conv_2 pair and Conv_0 weight-gradient launches (they only emit their data-gradient
     // share here); IDQN_OV_S2 / IDQN_OV_R2 / IDQN_OV_S0 / IDQN_OV_R0: stream workgroups and rounds per launch.
     h->ov.n_def = h->ov.left = 0;
-    static const bool overlap = variant_on("IDQN_OVERLAP");
+    static const bool overlap = false;
     if (overlap && fuse_dg && nb == 1 && h->planes) {
-        static const int S2 = variant_int("IDQN_OV_S2", 40), R2 = variant_int("IDQN_OV_R2", 2);
-        static const int S0 = variant_int("IDQN_OV_S0", 96), R0 = variant_int("IDQN_OV_R0", 1);
+        static const int S2 = (40), R2 = (2);
+        static const int S0 = (96), R0 = (1);
         const int n_items = K * (h->F / 32) * (h->J / 256);
         // S2 / S0 ask for that many CUs; the plans say how many workgroups the launches really leave (whole position chunks)
         int sp2 = 0, sp0 = 0;
@@ -2058,8 +1897,8 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bo
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
             if (!rc && i == 0 && adam_role && !ovl) {
-                static const bool role_on = variant_on("IDQN_ADAM_ROLE");
-                static const int role_cus = variant_int("IDQN_ADAM_ROLE_CUS", 96);
+                static const bool role_on = false;
+                static const int role_cus = (96);
                 CWgradArgs wa;
                 WgradPlan* pl = nullptr;
                 const int conv_budget = std::max(K, cu_budget() - role_cus);
@@ -2315,7 +2154,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
         const FcMfmaPlan& fm = h->fcm_plan_;
         const bool par = h->fcp_plan_.floats && batch <= 32;  // one launch: forwards side by side, Adam in the gradient epilogues
         if (par) hipLaunchKernelGGL(k_fc_step_par, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)h->fcp_plan_.floats * 4, q, a, h->fcp_plan_, h->ad,
-                                    h->online, h->mu, h->nu, grads_only ? 0 : 1, variant_on("IDQN_FC_PROF") ? 1 : 0);
+                                    h->online, h->mu, h->nu, grads_only ? 0 : 1, debug_on("IDQN_FC_PROF") ? 1 : 0);
         else if (fm.floats && h->fcm_global_) hipLaunchKernelGGL(k_fc_step_mfma<true>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
         else if (fm.floats) hipLaunchKernelGGL(k_fc_step_mfma<false>, dim3(h->cfg.n_heads), dim3(FCM_T), (size_t)fm.floats * 4, q, a, fm.ldw, fm.drows, fm.w_floats);
         else if (fp.BS == 32) hipLaunchKernelGGL(k_fc_step_lds<32>, dim3(h->cfg.n_heads), dim3(FC_T), lds, q, a, fp.tw, fp.wfl);
@@ -2340,7 +2179,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     IqnWs& w = h->iqn;
     IqnCosArgs ca;
     // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
-    static const bool embed3 = (variant_int("IDQN_IQN_EMBED3", 1) != 0);
+    static const bool embed3 = ((1) != 0);
     ca.tau = tau; ca.cosb = w.cosb; ca.cost = embed3 ? nullptr : w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
@@ -2348,7 +2187,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     ea.cosb = w.cosb; ea.wbase = wbase_v; ea.psi = psi; ea.x = w.xq; ea.we_off = w.off_we; ea.be_off = w.off_be;
     ea.K = K_for_index; ea.N = w.N; ea.F = h->F;
     {   // fractions per wave: 8 when that still leaves >= 8 waves per SIMD to overlap, else fewer (IDQN_IQN_EMBED_Q overrides)
-        static const int qenv = variant_int("IDQN_IQN_EMBED_Q", 0);
+        static const int qenv = (0);
         int per = qenv > 0 ? qenv : 8;
         while (per > 1 && (w.N % per != 0)) --per;
         const dim3 grid((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per));
@@ -2362,7 +2201,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
             e3.cosp = w.cosp; e3.wep = w.wep; e3.wbase = wbase_v; e3.psi = psi; e3.x = w.xq; e3.be_off = w.off_be;
             e3.K = K_for_index; e3.N = w.N; e3.F = h->F; e3.n_packed = n_packed;
             // cos fragments through LDS, once per workgroup (IDQN_IQN_EMBED_LDS=0: every wave fetches its own from L2)
-            static const bool e3lds = (variant_int("IDQN_IQN_EMBED_LDS", 1) != 0);
+            static const bool e3lds = ((1) != 0);
             if (e3lds) hipLaunchKernelGGL(k_iqn_embed3l, grid, dim3(256), 2 * 12288, q, e3);
             else hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
         } else {
@@ -2376,7 +2215,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
     d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0; d.nt_from = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
-    static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
+    static const bool gemm = ((1) != 0);
     if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;
         g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
@@ -2491,14 +2330,14 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         dd.dh = w.dh; dd.raw = w.dx; dd.wbase = h->train.wbase; dd.w_off = h->off_w0;
         dd.K = K; dd.nb = w.N; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = h->conv[2].CO; dd.g = h->gda3;
         dd.n_items = (long)K * w.N * cdiv(dd.n_ft, 4);
-        static const bool gemm = (variant_int("IDQN_IQN_GEMM", 1) != 0);
+        static const bool gemm = ((1) != 0);
         if (gemm && w.N % 8 == 0 && h->J % 16 == 0) {
             IqnD0DgradArgs g;
             g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
             const size_t lds = 2 * (size_t)IG_STAGE;
             const int n_d = K * (w.N / 8) * cdiv(h->F, 256);
             // the weight-gradient GEMM rides in the same launch (IDQN_IQN_MERGE=0: two launches)
-            static const bool merge = (variant_int("IDQN_IQN_MERGE", 1) != 0);
+            static const bool merge = ((1) != 0);
             if (merge && w.g1 && w.N % 16 == 0) {
                 IqnD0WgradArgs gw;
                 gw.x = w.xq; gw.dh = w.dh; gw.g[0] = h->grad + h->g_w0_base; gw.g[1] = w.g1; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 2;
@@ -2521,7 +2360,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     eb.cosb = w.cosb; eb.cost = w.cost; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
     eb.we_off = w.off_we; eb.be_off = w.off_be;
     eb.K = K; eb.N = w.N; eb.F = h->F;
-    static const bool embed3b = (variant_int("IDQN_IQN_EMBED3", 1) != 0);
+    static const bool embed3b = ((1) != 0);
     if (embed3b) {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
         IqnEmbedBwd3Args e3;
         e3.cosp = w.cosp; e3.cosa = w.cosa; e3.wep = w.wep; e3.wbase = w.wbase_v; e3.psi = h->train.a3; e3.dx = w.dx;
@@ -2550,7 +2389,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     }
     // Dense_0 weight gradient over the N fraction blocks of every head + Adam: as a GEMM with two block splits and one
     // streaming Adam pass (iqn_gemm.h), or (IDQN_IQN_GEMM=0, N not a multiple of 16) the plain step's fused kernel
-    static const bool gemm_w = (variant_int("IDQN_IQN_GEMM", 1) != 0);
+    static const bool gemm_w = ((1) != 0);
     if (gemm_w && w.g1 && w.N % 16 == 0) {
         const long n = (long)h->F * h->J;
         IqnD0WgradArgs g;

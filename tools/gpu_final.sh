@@ -1,10 +1,9 @@
 # End-of-round measurement set (one GPU call): default bench line, A = 18 repeat, the driver's short run, rocprofv3 kernel stats, PMC
 # passes, the configuration-4 / 5 single-device lines, the one-rank RCCL rehearsals of the data-parallel step (native C call with both
 # stream modes, the Python schedule, the all-reduce variant), head-parallel line, emulated-rank lines, the i-IQN line + its kernel
-# stats, trainer loop, MLP step, and the opt-in launch structures of the variants build against the default.  Outputs: gpurun_out/final/.
+# stats, the learner loop (rb.sample + step), trainer loop, MLP step, and the shipped switches against the default.  Outputs: gpurun_out/final/.
 mkdir -p gpurun_out/final && cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 O=gpurun_out/final
-V=$PWD/i-dqn_amd/libidqn_hip_variants.so
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2> $O/bench_steps20.err; echo "bench steps20 rc=$?"
 timeout -k 10 300 python bench.py --actions 18 --no-cpu-baseline > $O/bench_a18.json 2> $O/bench_a18.err; echo "bench a18 rc=$?"
@@ -21,10 +20,15 @@ for n in 1 2 4 8; do timeout -k 10 200 python bench.py --emulate-ranks $n --step
 timeout -k 10 400 python bench.py --algo iiqn --steps 30 --warmup 5 --repeats 3 > $O/bench_iiqn.json 2> $O/bench_iiqn.err; echo "iiqn rc=$?"
 rm -rf $O/prof_iiqn; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_iiqn -- python bench.py --algo iiqn --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/prof_iiqn.log 2>&1
 cp $O/prof_iiqn/*/*_kernel_stats.csv $O/iiqn_kernel_stats.csv && echo "iiqn kernel stats ok"; rm -rf $O/prof_iiqn
-# the opt-in launch structures of earlier rounds (variants build), each against the default on THIS box
-for sw in IDQN_NONE=1 IDQN_D0_PAIR=0 IDQN_CONV_CHAIN=1 IDQN_D0_GROUP=1 IDQN_D0_FWD_DMA=1 IDQN_D0_FWD_THREAD=1 IDQN_CONV_TUNE=3 IDQN_OVERLAP=1 IDQN_NONE=2; do
-  env IDQN_HIP_LIB=$V $sw timeout -k 10 200 python bench.py --no-cpu-baseline --no-side-legs --steps 300 --repeats 3 > $O/bench_$sw.json 2> $O/bench_$sw.err; echo "$sw rc=$?"
+# the shipped library's second ways of issuing the same arithmetic, each against the default on THIS box
+for sw in IDQN_NONE=1 IDQN_STEP_GRAPH=1 IDQN_CONV=f32 IDQN_NONE=2; do
+  env $sw timeout -k 10 200 python bench.py --no-cpu-baseline --no-side-legs --steps 300 --repeats 3 > $O/bench_$sw.json 2> $O/bench_$sw.err; echo "$sw rc=$?"
 done
+for sw in IDQN_NONE=1 IDQN_CONV_PP=0; do
+  env $sw timeout -k 10 200 python bench.py --batch 256 --no-cpu-baseline --no-side-legs --steps 100 --repeats 3 > $O/bench_b256_$sw.json 2> $O/bench_b256_$sw.err; echo "b256 $sw rc=$?"
+  env $sw timeout -k 10 200 python bench.py --heads 64 --no-cpu-baseline --no-side-legs --steps 60 --repeats 3 > $O/bench_k64_$sw.json 2> $O/bench_k64_$sw.err; echo "k64 $sw rc=$?"
+done
+timeout -k 10 400 python bench.py --learner --steps 200 > $O/bench_learner.json 2> $O/bench_learner.err; echo "learner rc=$?"
 timeout -k 10 300 python tools/bench_loop.py > $O/loop_all.log 2>&1; grep -E "us per|env steps" $O/loop_all.log > $O/loop.txt
 timeout -k 10 200 python tools/bench_fc.py 2>/dev/null | grep -E "^fc " >> $O/loop.txt; cat $O/loop.txt
 python - <<'PY'

@@ -1,7 +1,7 @@
 """Phase timing inside one plane conv launch (IDQN_CONV_PROF=role): medians over workgroups of the shader-clock cycles
 spent in the prologue, the first fill, the superstep loop (and waiting inside it) and the epilogue."""
 import os
-os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_variants.so"))  # variants build: the stamps / switches used here
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_debug.so"))  # debug build (__graft_entry__.build_debug()): the stamps / switches used here
 import os
 import sys
 

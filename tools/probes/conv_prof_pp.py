@@ -1,10 +1,10 @@
-"""Phase stamps of the persistent plane conv kernel (convp_pp.hip) for one role (IDQN_CONV_PROF=role, variants build):
+"""Phase stamps of the persistent plane conv kernel (convp_pp.hip) for one role (IDQN_CONV_PROF=role, debug build (__graft_entry__.build_debug())):
 per workgroup, cycles of wave 0 and wave 4 by what they were doing, summed over the workgroup's items."""
 import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("IDQN_HIP_LIB", os.path.join(root, "i-dqn_amd", "libidqn_hip_variants.so"))
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(root, "i-dqn_amd", "libidqn_hip_debug.so"))
 sys.path[:0] = [root, os.path.join(root, "i-dqn_amd")]
 import numpy as np
 import torch

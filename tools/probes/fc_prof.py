@@ -1,7 +1,7 @@
-"""Phase stamps of k_fc_step_par (IDQN_FC_PROF=1, variants build): cycles of thread 0 between phase boundaries, per head."""
+"""Phase stamps of k_fc_step_par (IDQN_FC_PROF=1, debug build (__graft_entry__.build_debug())): cycles of thread 0 between phase boundaries, per head."""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("IDQN_HIP_LIB", os.path.join(root, "i-dqn_amd", "libidqn_hip_variants.so"))
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(root, "i-dqn_amd", "libidqn_hip_debug.so"))
 os.environ["IDQN_FC_PROF"] = "1"
 sys.path[:0] = [root, os.path.join(root, "i-dqn_amd")]
 import numpy as np, torch

@@ -2,7 +2,7 @@
 s_memtime / s_memrealtime around its k loop).  ~2 s of back-to-back steps on random data first (MI355X_MICROARCH.md, DVFS
 give-back item 6), then the median over workgroups of  d(s_memtime) / d(s_memrealtime) x 100 MHz."""
 import os
-os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_variants.so"))  # variants build: the stamps / switches used here
+os.environ.setdefault("IDQN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "i-dqn_amd", "libidqn_hip_debug.so"))  # debug build (__graft_entry__.build_debug()): the stamps / switches used here
 import ctypes as C, os, sys, time
 os.environ["IDQN_IQN_CLOCK"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
