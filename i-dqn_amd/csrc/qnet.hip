@@ -205,6 +205,7 @@ int build_layout(const idqn_config_t& c, Layout& L) {
 struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
     int NS = 0;  // split-K of this set's Dense_0 forward
+    long part_slabs = 0;  // (block, split) slabs the partial buffer holds per net
     int G = 1;   // splits whose accumulators a workgroup adds through LDS before writing (k_dense0_fwd3): 4 or 1
     bool hidden_fused = false;  // the last Dense_0 forward of this set also ran the head's first stage (no k_hidden launch)
     const float** wbase = nullptr;  // dev [n_nets]
@@ -442,6 +443,7 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     long slabs = (long)nb * s.NS;  // the training set picks its splits per call (fewer, longer ones for more blocks): room for the largest
     if (&s == &h->train)
         for (int b = 1; b <= nb; ++b) slabs = std::max(slabs, (long)b * d0_splits(h, n_nets, b));
+    s.part_slabs = slabs;
     if ((rc = alloc_zero(&s.part, (long)n_nets * slabs * h->J * 32, h, (t + "part").c_str()))) return rc;
     return IDQN_OK;
 }
@@ -1450,6 +1452,27 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     // IDQN_D0_FWD_DMA=1: the weight stream through a per-wave LDS-DMA ring (k_dense0_fwd3d, bit-identical partials)
     static const bool fwd_dma = false;
     (void)fwd_dma;
+    // >= 8 sample blocks per net (B = 256): the tiled bf16x3 GEMM of the i-IQN heads (iqn_gemm.h: 256 x 256 tiles, operands split in
+    // registers and parked in LDS as MFMA fragments) -- the same interleaved split-K and product order, so the same partials
+    // layout for k_hidden; splits chosen to fill the chip.  IDQN_D0_FWD_GEMM=0: the block-inner streaming kernel (k_dense0_fwd3b).
+    static const bool fwd_gemm = !(getenv("IDQN_D0_FWD_GEMM") && atoi(getenv("IDQN_D0_FWD_GEMM")) == 0);
+    if (fwd_gemm && h->planes && &s == &h->train && s.G == 1 && nb % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
+        const int per_split = s.n_nets * (nb / 8) * (h->J / 256);
+        const int nsg = std::max(1, std::min(std::min(256 / std::max(1, per_split), 64), h->F / 16));
+        if ((long)nb * nsg <= s.part_slabs) {
+            s.NS = nsg;
+            IqnD0FwdArgs g;
+            g.x = s.a3; g.wbase = s.wbase; g.part = s.part; g.w_off = h->off_w0;
+            g.V = s.n_nets; g.nb = nb; g.NS = nsg; g.F = h->F; g.J = h->J; g.clk = nullptr;
+            const size_t lds = 2 * (size_t)IG_STAGE;
+            static LdsAttrMark attr;
+            if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_iqn_d0_fwd<2>, dim3((unsigned)(per_split * nsg)), dim3(512), lds, q, g);
+            tl_mark(h, q, "dense0 fwd (tiled GEMM)");
+            IDQN_HIP_CHECK(hipGetLastError());
+            return IDQN_OK;
+        }
+    }
     if (h->planes) {
         if (d.bb_inner) hipLaunchKernelGGL(k_dense0_fwd3b, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
         else {
