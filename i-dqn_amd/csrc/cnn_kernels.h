@@ -1065,11 +1065,10 @@ __global__ __launch_bounds__(256) void k_split_factors(SplitFactorsArgs a) {
 }
 
 
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1, bool FIN = false>
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG = false, bool BF3 = false, int RT = 1>
 __global__ __launch_bounds__(256) void k_dense0_wgrad(DenseWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 : 0) + (FIN ? 4 : 0)];  // (+ 4: the last-arriver flag)
-    d0_stagger(a.stagger);
-    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT, FIN>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+    __shared__ __attribute__((aligned(16))) float gs[32 * RT * 128 * NQ + (FUSE_DG ? 4096 : 0)];
+    dense0_wgrad_body<FUSE_ADAM, NQ, FUSE_DG, BF3, RT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 // The fused update on pairs of column tiles (dense0_update.h, dense0_pair_body): one workgroup per (head, 32 rows)
 // (cache policy: TH_ST_NT = false keeps theta_new on chip; ALL_DEFAULT: one or two heads, every stream default-policy; qnet.hip d0_keep_heads.
@@ -1084,8 +1083,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 template <int RT, bool TH_ST_NT = true>  // 32 * RT rows x 256 columns
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 1 ? 3 : 2))) void k_dense0_wgrad_alds(DenseWgradArgs a) {
     __shared__ __attribute__((aligned(1024))) float gs[RT == 1 ? 32 * 256 + 4096 : 64 * 256];
-    d0_stagger(a.stagger);
-    dense0_wgrad_body<true, 2, false, true, RT, false, true, TH_ST_NT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
+    dense0_wgrad_body<true, 2, false, true, RT, true, TH_ST_NT>(a, (int)blockIdx.x + a.item0, gs, (int)threadIdx.x);
 }
 
 // Sum of the column tiles' partial data gradients, ReLU mask of a3, and the three output forms of dL/da3: bf16 planes

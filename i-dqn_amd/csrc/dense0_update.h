@@ -39,12 +39,6 @@ __device__ __forceinline__ void st4(float* p, const float4& v) {
 // Dense_0 weight gradient (+ optionally fused Adam): g[f][j] = sum_b a3[f][b] * dh[j][b]
 // HBM-bound: the output (and, fused, theta/m/v) is the 15.9 MB/head matrix; MFMA work is ~10 % of the time.
 // --------------------------------------------------------------------------------------------
-// 16-byte write-through store (sc1: the line leaves the XCD's L2 for the memory side at once); hipcc does not count an asm
-// store: the publishing wave drains with s_waitcnt vmcnt(0) itself.  (Used by the FIN instantiation of the update kernel only.)
-__device__ __forceinline__ void store16_sc1(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
 struct AdamConsts {
     float lr_neg, b1, b2, omb1, omb2, eps;
 };
@@ -165,7 +159,6 @@ struct DenseWgradArgs {
     // sample block bb of head k: base + (bb / nb_inner) * outer + k * head + (bb % nb_inner) * inner   (floats)
     long a3_outer, a3_head, a3_inner, dh_outer, dh_head, dh_inner;
     int K, nb, nb_inner, n_ft, n_jt, F, J;
-    int stagger;   // > 0: workgroup b < 3 * 256 of the stand-alone kernel waits (b / 256) * stagger ticks of the 100 MHz clock first (d0_stagger)
     int keep_heads;  // host side only: heads [0, keep_heads) are launched with the kernel that stores theta_new with the default cache policy
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
     int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
@@ -176,32 +169,11 @@ struct DenseWgradArgs {
     ActGeom g;
     int C;
     float* dpart;  // FUSE_DG: partial data gradients [n_jt][K * nb][F][32] (this column tile's share of dL/da3), else unused
-    // FUSE_DG with column tiles (NQ < 4) and fin_ctr != nullptr: no finalize launch -- every workgroup writes its partial
-    // write-through and adds to the arrival counter of its 32 rows ([K * nb][n_ft], zero between launches); the one whose add
-    // comes last adds the column tiles' partials IN TILE ORDER (its own from registers, so the sum does not depend on who is
-    // last), applies the ReLU mask and writes the output forms (da3p / da3f / pb, g, C as for the full-row kernel).  Unlike the
-    // arrival at the end of the Dense_0 forward these arrivals are spread over the whole launch: the CU's other workgroup
-    // streams meanwhile.
-    unsigned* fin_ctr;
     // BF3: the two factors once more as three exact bf16 planes (k_split_factors), compact: a3p[plane][bb][k][F * 32],
     // dhp[plane][bb][k][J * 32]
     const unsigned short *a3p, *dhp;
 };
 
-
-// De-phasing experiment (IDQN_D0_STAGGER=<ticks of 10 ns>): the first 768 workgroups -- one per residency slot, three per CU --
-// start together and every tile costs the same, so the whole chip alternates between its MFMA phases and its streaming phase;
-// delaying the second and third slot of every CU by one and two thirds of a workgroup's lifetime lets one workgroup of a CU
-// contract while the other two stream.
-__device__ __forceinline__ void d0_stagger(const int ticks) {
-    (void)ticks;
-    return;
-    const int slot = (int)blockIdx.x >> 8;
-    if (ticks > 0 && slot > 0 && slot < 3) {
-        const long long t0 = __builtin_amdgcn_s_memrealtime(), d = (long long)slot * ticks;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
-}
 
 // Workgroup = one 32 (f) x 256 (j) tile of one head.  Phase 1: each of the 4 waves computes a 32 x 64 sub-tile
 // on the MFMA (2 accumulators, k = the 32 samples per batch block) and parks it in LDS.  Phase 2: all 256
@@ -228,8 +200,6 @@ __device__ __forceinline__ void d0_stagger(const int ticks) {
 // 32 x 64 wave tiles (wave w: row half w >> 1, column half w & 1), the same number of workgroups, but (64 + 128) instead of
 // (32 + 256) operand rows per sample block: a third less L2 -> CU operand traffic, which is what the N-block contraction of
 // the factored data-parallel update is bound by (qnet.hip, launch_dense0_wgrad); theta / m / v stream as 512-byte row pieces.
-// FIN (with FUSE_DG on column tiles): the last-arriving column-tile workgroup finishes dL/da3 (DenseWgradArgs::fin_ctr).  A
-// template parameter, not a run-time branch: as a branch it cost the DEFAULT instantiation 32 bytes of scratch per lane.
 // ALDS (with BF3, RT = 1, NQ = 2): the contraction over the N sample blocks of the factored data-parallel update was one
 // DEPENDENT round trip per block -- a tile's a3 planes are read exactly twice (once per column tile), i.e. they come from HBM,
 // and the 18 fragments of a block leave no registers for a second block in flight (7.7 us per extra block).  Here the tile's a3
@@ -237,7 +207,7 @@ __device__ __forceinline__ void d0_stagger(const int ticks) {
 // parked in afterwards (+ 16 KB): ONE HBM round trip per tile; the dh fragments (L2-resident: 0.8 MB per head) stay in registers,
 // two blocks ahead.  RT = 2 with ALDS: a 64 x 256 tile -- the two row tiles share every dh fragment (half the L2 -> CU operand
 // traffic, twice the products behind every fragment wait), 64 accumulator registers, two workgroups per CU.
-template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool FIN = false, bool ALDS = false, bool TH_ST_NT = (D0_WG_NT & 2) != 0>  // column tile JT = 128 * NQ (256 when the dense width allows it); TH_ST_NT: see dense0_pair_body
+template <bool FUSE_ADAM, int NQ, bool FUSE_DG, bool BF3, int RT = 1, bool ALDS = false, bool TH_ST_NT = (D0_WG_NT & 2) != 0>  // column tile JT = 128 * NQ (256 when the dense width allows it); TH_ST_NT: see dense0_pair_body
 __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int item, float* gs /* LDS, 32 * RT * JT floats (+ 4096 FUSE_DG) */,
                                                   const int t /* 0..255: thread of the 256-thread group that owns the item */) {
     constexpr int JT = 128 * NQ, LPR = JT / 4, RPI = 1024 / JT, NIT = 32 * RT / RPI;  // lanes/row, rows/iter (256 threads), iters
@@ -468,7 +438,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #ifndef D0W_PF3_MID
 #define D0W_PF3_MID 1
 #endif
-    constexpr int PF3 = (FUSE_DG && NQ == 2 && !FIN) ? D0W_PF3 : 0;
+    constexpr int PF3 = (FUSE_DG && NQ == 2) ? D0W_PF3 : 0;
     float dv[PF3 > 0 ? NCH3 : 1][8];
     auto load_dv = [&](int bb, auto c_lo, auto c_hi) {
         const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
@@ -584,70 +554,8 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
                     const float4 y = *reinterpret_cast<const float4*>(&red[w * 1024 + row * 32 + slot]);
                     s4.x += y.x; s4.y += y.y; s4.z += y.z; s4.w += y.w;
                 }
-                bool finish = ROWS;
-                if (!ROWS) {
-                    float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;
-                    if constexpr (FIN) {
-                        store16_sc1(O + t * 4, __builtin_bit_cast(u32x4, (f32x4v){s4.x, s4.y, s4.z, s4.w}));  // handed off in-launch
-                        int* flag = reinterpret_cast<int*>(gs + 32 * JT + 4096);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        if (t == 0) {
-                            unsigned* ctr = a.fin_ctr + ((long)k * a.nb + bb) * a.n_ft + ft;
-                            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const int last = old == (unsigned)a.n_jt - 1u;
-                            if (last) {
-                                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            }
-                            *flag = last;
-                        }
-                        __syncthreads();
-                        if (*flag) {  // the column tiles' partials in tile order; this tile's from registers
-                            const long tile = (long)a.K * a.nb * a.F * 32;
-                            const float* P0 = a.dpart + ((long)k * a.nb + bb) * a.F * 32 + (long)f0 * 32 + t * 4;
-                            float4 acc4 = jt == 0 ? s4 : *reinterpret_cast<const float4*>(P0);
-                            for (int j = 1; j < a.n_jt; ++j) {
-                                const float4 y = j == jt ? s4 : *reinterpret_cast<const float4*>(P0 + j * tile);
-                                acc4.x += y.x; acc4.y += y.y; acc4.z += y.z; acc4.w += y.w;
-                            }
-                            s4 = acc4;
-                            finish = true;
-                        }
-                    } else {
-                        *reinterpret_cast<float4*>(O + t * 4) = s4;
-                    }
-                }
-                if constexpr (ROWS || FIN)
-                if (finish) {
-                    // complete rows: ReLU mask of a3 and the three output forms of dL/da3 (as k_da3_finalize: one thread =
-                    // 4 samples of one row f, 8 threads a row)
-                    const int f = f0 + row, sl4 = (t & 7) * 4;
-                    const float4 m = *reinterpret_cast<const float4*>(a.a3 + bo * a.a3_outer + k * a.a3_head + bi * a.a3_inner + (long)f * 32 + sl4);
-                    s4.x = m.x > 0.f ? s4.x : 0.f; s4.y = m.y > 0.f ? s4.y : 0.f; s4.z = m.z > 0.f ? s4.z : 0.f; s4.w = m.w > 0.f ? s4.w : 0.f;
-                    const long sl = (long)k * a.nb + bb;
-                    const int pos = f / a.C, c = f - pos * a.C;
-                    const int oh = pos / a.g.W, ow = pos - oh * a.g.W;
-                    const long pix = (long)(oh + a.g.lo_h) * a.g.Wp + (ow + a.g.lo_w);
-                    if (a.da3f) *reinterpret_cast<float4*>(a.da3f + sl * a.g.block + (pix * a.C + c) * 32 + sl4) = s4;
-                    if (a.da3p) {
-                        unsigned short* O = a.da3p + sl * a.g.block * 3 + pix * (3L * a.C * 32) + (long)c * 32 + sl4;
-                        unsigned q0a, q1a, q2a, q0b, q1b, q2b;
-                        split3_pk(s4.x, s4.y, q0a, q1a, q2a);
-                        split3_pk(s4.z, s4.w, q0b, q1b, q2b);
-                        *reinterpret_cast<uint2*>(O) = make_uint2(q0a, q0b);
-                        *reinterpret_cast<uint2*>(O + (long)a.C * 32) = make_uint2(q1a, q1b);
-                        *reinterpret_cast<uint2*>(O + 2L * a.C * 32) = make_uint2(q2a, q2b);
-                    }
-                    if (a.pb) {
-                        float r = (s4.x + s4.y) + (s4.z + s4.w);
-                        r += __shfl_xor(r, 1);
-                        r += __shfl_xor(r, 2);
-                        r += __shfl_xor(r, 4);
-                        if ((t & 7) == 0) a.pb[(sl * (a.g.H * a.g.W) + pos) * a.C + c] = r;
-                    }
-                }
+                float* O = a.dpart + (((long)jt * a.K + k) * a.nb + bb) * a.F * 32 + (long)f0 * 32;  // finished by k_da3_finalize
+                *reinterpret_cast<float4*>(O + t * 4) = s4;
             }
             __syncthreads();  // red is reused by the next batch block
         }

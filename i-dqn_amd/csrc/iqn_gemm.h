@@ -223,20 +223,8 @@ struct IqnD0DgradArgs {
     int K, nb, F, J;
 };
 
-// FIN (variants build, IDQN_NB_DGRAD_FIN=1; the plain step's groups of 8 sample blocks, qnet.hip cnn_backward; measured neutral):
-// the epilogue finishes dL/da3 itself as k_da3_finalize would -- ReLU mask of a3, zero-bordered bf16 planes for the Conv_2 gradients, the per-position sums over the samples in the same
-// order (Conv_2 bias gradient), f32 rows for the f32 conv path -- instead of writing raw rows for a second launch to read back.
-struct IqnD0DgradFin {
-    const float* a3;       // [2K][nb][F * 32] (online nets first)
-    float* da3;            // f32 rows [K][nb][g.block] or nullptr
-    unsigned short* da3p;  // three planes per (net, block) or nullptr
-    float* pb;             // [K * nb][H * W][C] or nullptr
-    int C;
-    ActGeom g;
-};
-
-template <int D, bool FIN = false>
-__device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds, const IqnD0DgradFin* fin = nullptr) {
+template <int D>
+__device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
     // item = (net, 256-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
     const int nbg = a.nb / 8, nfg = (a.F + 255) / 256;
@@ -343,47 +331,10 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
         if (f >= a.F) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if constexpr (!FIN) {
-                float* O = a.dx + (((long)k * a.nb + bg * 8 + 2 * wm + j) * a.F + f) * 32 + 4 * h;
+            float* O = a.dx + (((long)k * a.nb + bg * 8 + 2 * wm + j) * a.F + f) * 32 + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(O + 8 * g) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            } else {
-                // the lane's four float4 are the 4-sample slots 2 g + h of its row (k_da3_finalize: one thread per slot)
-                const IqnD0DgradFin& e = *fin;
-                const long sl = (long)k * a.nb + bg * 8 + 2 * wm + j;
-                const int pos = f / e.C, c = f - pos * e.C;
-                const int oh = pos / e.g.W, ow = pos - oh * e.g.W;
-                const long pix = (long)(oh + e.g.lo_h) * e.g.Wp + (ow + e.g.lo_w);
-                const float* M = e.a3 + (sl * a.F + f) * 32 + 4 * h;
-                float4 m[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) m[g] = *reinterpret_cast<const float4*>(M + 8 * g);
-                float r[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                    v.x = m[g].x > 0.f ? v.x : 0.f; v.y = m[g].y > 0.f ? v.y : 0.f; v.z = m[g].z > 0.f ? v.z : 0.f; v.w = m[g].w > 0.f ? v.w : 0.f;
-                    const int slot = 2 * g + h;
-                    if (e.da3) *reinterpret_cast<float4*>(e.da3 + sl * e.g.block + (pix * e.C + c) * 32 + slot * 4) = v;
-                    if (e.da3p) {
-                        unsigned short* O = e.da3p + sl * e.g.block * 3 + pix * (3L * e.C * 32) + (long)c * 32 + slot * 4;
-                        unsigned q0a, q1a, q2a, q0b, q1b, q2b;
-                        split3_pk(v.x, v.y, q0a, q1a, q2a);
-                        split3_pk(v.z, v.w, q0b, q1b, q2b);
-                        *reinterpret_cast<uint2*>(O) = make_uint2(q0a, q0b);
-                        *reinterpret_cast<uint2*>(O + (long)e.C * 32) = make_uint2(q1a, q1b);
-                        *reinterpret_cast<uint2*>(O + 2L * e.C * 32) = make_uint2(q2a, q2b);
-                    }
-                    r[g] = (v.x + v.y) + (v.z + v.w);
-                }
-                if (e.pb) {  // k_da3_finalize's tree over the 8 slots: (0 + 1) + (2 + 3), then + ((4 + 5) + (6 + 7)); slots 2 g / 2 g + 1 sit in lanes bl / bl + 32
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) r[g] += __shfl_xor(r[g], 32);
-                    const float tot = (r[0] + r[1]) + (r[2] + r[3]);
-                    if (h == 0) e.pb[(sl * (e.g.H * e.g.W) + pos) * e.C + c] = tot;
-                }
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(O + 8 * g) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
     }
 }

@@ -20,12 +20,10 @@
 
 constexpr int IQN_EMBED = 64;  // cos features per fraction (IQN paper, section 3; Dopamine quantile_embedding_dim)
 
-// cos(pi * i * tau), i = 1..64, evaluated in fp64 and rounded once: cosb[slot][i - 1][b].  tau: [K][3][N][B] (floats in
+// cos(pi * i * tau), i = 1..64, evaluated in fp64 and rounded once.  tau: [K][3][N][B] (floats in
 // (0, 1)); slot = (type * K + k) * N + q.  Padded samples (b >= B) get tau = 0.5.
 struct IqnCosArgs {
     const float* tau;
-    float* cosb;
-    float* cost;  // the same block transposed, cost[slot][b][i - 1] (the embedding backward reads it as an MFMA A operand), or nullptr
     unsigned short* cosp;  // the block as MFMA B fragments in three exact bf16 planes: cosp[slot][k-step t][plane][lane (b, h)][8]
                            // = cos feature i = 16 t + 8 h + jj of sample b (k_iqn_embed3), or nullptr
     unsigned short* cosa;  // ... and as A fragments of cos (rows = features, k = samples): cosa[slot][row tile rt][k-step t][plane]
@@ -43,8 +41,6 @@ __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
     for (int jj = 0; jj < 8; ++jj) {
         const int i = 8 * g + jj;
         c[jj] = (float)cospi((double)(i + 1) * tau);
-        a.cosb[((long)slot * IQN_EMBED + i) * 32 + b] = c[jj];
-        if (a.cost) a.cost[((long)slot * 32 + b) * IQN_EMBED + i] = c[jj];
         ct[i][b] = c[jj];
     }
     if (a.cosp) {
@@ -72,65 +68,9 @@ __global__ __launch_bounds__(256) void k_iqn_cos(IqnCosArgs a) {
     }
 }
 
-// x = psi * relu(We^T cos + be): one wave = one tile of 32 features x 32 samples of one (virtual net, fraction) block.
-struct IqnEmbedArgs {
-    const float* cosb;          // [V * N][64][32]
-    const float* const* wbase;  // [V] parameter base of the virtual net
-    const float* psi;           // trunk features [2K][F * 32] (training set: online nets first)
-    float* x;                   // [V * N][F][32]
-    long we_off, be_off;
-    int K, N, F;
-};
-__global__ __launch_bounds__(256) void k_iqn_embed(IqnEmbedArgs a) {
-    // grid = (f tiles / 4, virtual net, fraction group): a wave keeps its 64 x 32 tile of We, its 32 x 32 tile of psi and
-    // the bias for all the fractions of its group (they belong to one virtual net) and requests the cos rows of fraction
-    // q + 1 before the products of fraction q -- one fetch of the shared operands and one exposed load latency per group
-    // instead of per (fraction, tile)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int ft = blockIdx.x * 4 + wave;
-    if (ft >= a.F / 32) return;
-    const int v = blockIdx.y, type = v / a.K, k = v - type * a.K;
-    const int nq = a.N / (int)gridDim.z, q0 = blockIdx.z * nq;
-    const int f0 = ft * 32;
-    const float* P = a.wbase[v];
-    const float* We = P + a.we_off + f0 + r;
-    float wa[32], cb[2][32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) wa[s] = We[(long)(2 * s + h) * a.F];
-    const float* C0 = a.cosb + (long)(v * a.N + q0) * IQN_EMBED * 32 + r;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) cb[0][s] = C0[(2 * s + h) * 32];
-    const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
-    float be[16], ps[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int f = f0 + mfma_row(i, h);
-        be[i] = P[a.be_off + f];
-        ps[i] = psi[(long)f * 32 + r];
-    }
-#define IE_STEP(q, st)                                                                              \
-    {                                                                                               \
-        if ((q) + 1 < nq) {                                                                         \
-            const float* Cn = C0 + (long)((q) + 1) * IQN_EMBED * 32;                                \
-            _Pragma("unroll") for (int s = 0; s < 32; ++s) cb[(st) ^ 1][s] = Cn[(2 * s + h) * 32]; \
-        }                                                                                           \
-        f32x16 acc;                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
-        _Pragma("unroll") for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], cb[st][s], acc);         \
-        float* X = a.x + (long)(v * a.N + q0 + (q)) * a.F * 32;                                     \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                              \
-            X[(long)(f0 + mfma_row(i, h)) * 32 + r] = fmaxf(acc[i] + be[i], 0.f) * ps[i];           \
-    }
-    for (int q = 0; q < nq; q += 2) {
-        IE_STEP(q, 0)
-        if (q + 1 < nq) IE_STEP(q + 1, 1)
-    }
-#undef IE_STEP
-}
-
 // ---- the embedding on the bf16 matrix cores (f32 accuracy: three exact planes, six products -- convp.h) -------------------
-// k_iqn_embed runs 32 f32 MFMAs (2048 cycles) per 32 x 32 tile: 0.20 ms for the K = 5 step, MFMA-bound.  Both operands are
-// small and shared by many tiles, so they are split ONCE per step into fragment-ordered planes (k_iqn_cos writes the cos
+// x = psi * relu(We^T cos + be): one wave = one tile of 32 features x 32 samples of one (virtual net, fraction) block.  As 32 f32
+// MFMAs (2048 cycles) per tile the K = 5 step spent 0.20 ms here, MFMA-bound.  Both operands are small and shared by many tiles, so they are split ONCE per step into fragment-ordered planes (k_iqn_cos writes the cos
 // blocks, k_iqn_we_pack the embedding kernels) and the tile costs 24 bf16 MFMAs (768 cycles) and no split work.
 struct IqnWePackArgs {
     const float* const* wbase;  // [n_nets]
@@ -163,65 +103,8 @@ struct IqnEmbed3Args {
     long be_off;
     int K, N, F, n_packed;       // virtual net v reads packed net v < n_packed ? v : v - K  (the two target sets share one)
 };
-__global__ __launch_bounds__(256) void k_iqn_embed3(IqnEmbed3Args a) {
-    // grid and roles as k_iqn_embed: a wave keeps its tile's We fragments (48 registers), psi tile and bias for the fractions of
-    // its group and requests the cos fragments of fraction q + 1 before the products of fraction q
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int ft = blockIdx.x * 4 + wave;
-    if (ft >= a.F / 32) return;
-    const int v = blockIdx.y, type = v / a.K, k = v - type * a.K;
-    const int nq = a.N / (int)gridDim.z, q0 = blockIdx.z * nq;
-    const int f0 = ft * 32, pv = v < a.n_packed ? v : v - a.K;
-    const unsigned short* Wf = a.wep + (((long)pv * (a.F / 32) + ft) * 12) * 512 + lane * 8;
-    bf16x8 wf[4][3], cf[2][4][3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wf[t][p] = *reinterpret_cast<const bf16x8*>(Wf + (t * 3 + p) * 512);
-    const unsigned short* C0 = a.cosp + ((long)(v * a.N + q0) * 12) * 512 + lane * 8;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) cf[0][t][p] = *reinterpret_cast<const bf16x8*>(C0 + (t * 3 + p) * 512);
-    const float* P = a.wbase[v];
-    const float* psi = a.psi + (long)((type == 0 ? 0 : a.K) + k) * a.F * 32;
-    float be[16], ps[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int f = f0 + mfma_row(i, h);
-        be[i] = P[a.be_off + f];
-        ps[i] = psi[(long)f * 32 + r];
-    }
-#define IE3_STEP(q, st)                                                                             \
-    {                                                                                               \
-        if ((q) + 1 < nq) {                                                                         \
-            const unsigned short* Cn = C0 + (long)((q) + 1) * 12 * 512;                             \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                           \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p)                                       \
-                    cf[(st) ^ 1][t][p] = *reinterpret_cast<const bf16x8*>(Cn + (t * 3 + p) * 512);  \
-        }                                                                                           \
-        f32x16 acc;                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
-            acc = mfma_bf16(wf[t][2], cf[st][t][0], acc);                                           \
-            acc = mfma_bf16(wf[t][0], cf[st][t][2], acc);                                           \
-            acc = mfma_bf16(wf[t][1], cf[st][t][1], acc);                                           \
-            acc = mfma_bf16(wf[t][1], cf[st][t][0], acc);                                           \
-            acc = mfma_bf16(wf[t][0], cf[st][t][1], acc);                                           \
-            acc = mfma_bf16(wf[t][0], cf[st][t][0], acc);                                           \
-        }                                                                                           \
-        float* X = a.x + (long)(v * a.N + q0 + (q)) * a.F * 32;                                     \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                              \
-            __builtin_nontemporal_store(fmaxf(acc[i] + be[i], 0.f) * ps[i], X + (long)(f0 + mfma_row(i, h)) * 32 + r); \
-    }
-    for (int q = 0; q < nq; q += 2) {
-        IE3_STEP(q, 0)
-        if (q + 1 < nq) IE3_STEP(q + 1, 1)
-    }
-#undef IE3_STEP
-}
-
-// The same with the cos fragments of a fraction copied ONCE per workgroup into LDS by LDS-DMA (the four waves of a
+// grid (f tiles / 4, virtual net, fraction group): a wave keeps its tile's We fragments (48 registers), psi tile and bias for the
+// fractions of its group.  The cos fragments of a fraction are copied ONCE per workgroup into LDS by LDS-DMA (the four waves of a
 // workgroup hold four feature tiles of the same (virtual net, fraction group) and read identical cos fragments: the
 // register version fetched them four times from L2, one step ahead, and waited for them -- 163 us where its 24 MFMAs per
 // 4 KB tile would allow ~45 and the 476 MB of stores ~95).  Two 12 KB buffers; per fraction: counted vmcnt (this wave's
@@ -500,126 +383,10 @@ __global__ __launch_bounds__(256) void k_iqn_head_grad_sum(IqnHeadGradSumArgs a)
 // Backward of the Hadamard product and of the embedding, one wave per (head, 32-feature tile), fractions in order:
 //   e, phi recomputed (the forward's MFMA);  dpsi[f][b] += dx * phi;  dphi = dx * psi * [e > 0];
 //   dWe[i][f] += sum_b cos[i][b] dphi[f][b]  (MFMA over the 32 samples, dphi through a per-wave LDS tile);  dbe[f] += sum_b dphi.
-struct IqnEmbedBwdArgs {
-    const float* cosb;  // [V * N][64][32] (online virtual nets = the first K * N slots)
-    const float* cost;  // [V * N][32][64] the same, transposed
-    const float* const* wbase;
-    const float* psi;   // [2K][F * 32]
-    const float* dx;    // [K][N][F][32]
-    float* dpsi;        // [QG][K][F][32] partial sums over the fractions of group qg (not yet masked by psi > 0)
-    float* gpart;       // [QG][K][65][F]: rows 0..63 = dL/dWe, row 64 = dL/dbe of group qg (k_iqn_embed_grad_sum adds the groups)
-    long we_off, be_off;
-    int K, N, F;
-};
-__global__ __launch_bounds__(256, 2) void k_iqn_embed_bwd(IqnEmbedBwdArgs a) {
-    // grid = (f tiles / 4, head, fraction group): the N fractions of a tile are dealt to gridDim.z workgroups (one wave
-    // walking all 32 of them was a single chain of dependent load / MFMA rounds: 0.35 ms at 1.2 waves per SIMD).
-    // The four waves of a workgroup (four feature tiles) share the fraction's cos block: it is copied to LDS once per
-    // fraction by LDS-DMA, in both orientations ([i][b]: B operand of the recomputed embedding; [b][i]: A operand of
-    // dL/dWe, conflict-free either way), one fraction ahead, like the next fraction's dx rows (registers).
-    __shared__ float tile[4][32][33];
-    __shared__ __attribute__((aligned(1024))) float cs[2][2][IQN_EMBED * 32];  // [buffer][cos | cos^T]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    const int k = blockIdx.y, qg = blockIdx.z;
-    const int nq = a.N / (int)gridDim.z, q_begin = qg * nq;
-    const bool live = (int)blockIdx.x * 4 + wave < a.F / 32;  // idle waves of the last workgroup still copy and join the barriers
-    const int ft = min((int)blockIdx.x * 4 + wave, a.F / 32 - 1);
-    const int f0 = ft * 32;
-    const float* P = a.wbase[k];
-    const float* We = P + a.we_off + f0 + r;
-    float wa[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) wa[s] = We[(long)(2 * s + h) * a.F];
-    float be[16], ps[16], dps[16], dbe[16];
-    const float* psi = a.psi + (long)k * a.F * 32;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int f = f0 + mfma_row(i, h);
-        be[i] = P[a.be_off + f];
-        ps[i] = psi[(long)f * 32 + r];
-        dps[i] = 0.f;
-        dbe[i] = 0.f;
-    }
-    f32x16 gw0, gw1;  // dWe rows i = 0..31 / 32..63 x the tile's 32 features
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { gw0[i] = 0.f; gw1[i] = 0.f; }
-    const unsigned lds_cs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&cs[0][0][0];
-    // this wave's quarter of the 16 KB [cos | cos^T] of fraction q -> buffer `buf` (four 1 KB pieces)
-    auto stage = [&](int q, int buf) {
-        const long slot = (long)k * a.N + q;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int piece = wave * 4 + c, which = piece >> 3, off = (piece & 7) * 256;
-            const float* src = (which ? a.cost : a.cosb) + slot * (IQN_EMBED * 32) + off;
-            dma16((unsigned)lane * 16, (unsigned long)src, lds_cs + (unsigned)(((buf * 2 + which) * IQN_EMBED * 32 + off) * 4));
-        }
-    };
-    float dxr[2][16];
-    auto fetch_dx = [&](int q, int st) {
-        const float* DX = a.dx + ((long)k * a.N + q) * a.F * 32;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dxr[st][i] = DX[(long)(f0 + mfma_row(i, h)) * 32 + r];
-    };
-    stage(q_begin, 0);
-    fetch_dx(q_begin, 0);
-#define EB_STEP(qi, st)                                                                                  \
-    {                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this fraction's copies and dx rows */         \
-        __builtin_amdgcn_s_barrier();                    /* ... of every wave; buffer st ^ 1 is free */   \
-        if ((qi) + 1 < nq) {                                                                             \
-            stage(q_begin + (qi) + 1, (st) ^ 1);                                                         \
-            fetch_dx(q_begin + (qi) + 1, (st) ^ 1);                                                      \
-        }                                                                                                \
-        const float* Cb = &cs[st][0][0];                                                                 \
-        const float* Ct = &cs[st][1][0];                                                                 \
-        f32x16 acc;                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;                                     \
-        _Pragma("unroll") for (int s = 0; s < 32; ++s) acc = mfma32(wa[s], Cb[(2 * s + h) * 32 + r], acc); \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                 \
-            const int fl = mfma_row(i, h);                                                               \
-            const float e = acc[i] + be[i];                                                              \
-            const float dx = dxr[st][i];                                                                 \
-            dps[i] = fmaf(dx, fmaxf(e, 0.f), dps[i]);                                                    \
-            const float dphi = e > 0.f ? dx * ps[i] : 0.f;                                               \
-            dbe[i] += dphi;                                                                              \
-            tile[wave][fl][r] = dphi; /* [feature][sample] */                                            \
-        }                                                                                                \
-        __builtin_amdgcn_wave_barrier();                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
-        /* dWe[i][f] += sum_b cos[i][b] * dphi[f][b]: A = cos^T (k = sample 2 s + h, row i = r (+32)), B = dphi (col f = r) */ \
-        _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                                 \
-            const float bv = tile[wave][r][2 * s + h];                                                   \
-            gw0 = mfma32(Ct[(2 * s + h) * IQN_EMBED + r], bv, gw0);                                      \
-            gw1 = mfma32(Ct[(2 * s + h) * IQN_EMBED + 32 + r], bv, gw1);                                 \
-        }                                                                                                \
-        __builtin_amdgcn_wave_barrier();                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
-    }
-    for (int qi = 0; qi < nq; qi += 2) {
-        EB_STEP(qi, 0)
-        if (qi + 1 < nq) EB_STEP(qi + 1, 1)
-    }
-#undef EB_STEP
-    if (!live) return;
-    float* DP = a.dpsi + ((long)qg * a.K + k) * a.F * 32;
-    float* G = a.gpart + ((long)qg * a.K + k) * 65 * a.F;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int fl = mfma_row(i, h);
-        DP[(long)(f0 + fl) * 32 + r] = dps[i];
-        float d = dbe[i];
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-        if (r == 0) G[64L * a.F + f0 + fl] = d;
-        G[(long)mfma_row(i, h) * a.F + f0 + r] = gw0[i];
-        G[(long)(32 + mfma_row(i, h)) * a.F + f0 + r] = gw1[i];
-    }
-}
-
 // The same backward on the bf16 matrix cores: the recomputed embedding from the pre-split planes (k_iqn_we_pack, cosp:
 // 24 products instead of 32 f32 MFMAs of twice the length), dL/dWe from the A-fragment planes of cos (cosa) and dphi split
 // in the kernel after its trip through the per-wave LDS tile (8 split3_pk per lane and fraction): 24 products instead of
-// 32.  Staging, grouping and outputs as k_iqn_embed_bwd.
+// 32.  grid = (f tiles / 4, head, fraction group): the N fractions of a tile are dealt to gridDim.z workgroups.
 struct IqnEmbedBwd3Args {
     const unsigned short* cosp;  // [V * N][12][512]
     const unsigned short* cosa;  // [V * N][12][512]

@@ -207,7 +207,6 @@ struct NetSet {
     int NS = 0;  // split-K of this set's Dense_0 forward
     long part_slabs = 0;  // (block, split) slabs the partial buffer holds per net
     int G = 1;   // splits whose accumulators a workgroup adds through LDS before writing (k_dense0_fwd3): 4 or 1
-    bool hidden_fused = false;  // the last Dense_0 forward of this set also ran the head's first stage (no k_hidden launch)
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -225,10 +224,9 @@ struct WgradPlan { int n_items = 0, n_chunks = 0, chunk_major = 0, MT = 0, PG = 
 struct IqnWs {
     int N = 0, V = 0, NS = 2;
     const float** wbase_v = nullptr;  // dev [V]: online k | target k | target k
-    float* cost = nullptr;  // cosb transposed per slot [V * N][32][64]
     unsigned short* cosa = nullptr;  // A-fragment planes of the cos blocks [V * N][12][512]
     unsigned short *cosp = nullptr, *wep = nullptr;  // bf16 fragment planes of the cos blocks [V * N][12][512] and of We [2K][F / 32][12][512]
-    float *cosb = nullptr, *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
+    float *xq = nullptr, *part = nullptr, *hbuf = nullptr, *qpart = nullptr, *dq = nullptr, *dh = nullptr,
           *dx = nullptr, *dpsi = nullptr, *dbg = nullptr, *z = nullptr;
     int QG = 1;              // fraction groups of the embedding backward (partials dpsi / gpart)
     float* gpart = nullptr;  // [QG][K][65][F]
@@ -342,9 +340,7 @@ struct idqn_handle_s {
     // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
     struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
     long adam_done_from = 0;  // > 0: the last backward's Conv_0 weight-gradient launch already updated the leaves from this element on
-    bool d0_rows = false;  // the last fused Dense_0 launch ran on full rows and finished dL/da3 itself
-    bool d0_fin = false;   // ... on column tiles whose last-arriving workgroup finished dL/da3 (DenseWgradArgs::fin_ctr)
-    unsigned* fin_ctr = nullptr;  // [K * nb_max][F / 32] arrival counters of that hand-off (zero between launches)
+    bool d0_rows = false;  // the last fused Dense_0 launch (pairs of column tiles) finished dL/da3 itself
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
     int pend_stage = 0;  // 1: stopped before the Dense_0 weight gradient, 2: stopped after it
@@ -514,11 +510,6 @@ int cnn_setup(idqn_handle_s* h) {
         h->chain_ws = reinterpret_cast<unsigned*>(ws);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
-        {
-            float* fc = nullptr;
-            if ((rc = alloc_zero(&fc, (long)K * nb * (h->F / 32) + 64, h, "fin_ctr"))) return rc;
-            h->fin_ctr = reinterpret_cast<unsigned*>(fc);
-        }
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
         if ((rc = alloc_zero16(&h->da2p, (long)K * nb * h->gda2.block * 3, h, "da2p"))) return rc;
         if ((rc = alloc_zero16(&h->da1p, (long)K * nb * h->gda1.block * 3, h, "da1p"))) return rc;
@@ -623,8 +614,6 @@ int cnn_setup(idqn_handle_s* h) {
             wv[K + k] = wv[2 * K + k] = h->target + (long)k * h->L.head_stride;
         }
         IDQN_HIP_CHECK(hipMemcpy(w.wbase_v, wv.data(), sizeof(float*) * w.V, hipMemcpyHostToDevice));
-        if ((rc = alloc_zero(&w.cosb, VN * IQN_EMBED * 32, h, "iqn_cos"))) return rc;
-        if ((rc = alloc_zero(&w.cost, VN * IQN_EMBED * 32, h, "iqn_cost"))) return rc;
         {
             float* tmp = nullptr;  // (alloc_zero counts floats: 12 x 512 bf16 = 3072 floats per block)
             if ((rc = alloc_zero(&tmp, VN * 3072, h, "iqn_cosp"))) return rc;
@@ -1422,36 +1411,16 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.bb_inner = (h->planes && s.G == 1 && nb > 1) ? 1 : 0;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
-    static const int rot_knob = (-1);  // experiment knob: 0 = online nets first
-    d.net_rot = s.n_in_sets > 1 ? (rot_knob >= 0 ? rot_knob : s.n_nets / 2) : 0;
+    d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
     // the online nets' Dense_0 kernels (re-read by the fused update of the same step) with default-policy loads: k_dense0_fwd3
-    static const int nt_from = (-1);  // experiment knob: 0 = every net non-temporally (round 3-4)
     // (K <= 3: the frozen target nets' kernels fit beside the online ones -- 2 K F J 4 <= 100 MB -- and are found on chip step after step:
     // K = 2 -3 us, K = 3 -2 us, K = 4 the same)
     const bool keep_target = d0_keep_online(h) && 2L * h->cfg.n_heads * h->F * h->J * 4 <= 100L << 20;
     // (the online nets' loads are default-policy for ANY number of heads: where nothing can stay on chip the fused update still runs 3-6 % faster behind
     // them -- K = 6 / 7 / 16 / 32: step -3.5 / -5 / -5 / -6 us, K = 8 / 64 the same; what depends on the size is only the store policy of theta_new)
-    d.nt_from = s.n_in_sets > 1 ? (nt_from >= 0 ? std::min(nt_from, s.n_nets) : keep_target ? s.n_nets : s.n_nets / 2) : 0;
+    d.nt_from = s.n_in_sets > 1 ? (keep_target ? s.n_nets : s.n_nets / 2) : 0;
     d.G = h->planes ? s.G : 1;
     d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
-    // IDQN_D0_FUSE_HIDDEN=1: the training set's head stage 1 (k_hidden) rides in this launch (DenseFwdArgs::arrive).  Opt-in:
-    // bit-identical and measured neutral (profiles/r4_d0fwd_group_fuse_ab.txt: the launch grows by the 7 us the head stage,
-    // the write-through drain, the arrival add and the acquire take on the 40 last-arriving workgroups; k_hidden took 5.5 + a
-    // boundary) -- the in-launch split-K seam costs what the launch it replaces did, as on the conv chain.
-    static const bool fuse_hidden = false;
-    s.hidden_fused = false;
-    if (d.G == 4 && fuse_hidden && &s == &h->train && h->chain_ws && h->J % 128 == 0 && (long)s.n_nets * nb * d.n_jt <= 4096 &&
-        128 * 33 + 128 * h->cfg.n_actions <= 16384) {
-        d.arrive = h->chain_ws + 64 + 2 * 4096; d.hbuf = h->hbuf; d.qpart = h->qpart;
-        s.hidden_fused = true;
-    }
-    if (d.G == 4) {
-        static LdsAttrMark attr;
-        if (attr.needs(65536 + 16)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_fwd3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16));
-    }
-    // IDQN_D0_FWD_DMA=1: the weight stream through a per-wave LDS-DMA ring (k_dense0_fwd3d, bit-identical partials)
-    static const bool fwd_dma = false;
-    (void)fwd_dma;
     // >= 8 sample blocks per net (B = 256): the tiled bf16x3 GEMM of the i-IQN heads (iqn_gemm.h: 256 x 256 tiles, operands split in
     // registers and parked in LDS as MFMA fragments) -- the same interleaved split-K and product order, so the same partials
     // layout for k_hidden; splits chosen to fill the chip.  IDQN_D0_FWD_GEMM=0: the block-inner streaming kernel (k_dense0_fwd3b).
@@ -1477,15 +1446,10 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         if (d.bb_inner) hipLaunchKernelGGL(k_dense0_fwd3b, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
         else {
             // fewer than 256 four-wave workgroups (plain DQN: 2 nets x 64 splits x 4 column tiles): two waves each, so that every
-            // CU streams (a CU is the unit of streaming bandwidth); IDQN_D0_FWD_WPW=4: always four
-            static const int wpw_forced = (0);
-            const int wpw = d.G == 4 ? 4 : wpw_forced > 0 ? wpw_forced : d.n_items <= 512 ? 2 : 4;
-            hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, wpw)), dim3(64 * wpw), d.G == 4 ? 65536 + 16 : 0, q, d);
+            // CU streams (a CU is the unit of streaming bandwidth)
+            const int wpw = d.n_items <= 512 ? 2 : 4;
+            hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, wpw)), dim3(64 * wpw), 0, q, d);
         }
-        // timing experiment (IDQN_D0_FWD_TWICE=1): the same launch again, idempotent -- how much of the forward's time is the state
-        // the previous launches leave the memory system in
-        static const bool twice = false;
-        if (twice && d.G == 1) hipLaunchKernelGGL(k_dense0_fwd3, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     } else hipLaunchKernelGGL(k_dense0_fwd, dim3(cdiv(d.n_items, 4)), dim3(256), 0, q, d);
     tl_mark(h, q, "dense0 fwd");
     IDQN_HIP_CHECK(hipGetLastError());
@@ -1575,14 +1539,9 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     DenseWgradArgs dw;
     dw.dpart = h->dpart;
     dw.a3p = dw.dhp = nullptr;
-    static const int stagger = (0);
-    dw.stagger = stagger;
-    dw.fin_ctr = nullptr;
     // The fused update over a GLOBAL batch (factored data-parallel step, >= 2 sample blocks per head): the factors are
-    // split into bf16 planes once and the contraction runs at the bf16 MFMA rate (IDQN_DP_F32=1: f32 MFMA as for one block).
-    static const bool dp_f32 = false;
-    static const int dp_bf3_min = (2);
-    const bool bf3 = h->planes && fuse_adam && !fuse_dg && !dp_f32 && nb_total >= dp_bf3_min && h->J % 256 == 0;
+    // split into bf16 planes once and the contraction runs at the bf16 MFMA rate.
+    const bool bf3 = h->planes && fuse_adam && !fuse_dg && nb_total >= 2 && h->J % 256 == 0;
     if (bf3) {
         if (h->fact_planes_cap < nb_total) {  // (first step of a job, or a larger world: outside any timed region)
             if (h->fact_planes) { IDQN_HIP_CHECK(hipStreamSynchronize(q)); IDQN_HIP_CHECK(hipFree(h->fact_planes)); }
@@ -1595,13 +1554,9 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         sa.K = K; sa.nb = nb_total; sa.nb_inner = nb_inner; sa.F = h->F; sa.J = h->J;
         sa.a3p = h->fact_planes; sa.dhp = h->fact_planes + (long)3 * nb_total * K * h->F * 32;
         // The default update kernel (k_dense0_wgrad_alds<1>) splits its a3 tiles itself, straight from the gathered f32 factors:
-        // only dL/dh (6 % of the factor bytes) goes through the plane copy.  IDQN_DP_A3_PLANES=1 (variants): a3 planes as in round 4.
-        static const bool a3_planes = false;
-        static const int alds_m = (1);
-        static const bool t64 = false;
-        const bool a3_in_kernel = !a3_planes && alds_m == 1 && !t64;
-        if (a3_in_kernel) sa.a3p = nullptr;
-        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)((a3_in_kernel ? 0 : h->F) + h->J) * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
+        // only dL/dh (6 % of the factor bytes) goes through the plane copy.
+        sa.a3p = nullptr;
+        hipLaunchKernelGGL(k_split_factors, dim3((unsigned)cdiv((long)h->J * 4, 256), (unsigned)(nb_total * K)), dim3(256), 0, q, sa);
         tl_mark(h, q, "factor planes");
         dw.a3p = sa.a3p; dw.dhp = sa.dhp;
     }
@@ -1610,25 +1565,9 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     dw.w_off = h->off_w0; dw.P = h->L.head_stride;
     dw.a3_outer = a3_outer; dw.a3_head = a3_head; dw.a3_inner = a3_inner;
     dw.dh_outer = dh_outer; dw.dh_head = dh_head; dw.dh_inner = dh_inner;
-    // IDQN_D0_ROWS=1: full 512-column rows (dense width 512, fused data gradient, nothing deferred) -- the kernel then finishes
-    // dL/da3 itself and k_da3_finalize is not launched.  Measured: the kernel takes 104-108 us against 95 + 9 for the
-    // two-column-tile kernel + finalize (two workgroups per CU instead of three, twice the MFMA phases per workgroup), the
-    // step 0.2974-0.3017 against 0.2941 ms (profiles/r3_dense0_rows_ab.txt): kept as a second schedule for the tests.
-    static const bool rows_on = false;
-    const bool rows = rows_on && fuse_adam && fuse_dg && h->J == 512 && h->ov.n_def == 0;
-    h->d0_rows = rows;
-    // IDQN_DP_TILE64=1: the bf16-plane update over several sample blocks (factored data-parallel step) on 64 x 128 tiles, a
-    // third less operand traffic per block than 32 x 256 (dense0_update.h).  Opt-in: parity green, measured neutral
-    // (profiles/r4_emulate_ranks_tile64_ab.txt: N = 8 emulated 414.9 against 412.7 us) -- the per-block cost of the contraction
-    // is the un-prefetched operand LATENCY of each block (loads, wait, 24 MFMAs, next block), not the operand bytes.
-    static const bool tile64_on = false;
-    // IDQN_DP_ALDS=0: the register version of the contraction (one dependent HBM round trip per sample block)
-    //   =2: the same on 64 x 256 tiles (two row tiles share every dh fragment; two workgroups per CU)
-    static const int alds_mode = (1);
-    const bool tile64 = bf3 && tile64_on && !rows && h->F % 64 == 0 && h->J % 128 == 0;
-    const bool alds = alds_mode != 0 && !tile64, tall = alds && alds_mode == 2 && h->F % 64 == 0;
-    const int nq = tile64 ? 1 : rows ? 4 : (h->J % 256 == 0) ? 2 : 1;  // 512-, 256- or 128-wide column tiles
-    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / ((tile64 || (bf3 && tall)) ? 64 : 32); dw.n_jt = h->J / (128 * nq);
+    h->d0_rows = false;
+    const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
+    dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
     dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1; dw.keep_heads = d0_keep_heads(h);
     dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
@@ -1647,46 +1586,18 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         h->ev_used += 2;
     }
     // (the extended launch only when there is something to time: it is not a capturable node of a step graph)
-    // IDQN_D0W_PAD: extra (unused) dynamic LDS per workgroup = fewer co-resident workgroups per CU (occupancy experiments)
-    static const int pad = (0);
 #define D0W_LAUNCH(...)                                                                                   \
     do {                                                                                                  \
-        static bool attr_set = false;                                                                     \
-        if (pad > 0 && !attr_set) {                                                                       \
-            IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_dense0_wgrad<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, pad)); \
-            attr_set = true;                                                                              \
-        }                                                                                                 \
-        if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, e0, e1, 0, dw); \
-        else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), pad, q, dw);             \
+        if (e0) hipExtLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, e0, e1, 0, dw); \
+        else hipLaunchKernelGGL((k_dense0_wgrad<__VA_ARGS__>), wgrid, dim3(256), 0, q, dw);               \
     } while (0)
-    // IDQN_D0_FIN=1: the column-tile kernel finishes dL/da3 itself -- the workgroup whose partial arrives last adds the tiles in
-    // order, masks and writes the output forms (DenseWgradArgs::fin_ctr), no k_da3_finalize launch.  Opt-in: bit-identical,
-    // measured 1 us SLOWER (profiles/r4_d0_fin_ab.txt): before its arrival add a workgroup has to drain its stores -- vmcnt
-    // counts in order, so that is every theta / m / v store of its streaming phase -- and the fused kernel grows by 7.6 us,
-    // the 5.4 us launch it saves (+ a boundary) notwithstanding.
-    static const bool fin_on = false;
-    h->d0_fin = false;
-    if (!rows && fuse_adam && nq == 2 && fuse_dg && fin_on && h->fin_ctr && h->planes) {
-        dw.fin_ctr = h->fin_ctr;
-        dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
-        h->d0_fin = true;
-        if (h->ov.n_def > 0) h->ov.dw.fin_ctr = nullptr;  // (the deferred update items of the stream roles emit no data gradient)
-    }
     // Default where it applies (one sample block, J = 512, nothing deferred): one workgroup per PAIR of column tiles
     // (dense0_pair_body) -- the second tile's requests go out under the first tile's last phase, and the workgroup finishes
     // dL/da3 itself (it holds both partials): no partials in HBM, no k_da3_finalize launch, no hand-off.  Bit-identical.
     // Measured on three boxes against two workgroups + finalize (profiles/r4_d0_pair_ab.txt): step -0.7 / -3 / -5 us; the kernel
     // itself takes 2 - 5 us more than the tile kernel (a row's two 1 KB halves are streamed 12 us apart instead of side by side by
     // sibling workgroups), the finalize launch it replaces took 5.3 us + a boundary.
-    //   IDQN_D0_PAIR=0: the tile kernel + k_da3_finalize.
-    //   =2: the pair is two ROW tiles of one column tile (siblings keep streaming a row's halves side by side; partials +
-    //   k_da3_finalize): 3.5 us SLOWER than the tile kernel -- what pays in the pair is the finished data gradient, not the pairing.
-    //   =3: the pair kernel with whole tiles in flight and cross-tile refills at two waves per SIMD (k_dense0_wgrad_pair8): the same
-    //   time to 0.4 us.
-    static const int pair_mode = (1);
-    const bool pair_on = pair_mode == 1 || pair_mode == 3 || (pair_mode == 2 && dw.n_ft % 2 == 0);
-    const bool pair = pair_on && !rows && !h->d0_fin && fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 &&
-                      h->ov.n_def == 0 && dw.upd_end < 0 && pad == 0;
+    const bool pair = fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 && h->ov.n_def == 0 && dw.upd_end < 0;
     if (pair) {
         // one workgroup per PAIR of column tiles; the launch finishes dL/da3 itself
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
@@ -1694,8 +1605,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
         const dim3 pgrid((unsigned)(K * dw.n_ft));
         // one or two heads at the Nature width: theta, m, v and the target nets (4 x 16 MB per head) fit the memory-side cache beside the step's
         // other traffic -- every stream of the update default-policy (K = 1 -1.9 us, K = 2 -4 us; K = 3 +5, K = 5 +16: profiles/r5_d0_keep_online_ab.txt)
-        static const int all_knob = (-1);
-        const bool keep_all = all_knob >= 0 ? all_knob != 0 : (d0_keep_online(h) && 4L * K * h->F * h->J * 4 <= 128L << 20);
+        const bool keep_all = d0_keep_online(h) && 4L * K * h->F * h->J * 4 <= 128L << 20;
         // heads [0, keep) keep theta_new on chip, the others store it non-temporally: one launch per policy (a kernel with both bodies spills)
         const int keep = keep_all ? K : std::min(dw.keep_heads, K);
         for (int part = 0; part < 2; ++part) {
@@ -1747,10 +1657,8 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     HiddenArgs hi;
     hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS / s.G;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
-    if (!s.hidden_fused) {
-        hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
-        tl_mark(h, q, "hidden");
-    }
+    hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
+    tl_mark(h, q, "hidden");
     TdArgs ta;
     ta.hbuf = h->hbuf; ta.qpart = h->qpart; ta.wbase = s.wbase; ta.b0_off = h->off_b0; ta.w1_off = h->off_w1;
     ta.b1_off = h->off_b1; ta.P = h->L.head_stride; ta.K = K;
@@ -1765,8 +1673,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
     ta.chain_err = h->chain_ws ? h->chain_ws + 32 : nullptr;
-    static const bool stage_part = nullptr && atoi(nullptr) == 1;  // (timing experiment: no packing blocks)
-    ta.bcinv_done = (h->planes && !stage_part) ? 1 : 0;
+    ta.bcinv_done = h->planes ? 1 : 0;  // (the plane path's staging launch writes the bias corrections)
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
         WtBuildArgs wb;
@@ -1780,28 +1687,22 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient).  On the fused single-device path it is
     // computed INSIDE the weight-gradient + Adam kernel (theta streams once) and finished by k_da3_finalize; the two-call
     // paths of the data-parallel step need it before the weight gradient and keep the separate kernel.
-    static const bool no_fuse_dg = false;
     // Several sample blocks on ONE device (B > 32): the schedule of the factored data-parallel step without its collectives -- the
     // data gradient as its own launch, the factors split once into bf16 planes, the update contracting them at the bf16 MFMA rate
-    // (k_dense0_wgrad_alds) -- instead of the fused kernel's f32 MFMAs over every block (IDQN_NB_FUSED=1: that kernel; B = 256:
-    // profiles/r5_b256_ab.txt)
-    static const bool nb_fused = false;
-    const bool many = nb >= 3 && h->planes && h->J % 256 == 0 && !nb_fused;  // (two blocks: the same either way, 0.5065 against 0.5085 ms)
-    const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !no_fuse_dg && !many;
+    // (k_dense0_wgrad_alds) -- instead of the fused kernel's f32 MFMAs over every block (B = 256: profiles/r5_b256_ab.txt)
+    const bool many = nb >= 3 && h->planes && h->J % 256 == 0;  // (two blocks: the same either way, 0.5065 against 0.5085 ms)
+    const bool fuse_dg = fuse_adam && !stop_after_dense0 && !stop_before_dense0_wgrad && h->dpart && !many;
     // eight (or a multiple of eight) local sample blocks: the data gradient as the tiled bf16x3 GEMM the i-IQN heads use for their
     // fraction blocks (csrc/iqn_gemm.h: W read once per group of 8 blocks, products at the bf16 rate) + the finalize launch for the
-    // ReLU mask / planes / per-position sums, instead of one f32-MFMA pass over W per block (IDQN_NB_DGRAD_F32=1: that kernel)
-    static const bool nb_dgrad_f32 = false;
-    if (!fuse_dg && many && nb % 8 == 0 && h->dpart && h->J % 16 == 0 && !nb_dgrad_f32) {
+    // ReLU mask / planes / per-position sums, instead of one f32-MFMA pass over W per block
+    if (!fuse_dg && many && nb % 8 == 0 && h->dpart && h->J % 16 == 0) {
         IqnD0DgradArgs g;
         g.dh = dh_of(h, nb); g.wbase = s.wbase; g.dx = h->dpart; g.w_off = h->off_w0; g.K = K; g.nb = nb; g.F = h->F; g.J = h->J;
         const size_t lds = 2 * (size_t)IG_STAGE;
         const unsigned grid = (unsigned)(K * (nb / 8) * cdiv(h->F, 256));
-        // IDQN_NB_DGRAD_FIN=1 (variants build): mask, planes and per-position sums in the GEMM's epilogue instead of the finalize
-        // launch -- bit-identical, 110.3 us against 84.3 + 25.6 (the epilogue's plane stores are 8-byte pieces a row apart)
-        static const bool fin_in_gemm = false;
+        // (mask, planes and per-position sums in the GEMM's epilogue instead of the finalize launch: bit-identical, 110.3 us against
+        // 84.3 + 25.6 -- the epilogue's plane stores are 8-byte pieces a row apart)
         {
-            (void)fin_in_gemm;
             static LdsAttrMark attr;
             if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3(grid), dim3(512), lds, q, g);
@@ -1834,30 +1735,12 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel.  IDQN_OVERLAP=1: the update of its last items is
-    // deferred to stream roles of the Conv_2 pair and Conv_0 weight-gradient launches (they only emit their data-gradient
-    // share here); IDQN_OV_S2 / IDQN_OV_R2 / IDQN_OV_S0 / IDQN_OV_R0: stream workgroups and rounds per launch.
+    // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
     h->ov.n_def = h->ov.left = 0;
-    static const bool overlap = false;
-    if (overlap && fuse_dg && nb == 1 && h->planes) {
-        static const int S2 = (40), R2 = (2);
-        static const int S0 = (96), R0 = (1);
-        const int n_items = K * (h->F / 32) * (h->J / 256);
-        // S2 / S0 ask for that many CUs; the plans say how many workgroups the launches really leave (whole position chunks)
-        int sp2 = 0, sp0 = 0;
-        bool dummy;
-        int rcp = planes_pair(h, 2, nb, q, &dummy, 256 - S2, R2, &sp2);
-        if (!rcp) rcp = planes_wgrad(h, 0, nb, q, 256 - S0, R0, &sp0);
-        if (rcp) return rcp;
-        h->ov.S2 = S2; h->ov.r2 = sp2 > 0 ? R2 : 0; h->ov.S0 = S0; h->ov.r0 = sp0 > 0 ? R0 : 0;
-        h->ov.n_def = std::min(n_items / 2, 2 * (sp2 * h->ov.r2 + sp0 * h->ov.r0));
-        h->ov.left = h->ov.n_def;
-        h->ov.next = n_items - h->ov.n_def;
-    }
     int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
-    if (fuse_dg && !h->d0_rows && !h->d0_fin) {
+    if (fuse_dg && !h->d0_rows) {
         Da3FinalizeArgs fa;
         fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
         fa.n_rows = (long)K * nb * h->F; fa.n_jt = h->J / 256; fa.F = h->F; fa.C = c2->CO; fa.K = K; fa.nb = nb; fa.g = h->gda3;
@@ -1919,26 +1802,6 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bo
             else if (i == 1) rc = planes_pair(h, i, nb, q, &paired);
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
-            if (!rc && i == 0 && adam_role && !ovl) {
-                static const bool role_on = false;
-                static const int role_cus = (96);
-                CWgradArgs wa;
-                WgradPlan* pl = nullptr;
-                const int conv_budget = std::max(K, cu_budget() - role_cus);
-                if (role_on && cu_budget() == 256 && (rc = wgrad_args(h, 0, nb, std::max(1, conv_budget / K), wa, pl)) == IDQN_OK &&
-                    convp_wgrad_adam_built(1, pl->MT, cl[0]->CO / 32, pl->PG) && 256 - pl->n_items >= 16) {
-                    h->npc_used[0] = pl->n_chunks;
-                    for (int j = 0; j < 3; ++j) fill_seg(h, j, h->segs[2 - j], 0);
-                    AdamArgs ad;
-                    const long begin = cl[1]->w_off, end = h->L.head_stride;  // leaf order: Conv_0/{kernel, bias} come first
-                    fill_adam_args(h, begin, end, h->off_w0, h->off_b0, true, false, ad);
-                    rc = convp_launch_wgrad_adam(wa, 1, pl->MT, cl[0]->CO / 32, pl->n_items, pl->lds, q, ad,
-                                                 end - begin - (h->off_b0 - h->off_w0), 256 - pl->n_items);
-                    h->adam_done_from = begin;
-                    tl_mark(h, q, "conv0 wgrad | adam (other small leaves)");
-                    continue;
-                }
-            }
             if (!rc) {
                 if (i == 0 && ovl && h->ov.r0) rc = planes_wgrad(h, i, nb, q, 256 - h->ov.S0, h->ov.r0);
                 else rc = planes_wgrad(h, i, nb, q);
@@ -2201,20 +2064,15 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
                       int B, hipStream_t q) {
     IqnWs& w = h->iqn;
     IqnCosArgs ca;
-    // the embedding on the bf16 matrix cores from operands split once per step (IDQN_IQN_EMBED3=0: the f32-MFMA kernel)
-    static const bool embed3 = ((1) != 0);
-    ca.tau = tau; ca.cosb = w.cosb; ca.cost = embed3 ? nullptr : w.cost; ca.cosp = embed3 ? w.cosp : nullptr; ca.cosa = embed3 ? w.cosa : nullptr; ca.K = K_for_index; ca.N = w.N; ca.B = B;
+    // the embedding on the bf16 matrix cores from operands split once per step
+    ca.tau = tau; ca.cosp = w.cosp; ca.cosa = w.cosa; ca.K = K_for_index; ca.N = w.N; ca.B = B;
     hipLaunchKernelGGL(k_iqn_cos, dim3((unsigned)(V * w.N)), dim3(256), 0, q, ca);
     tl_mark(h, q, "iqn cos features");
-    IqnEmbedArgs ea;
-    ea.cosb = w.cosb; ea.wbase = wbase_v; ea.psi = psi; ea.x = w.xq; ea.we_off = w.off_we; ea.be_off = w.off_be;
-    ea.K = K_for_index; ea.N = w.N; ea.F = h->F;
-    {   // fractions per wave: 8 when that still leaves >= 8 waves per SIMD to overlap, else fewer (IDQN_IQN_EMBED_Q overrides)
-        static const int qenv = (0);
-        int per = qenv > 0 ? qenv : 8;
+    {   // fractions per wave: 8 when that still leaves >= 8 waves per SIMD to overlap, else fewer 
+        int per = 8;
         while (per > 1 && (w.N % per != 0)) --per;
         const dim3 grid((unsigned)cdiv(h->F / 32, 4), (unsigned)V, (unsigned)(w.N / per));
-        if (embed3) {
+        {
             const int n_packed = std::min(V, 2 * K_for_index);  // virtual nets 2K .. 3K - 1 are the target nets again
             IqnWePackArgs pa;
             pa.wbase = wbase_v; pa.wep = w.wep; pa.we_off = w.off_we; pa.F = h->F;
@@ -2223,12 +2081,8 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
             IqnEmbed3Args e3;
             e3.cosp = w.cosp; e3.wep = w.wep; e3.wbase = wbase_v; e3.psi = psi; e3.x = w.xq; e3.be_off = w.off_be;
             e3.K = K_for_index; e3.N = w.N; e3.F = h->F; e3.n_packed = n_packed;
-            // cos fragments through LDS, once per workgroup (IDQN_IQN_EMBED_LDS=0: every wave fetches its own from L2)
-            static const bool e3lds = ((1) != 0);
-            if (e3lds) hipLaunchKernelGGL(k_iqn_embed3l, grid, dim3(256), 2 * 12288, q, e3);
-            else hipLaunchKernelGGL(k_iqn_embed3, grid, dim3(256), 0, q, e3);
-        } else {
-            hipLaunchKernelGGL(k_iqn_embed, grid, dim3(256), 0, q, ea);
+            // cos fragments through LDS, once per workgroup
+            hipLaunchKernelGGL(k_iqn_embed3l, grid, dim3(256), 2 * 12288, q, e3);
         }
     }
     tl_mark(h, q, "iqn embedding x features");
@@ -2238,8 +2092,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
     d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0; d.nt_from = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
-    static const bool gemm = ((1) != 0);
-    if (gemm && w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
+    if (w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;
         g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
         g.V = V; g.nb = w.N; g.NS = w.NS; g.F = h->F; g.J = h->J; g.clk = (long long*)w.clk;
@@ -2353,15 +2206,13 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         dd.dh = w.dh; dd.raw = w.dx; dd.wbase = h->train.wbase; dd.w_off = h->off_w0;
         dd.K = K; dd.nb = w.N; dd.n_ft = h->F / 32; dd.F = h->F; dd.J = h->J; dd.C = h->conv[2].CO; dd.g = h->gda3;
         dd.n_items = (long)K * w.N * cdiv(dd.n_ft, 4);
-        static const bool gemm = ((1) != 0);
-        if (gemm && w.N % 8 == 0 && h->J % 16 == 0) {
+        if (w.N % 8 == 0 && h->J % 16 == 0) {
             IqnD0DgradArgs g;
             g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
             const size_t lds = 2 * (size_t)IG_STAGE;
             const int n_d = K * (w.N / 8) * cdiv(h->F, 256);
             // the weight-gradient GEMM rides in the same launch (IDQN_IQN_MERGE=0: two launches)
-            static const bool merge = ((1) != 0);
-            if (merge && w.g1 && w.N % 16 == 0) {
+            if (w.g1 && w.N % 16 == 0) {
                 IqnD0WgradArgs gw;
                 gw.x = w.xq; gw.dh = w.dh; gw.g[0] = h->grad + h->g_w0_base; gw.g[1] = w.g1; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 2;
                 static LdsAttrMark attr;
@@ -2379,12 +2230,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         tl_mark(h, q, wgrad_done ? "iqn dense0 dgrad + wgrad" : "iqn dense0 dgrad");
     }
     const int QG = w.QG;
-    IqnEmbedBwdArgs eb;
-    eb.cosb = w.cosb; eb.cost = w.cost; eb.wbase = w.wbase_v; eb.psi = h->train.a3; eb.dx = w.dx; eb.dpsi = w.dpsi; eb.gpart = w.gpart;
-    eb.we_off = w.off_we; eb.be_off = w.off_be;
-    eb.K = K; eb.N = w.N; eb.F = h->F;
-    static const bool embed3b = ((1) != 0);
-    if (embed3b) {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
+    {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
         IqnEmbedBwd3Args e3;
         e3.cosp = w.cosp; e3.cosa = w.cosa; e3.wep = w.wep; e3.wbase = w.wbase_v; e3.psi = h->train.a3; e3.dx = w.dx;
         e3.dpsi = w.dpsi; e3.gpart = w.gpart; e3.be_off = w.off_be; e3.K = K; e3.N = w.N; e3.F = h->F;
@@ -2392,8 +2238,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         static LdsAttrMark attr;
         if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_embed_bwd3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_iqn_embed_bwd3, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), lds, q, e3);
-    } else
-    hipLaunchKernelGGL(k_iqn_embed_bwd, dim3((unsigned)cdiv(h->F / 32, 4), K, QG), dim3(256), 0, q, eb);
+    }
     tl_mark(h, q, "iqn embedding backward");
     {
         IqnEmbedGradSumArgs gs;
@@ -2412,8 +2257,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     }
     // Dense_0 weight gradient over the N fraction blocks of every head + Adam: as a GEMM with two block splits and one
     // streaming Adam pass (iqn_gemm.h), or (IDQN_IQN_GEMM=0, N not a multiple of 16) the plain step's fused kernel
-    static const bool gemm_w = ((1) != 0);
-    if (gemm_w && w.g1 && w.N % 16 == 0) {
+    if (w.g1 && w.N % 16 == 0) {
         const long n = (long)h->F * h->J;
         IqnD0WgradArgs g;
         g.x = w.xq; g.dh = w.dh; g.g[0] = h->grad + h->g_w0_base; g.g[1] = w.g1; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J; g.KS = 2;
