@@ -641,7 +641,6 @@ struct TdArgs {
     const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr = plain mean
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
     long long* prof;         // debug (IDQN_CONV_PROF=9): 8 stamps per workgroup, or nullptr
-    const unsigned* chain_err;  // chained conv launches: nonzero = a bounded spin gave up this run -> the losses come out NaN
 };
 
 __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
@@ -831,8 +830,6 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     if (jc == 0) {
         if (t < a.A) G[a.g_b1_off + t] = gb1;
         if (t == 0) {
-            // (a chained launch that could not make progress leaves garbage activations: say so instead of a plausible number)
-            if (a.chain_err && *a.chain_err) loss_acc = __uint_as_float(0x7fc00000u);
             a.losses[k] = loss_acc / (float)a.Bdiv;
             if (!a.bcinv_done) {
                 const double tt = (double)(a.count[k] + 1);

@@ -223,8 +223,20 @@ struct IqnD0DgradArgs {
     int K, nb, F, J;
 };
 
+// Hand-off between the two gradients of one group = (head, 256 rows of Dense_0/kernel) when the Adam update rides in the weight
+// gradient's epilogue (k_iqn_d0_bwd_adam): the data-gradient items of the group READ the rows the epilogue overwrites.  Each of
+// them adds one arrival when its last kernel fragment has been consumed; a weight-gradient item waits for all of them before its
+// first parameter store (bounded: it gives up after ~0.5 s, raises `err` -- the next steps' losses come out NaN -- and goes on),
+// and the last of the group's weight-gradient items to pass re-arms both counters for the next step.
+struct IqnD0Gate {
+    unsigned* arrived;  // [groups]
+    unsigned* passed;   // [groups]
+    unsigned* err;
+    long long* prof;    // debug build (IDQN_CONV_PROF=11): per workgroup {start, products done, wait done, end, item, -, -, -} (100 MHz clock)
+};
+
 template <int D>
-__device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds) {
+__device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds, unsigned* arrive = nullptr) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
     // item = (net, 256-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
     const int nbg = a.nb / 8, nfg = (a.F + 255) / 256;
@@ -337,6 +349,10 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
                 *reinterpret_cast<float4*>(O + 8 * g) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
     }
+    if (arrive) {  // (every wave is past its last product: the kernel fragments it asked for and used have arrived)
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
@@ -351,6 +367,13 @@ struct IqnD0WgradArgs {
     const float* dh;   // [K][nb][J][32]
     float* g[2];       // partial sums [K][F][J] of split 0 / 1
     int K, nb, F, J, KS;
+    // ADAM (KS = 1: the tile's sum is complete): the epilogue updates Dense_0/kernel itself -- parameter arenas with head stride P,
+    // the kernel at w_off; no gradient leaves the registers
+    float *theta, *mu, *nu;
+    const float* bcinv;
+    AdamConsts ad;
+    long P, w_off;
+    const char* dump;  // >= 2 KB + 12 rows of J floats: what the epilogue of a tile past row F reads and writes
 };
 
 template <int D>
@@ -360,8 +383,8 @@ __global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
 }
 
 
-template <int D>
-__device__ __forceinline__ void iqn_d0_wgrad_body(const IqnD0WgradArgs& a, int item, unsigned char* ig_lds) {
+template <int D, bool ADAM = false>
+__device__ __forceinline__ void iqn_d0_wgrad_body(const IqnD0WgradArgs& a, int item, unsigned char* ig_lds, const IqnD0Gate* gate = nullptr, int group = 0, int n_wait = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
     const int n_jh = a.J / 256, nfg = (a.F + 255) / 256;
     const int jh = item % n_jh;
@@ -466,6 +489,78 @@ __device__ __forceinline__ void iqn_d0_wgrad_body(const IqnD0WgradArgs& a, int i
     }
     // tile (i, j): rows f = 256 fg + 32 (4 wn + i) + mfma_row(r, h), column j = 256 jh + 32 (2 wm + j) + bl: a store
     // instruction writes two 128-byte row pieces
+    if constexpr (ADAM) {
+        if (gate) {
+            if (threadIdx.x == 0) {
+                if (gate->prof) gate->prof[8L * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+                int polls = 0;
+                while (__hip_atomic_load(gate->arrived + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_wait) {
+                    if (++polls > (1 << 18)) { __hip_atomic_store(gate->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(64);
+                }
+                const unsigned old = __hip_atomic_fetch_add(gate->passed + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)n_jh - 1u) {  // both have read `arrived`: re-armed for the next step
+                    __hip_atomic_store(gate->arrived + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(gate->passed + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (gate->prof) gate->prof[8L * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+            }
+            __syncthreads();
+        }
+        // Every stream non-temporal, uniform bases + 32-bit byte offsets (the kernel of one head is < 4 GB).  A wave's 8 tiles are
+        // walked as 16 chunks of 8 rows (half a 32 x 32 tile: 3 x 8 loads per lane), EPI_NB - 1 chunks requested ahead of the one
+        // being updated: tile by tile -- 48 loads, wait, 48 stores, and the next loads queued behind those stores -- an item spent
+        // 54 us here, one full round trip per tile.
+        if (!a.theta) return;  // (timing probe of the debug build: the schedule without the epilogue)
+        const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
+        const long hb = (long)k * a.P + a.w_off;
+        const char* const T = reinterpret_cast<const char*>(a.theta + hb);
+        const char* const M = reinterpret_cast<const char*>(a.mu + hb);
+        const char* const V = reinterpret_cast<const char*>(a.nu + hb);
+        const unsigned rowb = (unsigned)a.J * 4u;
+        constexpr int EPI_NB = 4;
+        float th[EPI_NB][8], mm[EPI_NB][8], vv[EPI_NB][8];
+        // chunk c = (tile row i = c >> 2, tile column j = (c >> 1) & 1, row half c & 1): accumulator registers 8 (c & 1) + rr, i.e.
+        // rows mfma_row(8 (c & 1) + rr, h) = 16 (c & 1) + 8 (rr >> 2) + (rr & 3) + 4 h
+        auto live = [&](int c) { return fg * 256 + (4 * wn + (c >> 2)) * 32 < a.F; };  // (F is a multiple of 32: whole tiles are in or out)
+        auto cofs = [&](int c) {
+            const int f0 = fg * 256 + (4 * wn + (c >> 2)) * 32 + 16 * (c & 1) + 4 * h;
+            return (unsigned)f0 * rowb + (unsigned)(jh * 256 + (2 * wm + ((c >> 1) & 1)) * 32 + bl) * 4u;
+        };
+        // (no branches in here: across basic blocks hipcc drains vmcnt to 0 in front of every store.  The tiles past row F of the
+        // last row group read and write a 32 KB dump instead -- a.dump, never read by anyone)
+        auto request = [&](int c) {
+            const bool lv = live(c);
+            const unsigned o0 = lv ? cofs(c) : threadIdx.x * 4u;
+            const char *Tc = lv ? T : a.dump, *Mc = lv ? M : a.dump, *Vc = lv ? V : a.dump;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const unsigned o = o0 + (unsigned)(8 * (rr >> 2) + (rr & 3)) * rowb;
+                th[c % EPI_NB][rr] = __builtin_nontemporal_load(reinterpret_cast<const float*>(Tc + o));
+                mm[c % EPI_NB][rr] = __builtin_nontemporal_load(reinterpret_cast<const float*>(Mc + o));
+                vv[c % EPI_NB][rr] = __builtin_nontemporal_load(reinterpret_cast<const float*>(Vc + o));
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < EPI_NB - 1; ++c) request(c);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c + EPI_NB - 1 < 16) request(c + EPI_NB - 1);
+            const bool lv = live(c);
+            const unsigned o0 = lv ? cofs(c) : threadIdx.x * 4u;
+            char *Tc = const_cast<char*>(lv ? T : a.dump), *Mc = const_cast<char*>(lv ? M : a.dump), *Vc = const_cast<char*>(lv ? V : a.dump);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const unsigned o = o0 + (unsigned)(8 * (rr >> 2) + (rr & 3)) * rowb;
+                float t1 = th[c % EPI_NB][rr], m1 = mm[c % EPI_NB][rr], v1 = vv[c % EPI_NB][rr];
+                adam_elem(a.ad, bc1, bc2, acc[c >> 2][(c >> 1) & 1][8 * (c & 1) + rr], t1, m1, v1);
+                __builtin_nontemporal_store(t1, reinterpret_cast<float*>(Tc + o));
+                __builtin_nontemporal_store(m1, reinterpret_cast<float*>(Mc + o));
+                __builtin_nontemporal_store(v1, reinterpret_cast<float*>(Vc + o));
+            }
+        }
+        return;
+    }
     float* G = a.g[ks] + (long)k * a.F * a.J + jh * 256 + bl;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -496,6 +591,30 @@ __global__ __launch_bounds__(512) void k_iqn_d0_bwd(IqnD0DgradArgs d, int n_dgra
         const int n = (int)gridDim.x - n_dgrad, b = (int)blockIdx.x - n_dgrad;
         const int q = n >> 3, r = n & 7, x = b & 7;
         iqn_d0_wgrad_body<D>(w, (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3), ig_lds);
+    }
+}
+
+// The same launch with the Adam update of Dense_0/kernel in the weight gradient's epilogue (one split: the tile's sum is complete in
+// registers): no gradient written and read back (2 x 79 MB at K = 5 with one split), no Adam launch, and the parameter streams of a
+// finishing item run under the other CUs' matrix work.  A group = (head, 256 kernel rows): nb / 8 data-gradient items, which read
+// those rows, and J / 256 weight-gradient items, which overwrite them (IqnD0Gate).  Group g lives on XCD g % 8 (workgroup b runs on
+// XCD b % 8), its data-gradient items at earlier slots there than its weight-gradient items: they are dispatched before the items
+// that wait for them and wait for nothing themselves, so the wait cannot block progress, and they share the group's kernel rows /
+// x rows through that XCD's L2.  The order itself is the host's (qnet.hip, plan_iqn_bwd_order: it decides where the long items
+// -- two k-halves + the epilogue -- start, i.e. the tail of the launch).
+template <int D>
+__global__ __launch_bounds__(512) void k_iqn_d0_bwd_adam(IqnD0DgradArgs d, IqnD0WgradArgs w, IqnD0Gate gate, const int32_t* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
+    const int nbg = d.nb / 8, n_jh = w.J / 256;
+    const int e = __builtin_amdgcn_readfirstlane(items[blockIdx.x]);  // (group << 8) | item of the group, or -1 (qnet.hip, plan_iqn_bwd_order)
+    if (e < 0) return;
+    const int group = e >> 8, within = e & 255;
+    if (gate.prof && threadIdx.x == 0) { gate.prof[8L * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); gate.prof[8L * blockIdx.x + 4] = e; }
+    if (within < nbg) iqn_d0_dgrad_body<D>(d, group * nbg + within, ig_lds, gate.arrived + group);
+    else iqn_d0_wgrad_body<D, true>(w, group * n_jh + (within - nbg), ig_lds, &gate, group, nbg);
+    if (gate.prof) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) gate.prof[8L * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -210,6 +210,7 @@ struct IqnLossArgs {
     double* cum;
     int finish_step;
     float* dbg;  // [K][(2 N + 32 + 1)][32]: Z_online(a) rows, Z_target(a*) rows, q_select rows (32), a* row -- tests
+    const unsigned* gate_err;  // nonzero: a bounded wait of an earlier step's fused Dense_0 update (iqn_gemm.h, IqnD0Gate) gave up -> NaN losses
 };
 __global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs a) {
     extern __shared__ float sm[];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_iqn_loss(IqnLossArgs a) {
             s += sb;
         }
         const float loss = s / (float)a.Bdiv;
-        a.losses[k] = loss;
+        a.losses[k] = (a.gate_err && *a.gate_err) ? __uint_as_float(0x7fc00000u) : loss;
         if (a.finish_step) {
             a.count[k] += 1;
             a.cum[k] = a.cum[k] + (double)loss;

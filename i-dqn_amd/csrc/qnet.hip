@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <queue>
+#include <functional>
 
 #include <map>
 #include <tuple>
@@ -233,6 +235,10 @@ struct IqnWs {
     int HG = 1;              // fraction groups of k_iqn_dh (partials hpart)
     float* hpart = nullptr;  // [HG][K][J * A + J + A]
     float* clk = nullptr;  // IDQN_IQN_CLOCK=1: clock stamps of the forward GEMM's workgroups [<= 1024][4] int64 (debug buffer "iqn_clk")
+    int32_t* bwd_items = nullptr;  // dispatch order of the merged Dense_0 gradient launch with Adam in its epilogue (plan_iqn_bwd_order)
+    int bwd_blocks = 0;
+    unsigned* gate = nullptr;  // [2 * K * ceil(F / 256) + 64]: IqnD0Gate (arrived, passed, err) of the fused Dense_0 update
+    bool d0_adam_done = false;  // this step's merged gradient launch updated Dense_0/kernel itself
     float* g1 = nullptr;  // second partial of the Dense_0 weight gradient [K][F * J] (iqn_gemm.h), N a multiple of 16 only
     long off_we = 0, off_be = 0;
 };
@@ -299,9 +305,7 @@ struct idqn_handle_s {
     std::map<std::tuple<int, int, int, int>, FwdPlan> fwd_plans;  // (role, n_nets, nb, target workgroups)
     std::map<std::tuple<int, int, int>, WgradPlan> wgrad_plans;   // (layer, nb, position chunks)
     int npc_used[3] = {0, 0, 0};  // position chunks (= slabs per head) the weight-gradient launches of THIS step wrote
-    // chained conv launches (convp_chain.hip): [0] the step's epoch (bumped by the staging launch), [32] err, [64...) flags
-    unsigned* chain_ws = nullptr;
-    int n_cus = 256;  // CUs of the device (a chained launch needs every workgroup resident)
+    int n_cus = 256;  // CUs of the device
     float* cprof = nullptr;  // debug (IDQN_CONV_PROF=role): phase stamps of one plane conv launch
     int cprof_role = -1;
     int npc[3], pos_per_chunk[3];
@@ -444,6 +448,7 @@ int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets,
     return IDQN_OK;
 }
 
+int plan_iqn_bwd_order(idqn_handle_s* h, int forced_e);
 int cnn_setup(idqn_handle_s* h) {
     const idqn_config_t& c = h->cfg;
     int ih = c.obs_h, iw = c.obs_w, ci = c.obs_c;
@@ -505,9 +510,6 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&h->cprof, (h->cprof_role == 10 ? 3 : 1) * 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
     }
     if (h->planes) {
-        float* ws = nullptr;
-        if ((rc = alloc_zero(&ws, 64 + 3L * 4096, h, "chain_ws"))) return rc;  // (the third block: arrival counters of the Dense_0 forward)
-        h->chain_ws = reinterpret_cast<unsigned*>(ws);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
@@ -641,9 +643,78 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&w.hpart, (long)w.HG * K * ((long)h->J * c.n_actions + h->J + c.n_actions), h, "iqn_hpart"))) return rc;
         if (debug_env("IDQN_IQN_CLOCK") && (rc = alloc_zero(&w.clk, (1024 + 256 * 8 * 2 + 512) * 2, h, "iqn_clk"))) return rc;
         if (w.N % 16 == 0 && (rc = alloc_zero(&w.g1, (long)K * h->F * h->J, h, "iqn_g1"))) return rc;
+        {
+            float* gw = nullptr;
+            if ((rc = alloc_zero(&gw, 2L * K * cdiv(h->F, 256) + 64, h, "iqn_gate"))) return rc;
+            w.gate = reinterpret_cast<unsigned*>(gw);
+        }
+        if (w.N % 16 == 0 && h->J % 256 == 0 && (rc = plan_iqn_bwd_order(h, debug_int("IDQN_IQN_BWD_EARLY", -1)))) return rc;
         if ((rc = alloc_zero(&w.dbg, (long)K * (2 * w.N + 33) * 32, h, "iqn_dbg"))) return rc;
     }
     h->dominant = "k_dense0_wgrad";
+    return IDQN_OK;
+}
+
+// Dispatch order of k_iqn_d0_bwd_adam (iqn_gemm.h).  A group = (head, 256 rows of Dense_0/kernel) has nbg data-gradient items, which read
+// those rows, and n_jh weight-gradient items, which overwrite them in their epilogue and are ~2 x as long (N = 32).  Rules: a group's
+// items sit on ONE XCD (workgroup b runs on XCD b % 8; its slot there is b / 8) with the data-gradient items at EARLIER slots than
+// the weight-gradient items -- they are dispatched first and wait for nothing, so the gate of the epilogue cannot block progress.
+// Within that, the order decides the launch time: the last item of every valid order is a long one, and with each group's items
+// back to back the long items start as late as 0.7 of the launch (513 us measured where 408 us of work per CU were queued:
+// profiles/r6_iiqn_adam_fuse.txt).  Candidates `e`: the first e groups of the XCD back to back (their long items start in the
+// first round), then every other data-gradient item, then the remaining long items together as the last round.  The candidate
+// with the smallest list-scheduled makespan on the XCD's 32 CUs, averaged over +- 8 % of the long items' length, is taken.
+static double iqn_bwd_makespan(const std::vector<char>& seq, double dw, int ncu) {
+    std::priority_queue<double, std::vector<double>, std::greater<double>> cus;
+    for (int i = 0; i < ncu; ++i) cus.push(0.0);
+    double end = 0;
+    for (char it : seq) {
+        const double e = cus.top() + (it ? dw : 1.0);
+        cus.pop();
+        cus.push(e);
+        end = std::max(end, e);
+    }
+    return end;
+}
+static std::vector<char> iqn_bwd_seq(int n, int e, int nbg, int n_jh) {  // 0 = data-gradient item, 1 = weight-gradient item
+    std::vector<char> s;
+    for (int g = 0; g < e; ++g) { s.insert(s.end(), nbg, 0); s.insert(s.end(), n_jh, 1); }
+    s.insert(s.end(), (size_t)nbg * (n - e), 0);
+    s.insert(s.end(), (size_t)n_jh * (n - e), 1);
+    return s;
+}
+int plan_iqn_bwd_order(idqn_handle_s* h, int forced_e) {
+    IqnWs& w = h->iqn;
+    const int K = h->cfg.n_heads, nbg = w.N / 8, n_jh = h->J / 256, G = K * cdiv(h->F, 256), per = nbg + n_jh;
+    // lengths in units of a data-gradient item: 8 blocks x 256 rows x J against 256 x 256 x (32 N) products (measured 141 : 84 us at N = 32, J = 512) + epilogue
+    const double dw = 1.68 * (w.N / 32.0) * (512.0 / h->J) + 0.33;
+    const int S = cdiv(G, 8) * per;
+    std::vector<int32_t> items((size_t)S * 8, -1);
+    for (int x = 0; x < 8; ++x) {
+        const int n = (G - x + 7) / 8;  // groups x, x + 8, ...
+        int best_e = n;
+        double best = 0;
+        for (int e = 0; e <= n; ++e) {
+            const std::vector<char> seq = iqn_bwd_seq(n, e, nbg, n_jh);
+            double sum = 0;
+            for (double sc : {0.92, 0.96, 1.0, 1.04, 1.08}) sum += iqn_bwd_makespan(seq, dw * sc, std::max(1, h->n_cus / 8));
+            if (e == 0 || sum < best) { best = sum; best_e = e; }
+        }
+        if (forced_e >= 0) best_e = std::min(forced_e, n);
+        if (debug_on("IDQN_PLAN_PRINT") && x == 0) fprintf(stderr, "[plan] iqn dense0 gradients: %d groups on XCD 0, %d of them back to back\n", n, best_e);
+        int s = 0;
+        auto put = [&](int g, int within) { items[(size_t)(s++) * 8 + x] = ((x + 8 * g) << 8) | within; };
+        for (int g = 0; g < best_e; ++g)
+            for (int i = 0; i < per; ++i) put(g, i);
+        for (int g = best_e; g < n; ++g)
+            for (int i = 0; i < nbg; ++i) put(g, i);
+        for (int g = best_e; g < n; ++g)
+            for (int i = nbg; i < per; ++i) put(g, i);
+    }
+    if (w.bwd_items) (void)hipFree(w.bwd_items);
+    IDQN_HIP_CHECK(hipMalloc((void**)&w.bwd_items, items.size() * 4));
+    IDQN_HIP_CHECK(hipMemcpy(w.bwd_items, items.data(), items.size() * 4, hipMemcpyHostToDevice));
+    w.bwd_blocks = (int)items.size();
     return IDQN_OK;
 }
 
@@ -781,7 +852,7 @@ int fc_setup(idqn_handle_s* h) {
     if ((rc = alloc_zero(&h->fc_ws, K * ((long)(n.L + 3) * B * n.dmax + 2 * B) + 2 * 32 * n.dmax, h, "fc_ws"))) return rc;
     if ((rc = alloc_zero(&h->qdbg, 2 * K * B * c.n_actions, h, "q"))) return rc;
     h->fc_plan_ = fc_plan(n);
-    if (nullptr || n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
+    if (n.dmax > FC_MAX_WIDTH) h->fc_plan_.BS = 0;  // wider layers: the generic kernel (any width)
     if (h->fc_plan_.BS) {
         const int bytes = (int)(h->fc_plan_.floats * 4);
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -790,15 +861,13 @@ int fc_setup(idqn_handle_s* h) {
     }
     h->fcp_plan_ = fc_par_plan(n, h->L.head_stride);
     // IDQN_FC_PAR=0: the two-launch path (k_fc_step_mfma / k_fc_step_lds + k_adam) for every batch size
-    if ((getenv("IDQN_FC_PAR") && atoi(getenv("IDQN_FC_PAR")) == 0) || nullptr || nullptr ||
-        n.dmax > FC_MAX_WIDTH)
-        h->fcp_plan_.floats = 0;
+    if ((getenv("IDQN_FC_PAR") && atoi(getenv("IDQN_FC_PAR")) == 0) || n.dmax > FC_MAX_WIDTH) h->fcp_plan_.floats = 0;
     if (h->fcp_plan_.floats)
         IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_fc_step_par, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->fcp_plan_.floats * 4)));
     h->fcm_plan_ = fc_mfma_plan(n);
-    if (nullptr || nullptr || n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;  // A/B switches
+    if (n.dmax > FC_MAX_WIDTH) h->fcm_plan_.floats = 0;
     h->fcm_global_ = false;
-    if (!h->fcm_plan_.floats && !(nullptr || nullptr || nullptr || n.dmax > FC_MAX_WIDTH)) {
+    if (!h->fcm_plan_.floats && n.dmax <= FC_MAX_WIDTH) {
         // the matrix does not fit LDS beside the activations: the same kernel with the weight operand read from global memory
         h->fcm_plan_ = fc_mfma_plan_g(n);
         h->fcm_global_ = h->fcm_plan_.floats != 0;
@@ -1672,7 +1741,6 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
     ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
-    ta.chain_err = h->chain_ws ? h->chain_ws + 32 : nullptr;
     ta.bcinv_done = h->planes ? 1 : 0;  // (the plane path's staging launch writes the bias corrections)
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
@@ -2182,7 +2250,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
     la.z = w.z; la.K = K; la.N = w.N; la.A = A;
     la.B = batch; la.Bdiv = batch; la.action = action_dev; la.reward = reward_dev; la.terminal = terminal_dev; la.tau = tau_dev;
     la.gamma_n = h->gamma_n; la.dq = w.dq; la.losses = h->losses; la.count = h->count; la.cum = h->cum; la.finish_step = 1;
-    la.dbg = w.dbg;
+    la.dbg = w.dbg; la.gate_err = w.gate + 2L * K * cdiv(h->F, 256);
     hipLaunchKernelGGL(k_iqn_loss, dim3(K), dim3(256), (size_t)(2 * w.N * 32 + 32 * 32 + 8 * 32) * 4, q, la);
     tl_mark(h, q, "iqn quantile huber loss");
     const long w0n = h->g_w0_end - h->g_w0_begin;
@@ -2211,9 +2279,25 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
             g.dh = w.dh; g.wbase = h->train.wbase; g.dx = w.dx; g.w_off = h->off_w0; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J;
             const size_t lds = 2 * (size_t)IG_STAGE;
             const int n_d = K * (w.N / 8) * cdiv(h->F, 256);
-            // the weight-gradient GEMM rides in the same launch (IDQN_IQN_MERGE=0: two launches)
-            if (w.g1 && w.N % 16 == 0) {
+            // the weight-gradient GEMM rides in the same launch
+            const int n_groups = K * cdiv(h->F, 256), n_w1 = n_groups * (h->J / 256);
+            w.d0_adam_done = false;
+            if (w.g1 && w.bwd_items && n_d + n_w1 > cu_budget() && debug_int("IDQN_IQN_ADAM_FUSE", 1)) {
+                // more than one round of items even with unsplit weight-gradient tiles: one split, Adam in its epilogue (k_iqn_d0_bwd_adam)
                 IqnD0WgradArgs gw;
+                gw.x = w.xq; gw.dh = w.dh; gw.g[0] = gw.g[1] = nullptr; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 1;
+                gw.theta = debug_on("IDQN_IQN_ADAM_SKIP") ? nullptr : h->online; gw.mu = h->mu; gw.nu = h->nu; gw.bcinv = h->bcinv; gw.ad = h->ad; gw.P = h->L.head_stride; gw.w_off = h->off_w0; gw.dump = reinterpret_cast<const char*>(w.g1);  // (g1: K * F * J floats, unused on this path)
+                IqnD0Gate gate;
+                gate.arrived = w.gate; gate.passed = w.gate + n_groups; gate.err = w.gate + 2L * n_groups;
+                gate.prof = (h->cprof && h->cprof_role == 11) ? (long long*)h->cprof : nullptr;
+                static LdsAttrMark attr;
+                if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_bwd_adam<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_iqn_d0_bwd_adam<2>, dim3((unsigned)w.bwd_blocks), dim3(512), lds, q, g, gw, gate, w.bwd_items);
+                wgrad_done = true;
+                w.d0_adam_done = true;
+            } else if (w.g1 && w.N % 16 == 0) {
+                IqnD0WgradArgs gw;
+                memset(&gw, 0, sizeof(gw));
                 gw.x = w.xq; gw.dh = w.dh; gw.g[0] = h->grad + h->g_w0_base; gw.g[1] = w.g1; gw.K = K; gw.nb = w.N; gw.F = h->F; gw.J = h->J; gw.KS = 2;
                 static LdsAttrMark attr;
                 if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2227,7 +2311,7 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         } else {
             hipLaunchKernelGGL((k_dense0_dgrad<4>), dim3((unsigned)dd.n_items), dim3(256), h->J * 32 * 4, q, dd);
         }
-        tl_mark(h, q, wgrad_done ? "iqn dense0 dgrad + wgrad" : "iqn dense0 dgrad");
+        tl_mark(h, q, w.d0_adam_done ? "iqn dense0 dgrad + wgrad + adam" : wgrad_done ? "iqn dense0 dgrad + wgrad" : "iqn dense0 dgrad");
     }
     const int QG = w.QG;
     {  // (the forward of this step packed the embedding kernels and wrote the cos planes)
@@ -2255,11 +2339,13 @@ extern "C" int idqn_iqn_learn_on_batch(idqn_handle_t h, const void* state_dev, c
         hipLaunchKernelGGL(k_da3_finalize, dim3(cdiv(fa.n_rows * 8, 256)), dim3(256), 0, q, fa);
         tl_mark(h, q, "da3 finalize (sum, mask, planes)");
     }
-    // Dense_0 weight gradient over the N fraction blocks of every head + Adam: as a GEMM with two block splits and one
-    // streaming Adam pass (iqn_gemm.h), or (IDQN_IQN_GEMM=0, N not a multiple of 16) the plain step's fused kernel
-    if (w.g1 && w.N % 16 == 0) {
+    // Dense_0 weight gradient over the N fraction blocks of every head + Adam: inside the merged launch above, or as a GEMM with
+    // two block splits and one streaming Adam pass (iqn_gemm.h), or (N not a multiple of 16) the plain step's fused kernel
+    if (w.d0_adam_done) {
+    } else if (w.g1 && w.N % 16 == 0) {
         const long n = (long)h->F * h->J;
         IqnD0WgradArgs g;
+        memset(&g, 0, sizeof(g));
         g.x = w.xq; g.dh = w.dh; g.g[0] = h->grad + h->g_w0_base; g.g[1] = w.g1; g.K = K; g.nb = w.N; g.F = h->F; g.J = h->J; g.KS = 2;
         const size_t lds = 2 * (size_t)IG_STAGE;
         static LdsAttrMark attr;
@@ -2606,8 +2692,8 @@ static int act_host_wait(idqn_handle_t h, int32_t* action_host_pinned, hipStream
             }
         }
         if (!seen) {  // resynchronise the two counters, then report
-            hipStreamSynchronize(q);
-            hipMemcpy(&h->act_expected, h->act_seq, 4, hipMemcpyDeviceToHost);
+            IDQN_HIP_CHECK(hipStreamSynchronize(q));
+            IDQN_HIP_CHECK(hipMemcpy(&h->act_expected, h->act_seq, 4, hipMemcpyDeviceToHost));
             IDQN_REQUIRE(false, "idqn_act_host: the acting launch finished without delivering its action");
         }
         *action_host_pinned = mail[0];
