@@ -1243,6 +1243,7 @@ int planes_stage(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* 
         a.act_out = h->rp_action; a.rew_out = h->rp_reward; a.term_out = h->rp_terminal;
         return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q, &h->rp->slots);
     }
+    if (debug_on("IDQN_STAGE_SKIP_PIXELS")) a.n_prep_blocks = 0;  // timing probe: the launch without its pixel half (wrong results)
     return convp_launch_stage(a, a.n_prep_blocks + (int)blocks, q);
 }
 
