@@ -641,9 +641,15 @@ struct TdArgs {
     const float* is_weight;  // [B] per-sample loss weights (prioritized-replay extension) or nullptr = plain mean
     float* td_abs;           // [K][B] out: |TD error| per head and sample, or nullptr
     long long* prof;         // debug (IDQN_CONV_PROF=9): 8 stamps per workgroup, or nullptr
+    // Several sample blocks, one workgroup per (chunk, head, BLOCK) (gridDim.z = nb) instead of a loop over the blocks: every
+    // workgroup leaves its block's gradient partials in bpart[(head, chunk)][block][TD_BPART] and adds an arrival; the last one
+    // to arrive adds the nb partials IN BLOCK ORDER -- the loop's order, bit-identical -- and writes the leaves.  nullptr: the loop.
+    float* bpart;
+    unsigned* bctr;          // [K * J / 32], zero between launches
 };
+constexpr int TD_BPART = 1152;  // 1024 Dense_1 kernel elements of the chunk, 32 Dense_0 biases, 32 Dense_1 biases, the loss
 
-__device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
+__device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k, const int bb_only = -1) {
     __shared__ float hs[32][33];
     __shared__ float qo[32 * 32], qt[32 * 32];
     __shared__ float qmax[32], cs[32], red[1];
@@ -658,7 +664,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb0[4] = {0.f, 0.f, 0.f, 0.f}, gb1 = 0.f, loss_acc = 0.f;
     long long ts[8];
     ts[0] = clock64();
-    for (int bb = 0; bb < a.nb; ++bb) {
+    for (int bb = bb_only < 0 ? 0 : bb_only; bb < (bb_only < 0 ? a.nb : bb_only + 1); ++bb) {
         const long so = (long)k * a.nb + bb, st = (long)(a.K + k) * a.nb + bb;
         // this block's hidden rows do not depend on the q reduction below: have them in flight meanwhile
         const float* hb = a.hbuf + so * a.J * 32 + (long)jc * 32 * 32;
@@ -704,7 +710,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
                 b1o[r] = po[a.b1_off + (e >> 5)];
                 b1t[r] = pt[a.b1_off + (e >> 5)];
             }
-            if (bb == 0) {
+            if (bb == 0 || bb_only >= 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) wv[r] = t + 256 * r < 32 * a.A ? w1[(long)jc * 32 * a.A + t + 256 * r] : 0.f;
             }
@@ -734,7 +740,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
             case 3: q_reduce(std::integral_constant<int, 3>{}); break;
             default: q_reduce(std::integral_constant<int, 4>{}); break;
         }
-        if (bb == 0) {
+        if (bb == 0 || bb_only >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (t + 256 * r < 32 * a.A) w1s[t + 256 * r] = wv[r];
@@ -814,6 +820,60 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
         }
         __syncthreads();
     }
+    if (bb_only >= 0) {
+        // this block's partials past the non-coherent caches, then the arrival; the last workgroup of the (head, chunk) goes on
+        float* P = a.bpart + (((long)k * NJC + jc) * a.nb + bb_only) * TD_BPART;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) __hip_atomic_store(P + t + 256 * m, gw[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (b == 0) __hip_atomic_store(P + 1024 + jj + 8 * i, gb0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < 32) __hip_atomic_store(P + 1056 + t, gb1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) __hip_atomic_store(P + 1088, loss_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            unsigned* ctr = a.bctr + (long)k * NJC + jc;
+            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)a.nb - 1u;
+            if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+            acts[0] = last;
+        }
+        __syncthreads();
+        if (!acts[0]) return;
+        const float* P0 = a.bpart + ((long)k * NJC + jc) * a.nb * TD_BPART;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gw[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gb0[i] = 0.f;
+        gb1 = 0.f;
+        loss_acc = 0.f;
+        for (int x0 = 0; x0 < a.nb; x0 += 8) {  // (the loop's order: 0 + p0 + p1 + ...; eight blocks' partials in flight at once)
+            float pw[8][4], pb0[8][4], pb1[8], pl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* Px = P0 + (long)min(x0 + u, a.nb - 1) * TD_BPART;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) pw[u][m] = __hip_atomic_load(Px + t + 256 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pb0[u][i] = __hip_atomic_load(Px + 1024 + jj + 8 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pb1[u] = __hip_atomic_load(Px + 1056 + (t & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pl[u] = __hip_atomic_load(Px + 1088, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (x0 + u < a.nb) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) gw[m] += pw[u][m];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gb0[i] += pb0[u][i];
+                    gb1 += pb1[u];
+                    loss_acc += pl[u];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (b == 0) G[a.g_b0_off + jc * 32 + jj + 8 * i] = gb0[i];
@@ -845,7 +905,7 @@ __device__ __forceinline__ void td_dh_body(const TdArgs& a, int jc, int k) {
 }
 __global__ __launch_bounds__(256) void k_td_dh(TdArgs a) {
     warm_kernargs<sizeof(TdArgs)>();
-    td_dh_body(a, blockIdx.x, blockIdx.y);
+    td_dh_body(a, blockIdx.x, blockIdx.y, a.bpart ? (int)blockIdx.z : -1);
 }
 
 // The TD / loss kernel has J / 32 x K workgroups (80 for the Atari net) and is latency-bound; the re-indexing of the

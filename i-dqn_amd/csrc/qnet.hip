@@ -306,6 +306,8 @@ struct idqn_handle_s {
     std::map<std::tuple<int, int, int>, WgradPlan> wgrad_plans;   // (layer, nb, position chunks)
     int npc_used[3] = {0, 0, 0};  // position chunks (= slabs per head) the weight-gradient launches of THIS step wrote
     int n_cus = 256;  // CUs of the device
+    float* td_bpart = nullptr;   // [K * J / 32][nb][TD_BPART] per-block gradient partials of k_td_dh (max_batch > 32)
+    unsigned* td_bctr = nullptr;
     float* cprof = nullptr;  // debug (IDQN_CONV_PROF=role): phase stamps of one plane conv launch
     int cprof_role = -1;
     int npc[3], pos_per_chunk[3];
@@ -510,6 +512,12 @@ int cnn_setup(idqn_handle_s* h) {
         if ((rc = alloc_zero(&h->cprof, (h->cprof_role == 10 ? 3 : 1) * 2L * 2 * 8 * 4096, h, "cprof"))) return rc;
     }
     if (h->planes) {
+        if (nb > 1) {
+            float* c = nullptr;
+            if ((rc = alloc_zero(&h->td_bpart, (long)K * (h->J / 32) * nb * TD_BPART, h, "td_bpart"))) return rc;
+            if ((rc = alloc_zero(&c, (long)K * (h->J / 32) + 16, h, "td_bctr"))) return rc;
+            h->td_bctr = reinterpret_cast<unsigned*>(c);
+        }
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
         if ((rc = alloc_zero16(&h->da3p, (long)K * nb * h->gda3.block * 3, h, "da3p"))) return rc;
@@ -1741,7 +1749,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     ta.dh = dh_of(h, nb); ta.q_dbg = h->qdbg; ta.grad = h->grad; ta.losses = h->losses;
     ta.count = h->count; ta.bcinv = h->bcinv; ta.b1 = h->ad.b1; ta.b2 = h->ad.b2;
     ta.cum = h->cum; ta.finish_step = fuse_adam ? 1 : 0;
-    ta.is_weight = h->is_weight; ta.td_abs = h->td_abs;
+    ta.is_weight = h->is_weight; ta.td_abs = h->td_abs; ta.bpart = nullptr; ta.bctr = nullptr;
     ta.bcinv_done = h->planes ? 1 : 0;  // (the plane path's staging launch writes the bias corrections)
     h->wt_ready = false;
     if (!h->planes) {  // (the plane path packs the data-gradient kernels in its staging launch)
@@ -1750,7 +1758,10 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         hipLaunchKernelGGL(k_td_dh_wt, dim3((h->J / 32) * K + nx * K * 2), dim3(256), 0, q, ta, wb, nx);
         h->wt_ready = true;
     } else {
-        hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K), dim3(256), 0, q, ta);
+        // several sample blocks: one workgroup per block, the last to arrive adds the blocks' gradient partials in block order
+        const bool per_block = nb > 1 && h->td_bpart && debug_int("IDQN_TD_PER_BLOCK", 1);
+        if (per_block) { ta.bpart = h->td_bpart; ta.bctr = h->td_bctr; }
+        hipLaunchKernelGGL(k_td_dh, dim3(h->J / 32, K, per_block ? nb : 1), dim3(256), 0, q, ta);
     }
     tl_mark(h, q, "td + loss + dh");
     // Dense_0 data gradient -> da3 (zero-bordered for the Conv_2 data gradient).  On the fused single-device path it is
