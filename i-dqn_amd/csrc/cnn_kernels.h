@@ -263,21 +263,6 @@ struct DenseFwdArgs {
     int n_nets, nb, NS, n_jt, F, J;
     int net_rot;  // work item n covers net (n + net_rot) % n_nets: the training set runs its target nets first, so that
                   // the online Dense_0 kernel is the most recently streamed 79 MB when the backward pass re-reads it
-    int G;        // k_dense0_fwd3: 4 = the four waves of a workgroup take four CONSECUTIVE splits of one (net, block, column
-                  // tile) and add their accumulators through LDS in split order before anything is written: part holds
-                  // NS / 4 slabs per (net, block) instead of NS (a quarter of the partial traffic, k_hidden adds a quarter
-                  // of the slabs).  1 = one slab per split (NS not a multiple of 4; 64 KB of dynamic LDS not requested).
-    // G == 4 and arrive != nullptr: the head's first stage rides in this launch.  Every workgroup of a (net, block, column
-    // tile) group writes its slab write-through and adds to the group's arrival counter; the one whose add comes LAST
-    // (whichever it is: it then adds the slabs in slab order, so the sums do not depend on it) does what k_hidden does for
-    // the tile's 128 hidden units -- bias + ReLU -> hbuf, the Dense_1 chunk partials -> qpart (architectures/dqn.py:67-70)
-    // -- and re-arms the counter.  Bit-identical to d0fwd + k_hidden, one launch and the re-read of the slabs by a second
-    // grid fewer.
-    unsigned* arrive;   // [n_nets * nb * n_jt], zero between launches
-    float* hbuf;        // [n_nets][nb][J][32]
-    float* qpart;       // [n_nets][nb][J / 32][32][32]
-    long b0_off, w1_off;
-    int A;
     int bb_inner;  // k_dense0_fwd3: the sample block is the FASTEST index of the work item (B > 32)
     int nt_from;   // k_dense0_fwd3: W of nets [0, nt_from) with default-policy loads, of the others non-temporally
 };
@@ -350,9 +335,9 @@ __global__ __launch_bounds__(256) void k_dense0_fwd(DenseFwdArgs a) {
 // MFMA chain (704 x 64 cycles per wave on < 1 wave per SIMD: 4.1 TB/s); this one by HBM and the split's VALU work.
 __device__ __forceinline__ bf16x8 planes8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, (u32x4){p[0], p[1], p[2], p[3]}); }
 
-template <int RING, bool PLAIN = true, int ABL = 0, bool XW = false, bool WNT = (D0_FWD_NT != 0)>  // XW: the k-step's 2 KB of activations as two 16-byte loads per lane, turned round in wave-private LDS; ABL (timing ablations, WRONG results): 1 no activation loads, 2 no partial stores, 4 no split / products, 8 four k-steps requested at once; RING: k-steps of W / activation rows in flight per lane (4: one wave per SIMD; 3: two);
-__device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PLAIN: the compiler's own order of split and products (A/B)
-    extern __shared__ __attribute__((aligned(16))) float d3_red[];  // G == 4: [wave][tile q][register r][lane]
+template <bool PLAIN = true, bool WNT = (D0_FWD_NT != 0)>  // PLAIN: the compiler's own order of split and products; WNT: non-temporal W loads
+__device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {
+    constexpr int RING = 4;  // k-steps of W / activation rows in flight per lane (one wave per SIMD)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bl = lane & 31, h = lane >> 5;
     long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // (4 waves per workgroup; fewer when the launch has too few items to put one workgroup on every CU otherwise)
     int jt, s;
@@ -371,12 +356,10 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
         s = (int)(item % a.NS);
         n = ((int)(item / a.NS) + a.net_rot) % a.n_nets;
     } else {
-        if (a.G != 4) {
-            jt = (int)(item % a.n_jt);
-            item /= a.n_jt;
-            s = (int)(item % a.NS);
-            item /= a.NS;
-        }
+        jt = (int)(item % a.n_jt);
+        item /= a.n_jt;
+        s = (int)(item % a.NS);
+        item /= a.NS;
         bb = (int)(item % a.nb);
         n = ((int)(item / a.nb) + a.net_rot) % a.n_nets;
     }
@@ -399,29 +382,14 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
     // per SIMD the kernel was bound by how many bytes it kept in flight, not by HBM or the matrix cores)
     float4 wv[RING][8];
     float xv[RING][8];
-    // XW: a k-step's 16 activation rows are 2 KB contiguous; lane l takes bytes [16 l, 16 l + 16) of each KB (two coalesced 1 KB
-    // loads instead of eight 256-byte ones: timing ablations put 2.9 of the kernel's 36 us on those eight, profiles/r5_d0fwd_ablations.txt)
-    // and the wave turns them round through its own 2 KB of LDS into the MFMA's k-major operand
-    __shared__ __attribute__((aligned(16))) float d3_xs[XW ? 4 * 512 : 4];
-    f32x4v xq0[RING], xq1[RING];
-    const float* XQ = a.in + ((long)n * a.nb + bb) * a.F * 32 + (long)(16 * s) * 32 + 4 * lane;
-    float* const xs_w = d3_xs + (XW ? wave * 512 : 0);
 #define D3_LOAD(c, s)                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                         \
-        wv[s][jj] = ld4<WNT>(W + ((long)(c) * step_rows + jj) * a.J);                                    \
-        if (XW) { if (jj == 0) xq0[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32);          \
-                  if (jj == 1) xq1[s] = *reinterpret_cast<const f32x4v*>(XQ + (long)(c) * step_rows * 32 + 256); }  \
-        else if (!(ABL & 1)) xv[s][jj] = X[((long)(c) * step_rows + jj) * 32]; else xv[s][jj] = 1.0f;  \
+        wv[s][jj] = ld4<WNT>(W + ((long)(c) * step_rows + jj) * a.J);                           \
+        xv[s][jj] = X[((long)(c) * step_rows + jj) * 32];                                      \
     }
 #define D3_GETX(s)                                                                             \
     float xr[8];                                                                               \
-    if (XW) {                                                                                  \
-        *reinterpret_cast<f32x4v*>(xs_w + 4 * lane) = xq0[s];                                  \
-        *reinterpret_cast<f32x4v*>(xs_w + 256 + 4 * lane) = xq1[s];                            \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xr[jj] = xs_w[(8 * h + jj) * 32 + bl]; \
-    } else {                                                                                   \
-        _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xr[jj] = xv[s][jj];                   \
-    }
+    _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) xr[jj] = xv[s][jj];
 // One k-step: the three planes of the activations, then per column tile q six products.  hipcc leaves each tile's six MFMAs back
 // to back behind its 44-instruction split (rocprofv3 --pmc, profiles/r5_d0fwd_pmc_vs_reader.txt: a wave spent 33 % of its cycles
 // issuing VALU and another 32 % stalled at MFMA issue, against 9 % + 1 % for a plain reader of the same bytes in the same
@@ -473,31 +441,17 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
         D3_TILE(s, 0, pa, pb, y, true) D3_TILE(s, 1, pb, pa, z, true)                          \
         D3_TILE(s, 2, pa, pb, w, true) D3_TILE(s, 3, pb, pa, x, false)                         \
     }
-#define D3_MMA_A(s) { D3_GETX(s) _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) acc[0][0] += wv[s][jj].x + wv[s][jj].y + wv[s][jj].z + wv[s][jj].w + xr[jj]; }
 #define D3_STEP(u)                                                                             \
     D3_LOAD(min(c + (u) + RING - 1, NC - 1), ((u) + RING - 1) % RING)                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if (c + (u) < NC) { if (ABL & 4) D3_MMA_A(u) else if (PLAIN) D3_MMA_P(u) else D3_MMA(u) }  \
+    if (c + (u) < NC) { if (PLAIN) D3_MMA_P(u) else D3_MMA(u) }                                \
     __builtin_amdgcn_sched_barrier(0);
     D3_LOAD(0, 0)
     D3_LOAD(min(1, NC - 1), 1)
-    if (RING == 4) { D3_LOAD(min(2, NC - 1), 2) }
+    D3_LOAD(min(2, NC - 1), 2)
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL & 8) {  // (RING == 4) whole rings at a time: the next four k-steps are requested only when all four slots are free
-        for (int c = 0; c < NC; c += 4) {
-            if (c > 0) { D3_LOAD(min(c, NC - 1), 0) D3_LOAD(min(c + 1, NC - 1), 1) D3_LOAD(min(c + 2, NC - 1), 2) }
-            D3_LOAD(min(c + 3, NC - 1), 3)
-            __builtin_amdgcn_sched_barrier(0);
-            if (c < NC) D3_MMA_P(0)
-            if (c + 1 < NC) D3_MMA_P(1)
-            if (c + 2 < NC) D3_MMA_P(2)
-            if (c + 3 < NC) D3_MMA_P(3)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else
     for (int c = 0; c < NC; c += RING) {
-        D3_STEP(0) D3_STEP(1) D3_STEP(2)
-        if (RING == 4) { D3_STEP(3) }
+        D3_STEP(0) D3_STEP(1) D3_STEP(2) D3_STEP(3)
     }
 #undef D3_STEP
 #undef D3_LOAD
@@ -506,17 +460,9 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
 #undef D3_SB
 #undef D3_TILE_P
 #undef D3_MMA_P
-#undef D3_MMA_A
 #undef D3_GETX
 #undef D3_MMA
     float* P = a.part + ((((long)n * a.nb + bb) * a.NS + s) * a.J + jt * 128) * 32 + bl;
-    if (ABL & 2) {  // keep the accumulators alive, store one value per wave
-        float t_ = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t_ += acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r];
-        if (t_ == 123.456f) P[0] = t_;
-        return;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int i = mfma_row(r, h);
@@ -532,19 +478,19 @@ __device__ __forceinline__ void dense0_fwd3_body(const DenseFwdArgs& a) {  // PL
 // (all 158 MB default-policy: every later conv launch +0.3 ... 1 us; profiles/r5_d0_keep_online_ab.txt).  A workgroup's waves are the
 // column tiles of one (net, split): the choice is workgroup-uniform.
 __global__ __launch_bounds__(256) void k_dense0_fwd3(DenseFwdArgs a) {
-    if (a.nt_from > 0 && a.G == 1 && !a.bb_inner) {
+    if (a.nt_from > 0 && !a.bb_inner) {
         const long item = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) / ((long)a.n_jt * a.NS * a.nb);
         const int n = __builtin_amdgcn_readfirstlane(((int)item + a.net_rot) % a.n_nets);
         if (n < a.nt_from) {
-            dense0_fwd3_body<4, true, 0, false, false>(a);
+            dense0_fwd3_body<true, false>(a);
             return;
         }
     }
-    dense0_fwd3_body<4, true>(a);
+    dense0_fwd3_body<true>(a);
 }
 // several sample blocks per net: block-inner work items, default-policy W loads (the neighbours' re-reads hit on-chip)
 // -- and the threaded split: with every window of W serving several blocks the waves are bound by their own issue, not by the stream
-__global__ __launch_bounds__(256) void k_dense0_fwd3b(DenseFwdArgs a) { dense0_fwd3_body<4, false, 0, false, false>(a); }
+__global__ __launch_bounds__(256) void k_dense0_fwd3b(DenseFwdArgs a) { dense0_fwd3_body<false, false>(a); }
 
 
 // --------------------------------------------------------------------------------------------

@@ -208,7 +208,6 @@ struct NetSet {
     int n_nets = 0, nb_cap = 0, n_in_sets = 0;
     int NS = 0;  // split-K of this set's Dense_0 forward
     long part_slabs = 0;  // (block, split) slabs the partial buffer holds per net
-    int G = 1;   // splits whose accumulators a workgroup adds through LDS before writing (k_dense0_fwd3): 4 or 1
     const float** wbase = nullptr;  // dev [n_nets]
     int* in_set = nullptr;          // dev [n_nets] input set read by Conv_0
     int* ident = nullptr;           // dev [n_nets] 0..n_nets-1 (later layers read their own activations)
@@ -407,7 +406,6 @@ int d0_splits(const idqn_handle_s* h, int n_nets, int nb) {
 int netset_alloc(idqn_handle_s* h, NetSet& s, int n_nets, int nb, int n_in_sets, const char* tag, int units_per_split = 0) {
     s.n_nets = n_nets; s.nb_cap = nb; s.n_in_sets = n_in_sets;
     s.NS = h->NS;
-    s.G = 1;  // (splits per workgroup of the Dense_0 forward: groups of four measured slower, profiles/r4_d0fwd_group_fuse_ab.txt)
     if (units_per_split > 0) {  // a single acting net: more, shorter splits (each wave's MFMA chain is the latency)
         const int units = h->F / 32;
         s.NS = (units + units_per_split - 1) / units_per_split;
@@ -1482,12 +1480,12 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    if (&s == &h->train && s.G == 1 && nb > 1) s.NS = d0_splits(h, s.n_nets, nb);  // (nb == 1: the value cnn_setup chose)
-    else if (&s == &h->train && s.G == 1) s.NS = h->NS;
+    if (&s == &h->train && nb > 1) s.NS = d0_splits(h, s.n_nets, nb);  // (nb == 1: the value cnn_setup chose)
+    else if (&s == &h->train) s.NS = h->NS;
     DenseFwdArgs d;
     d.in = s.a3; d.part = s.part; d.wbase = s.wbase; d.w_off = h->off_w0;
     d.n_nets = s.n_nets; d.nb = nb; d.NS = s.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
-    d.bb_inner = (h->planes && s.G == 1 && nb > 1) ? 1 : 0;
+    d.bb_inner = (h->planes && nb > 1) ? 1 : 0;
     d.n_items = (long)s.n_nets * nb * d.NS * d.n_jt;
     d.net_rot = s.n_in_sets > 1 ? s.n_nets / 2 : 0;
     // the online nets' Dense_0 kernels (re-read by the fused update of the same step) with default-policy loads: k_dense0_fwd3
@@ -1497,13 +1495,11 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     // (the online nets' loads are default-policy for ANY number of heads: where nothing can stay on chip the fused update still runs 3-6 % faster behind
     // them -- K = 6 / 7 / 16 / 32: step -3.5 / -5 / -5 / -6 us, K = 8 / 64 the same; what depends on the size is only the store policy of theta_new)
     d.nt_from = s.n_in_sets > 1 ? (keep_target ? s.n_nets : s.n_nets / 2) : 0;
-    d.G = h->planes ? s.G : 1;
-    d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = h->off_b0; d.w1_off = h->off_w1; d.A = h->cfg.n_actions;
     // >= 8 sample blocks per net (B = 256): the tiled bf16x3 GEMM of the i-IQN heads (iqn_gemm.h: 256 x 256 tiles, operands split in
     // registers and parked in LDS as MFMA fragments) -- the same interleaved split-K and product order, so the same partials
     // layout for k_hidden; splits chosen to fill the chip.  IDQN_D0_FWD_GEMM=0: the block-inner streaming kernel (k_dense0_fwd3b).
     static const bool fwd_gemm = !(getenv("IDQN_D0_FWD_GEMM") && atoi(getenv("IDQN_D0_FWD_GEMM")) == 0);
-    if (fwd_gemm && h->planes && &s == &h->train && s.G == 1 && nb % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
+    if (fwd_gemm && h->planes && &s == &h->train && nb % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         const int per_split = s.n_nets * (nb / 8) * (h->J / 256);
         const int nsg = std::max(1, std::min(std::min(256 / std::max(1, per_split), 64), h->F / 16));
         if ((long)nb * nsg <= s.part_slabs) {
@@ -1733,7 +1729,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
     const ConvL *c0 = &h->conv[0], *c1 = &h->conv[1], *c2 = &h->conv[2];
     // head: h + Dense_1 partials for all 2K nets, then TD / loss / dL/dq / dL/dh / Dense_1 + Dense_0-bias gradients
     HiddenArgs hi;
-    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS / s.G;
+    hi.part = s.part; hi.wbase = s.wbase; hi.b0_off = h->off_b0; hi.w1_off = h->off_w1; hi.nb = nb; hi.NS = s.NS;
     hi.J = h->J; hi.A = h->cfg.n_actions; hi.hbuf = h->hbuf; hi.qpart = h->qpart;
     hipLaunchKernelGGL(k_hidden, dim3(h->J / 32, 2 * K * nb), dim3(256), 0, q, hi);
     tl_mark(h, q, "hidden");
@@ -2170,7 +2166,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.in = w.xq; d.part = w.part; d.wbase = wbase_v; d.w_off = h->off_w0;
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
-    d.net_rot = 0; d.G = 1; d.arrive = nullptr; d.hbuf = nullptr; d.qpart = nullptr; d.b0_off = 0; d.w1_off = 0; d.A = 0; d.bb_inner = 0; d.nt_from = 0;
+    d.net_rot = 0; d.bb_inner = 0; d.nt_from = 0;
     // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
     if (w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;

@@ -126,6 +126,30 @@ def test_iqn_step_is_reproducible_bit_for_bit():
         assert np.array_equal(runs[0][2][leaf], runs[1][2][leaf]), leaf
 
 
+def test_iqn_update_in_the_gradient_launch_over_several_steps():
+    """Atari shape, K = 5, N = 32: the Adam update of Dense_0/kernel rides in the weight gradient's epilogue of the merged gradient
+    launch (csrc/iqn_gemm.h, k_iqn_d0_bwd_adam) behind a gate that the data-gradient items of the same rows open and the last
+    weight-gradient item re-arms.  Several steps in a row: finite losses (a gate that gave up poisons them), and two runs from the
+    same state end with identical bits (one split: no cross-workgroup sums)."""
+    from slimdqn.networks.iiqn import iIQN
+
+    rng = np.random.default_rng(8)
+    obs, A, K, N, B = (84, 84, 4), 6, 5, 32, 32
+    s = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
+    s2 = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
+    batch = Batch(s, rng.integers(0, A, size=B).astype(np.int32), rng.standard_normal(B).astype(np.float32), s2, rng.random(B) < 0.1)
+    taus = [rng.random((K, 3, N, B)).astype(np.float32) * 0.98 + 0.01 for _ in range(4)]
+    runs = []
+    for _ in range(2):
+        agent = iIQN(5, obs, A, K, [32, 64, 64, 512], "cnn", 6.25e-5, 0.99, 1, 1, 10**9, 10**9, adam_eps=1.5e-4, n_quantiles=N)
+        losses = [agent._learn(batch, taus=t).cpu().numpy().copy() for t in taus]
+        runs.append((losses, agent._flat(agent._online)["Dense_0/kernel"], agent._flat(agent._nu)["Dense_0/kernel"]))
+    for la, lb in zip(runs[0][0], runs[1][0]):
+        assert np.isfinite(la).all() and np.array_equal(la, lb)
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert np.abs(runs[0][2]).max() > 0  # (the second moments moved: the epilogue ran)
+
+
 def test_iqn_trainer_entry_point(tmp_path):
     """experiments/atari/iiqn.py (extension): the reference's trainer loop -- collect, update_online, T-step copy / shift,
     D-step sync, logs, checkpoint -- with the quantile agent on the synthetic Atari environment."""
