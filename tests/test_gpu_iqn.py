@@ -126,15 +126,16 @@ def test_iqn_step_is_reproducible_bit_for_bit():
         assert np.array_equal(runs[0][2][leaf], runs[1][2][leaf]), leaf
 
 
-def test_iqn_update_in_the_gradient_launch_over_several_steps():
-    """Atari shape, K = 5, N = 32: the Adam update of Dense_0/kernel rides in the weight gradient's epilogue of the merged gradient
+@pytest.mark.parametrize("K,N", [(5, 32), (2, 16), (3, 64)])
+def test_iqn_update_in_the_gradient_launch_over_several_steps(K, N):
+    """Atari shape (K = 5, N = 32 is BASELINE config 3; other head / fraction counts change the item mix and the planned order): the Adam update of Dense_0/kernel rides in the weight gradient's epilogue of the merged gradient
     launch (csrc/iqn_gemm.h, k_iqn_d0_bwd_adam) behind a gate that the data-gradient items of the same rows open and the last
     weight-gradient item re-arms.  Several steps in a row: finite losses (a gate that gave up poisons them), and two runs from the
     same state end with identical bits (one split: no cross-workgroup sums)."""
     from slimdqn.networks.iiqn import iIQN
 
     rng = np.random.default_rng(8)
-    obs, A, K, N, B = (84, 84, 4), 6, 5, 32, 32
+    obs, A, B = (84, 84, 4), 6, 32
     s = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
     s2 = rng.integers(0, 256, size=(B,) + obs, dtype=np.uint8)
     batch = Batch(s, rng.integers(0, A, size=B).astype(np.int32), rng.standard_normal(B).astype(np.float32), s2, rng.random(B) < 0.1)
