@@ -1497,8 +1497,8 @@ int cnn_forward(idqn_handle_s* h, NetSet& s, const uint8_t* st, const uint8_t* s
     d.nt_from = s.n_in_sets > 1 ? (keep_target ? s.n_nets : s.n_nets / 2) : 0;
     // >= 8 sample blocks per net (B = 256): the tiled bf16x3 GEMM of the i-IQN heads (iqn_gemm.h: 256 x 256 tiles, operands split in
     // registers and parked in LDS as MFMA fragments) -- the same interleaved split-K and product order, so the same partials
-    // layout for k_hidden; splits chosen to fill the chip.  IDQN_D0_FWD_GEMM=0: the block-inner streaming kernel (k_dense0_fwd3b).
-    static const bool fwd_gemm = !(getenv("IDQN_D0_FWD_GEMM") && atoi(getenv("IDQN_D0_FWD_GEMM")) == 0);
+    // layout for k_hidden; splits chosen to fill the chip (debug build, IDQN_D0_FWD_GEMM=0: the block-inner streaming kernel k_dense0_fwd3b).
+    static const bool fwd_gemm = debug_int("IDQN_D0_FWD_GEMM", 1) != 0;
     if (fwd_gemm && h->planes && &s == &h->train && nb % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         const int per_split = s.n_nets * (nb / 8) * (h->J / 256);
         const int nsg = std::max(1, std::min(std::min(256 / std::max(1, per_split), 64), h->F / 16));
