@@ -207,20 +207,11 @@ int convp_launch_fwd(const CFwdArgs& a, int NPA, int CT, int NQ, int NT, int n_i
 int convp_fwd_ring(size_t stage_bytes, int NT, int epilogue, size_t budget);  // stage buffers: 3 when they fit the budget
 size_t convp_fwd_mask_off(size_t stage_bytes, int NT, int ring, bool planes_out, bool f32_out);
 size_t convp_fwd_lds(size_t stage_bytes, int NT, int epilogue, int ring, bool planes_out, bool f32_out);  // prof: per-workgroup phase stamps [n_items][8] (debugging) or nullptr
-struct D0Stream;  // dense0_update.h: a share of the fused Dense_0 update carried by the launch's spare workgroups (or nullptr)
-int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q,
-                       const D0Stream* ds = nullptr);
-bool convp_wgrad_stream_built(int NPX, int MT, int CT, int PG);
-struct AdamArgs;  // dense0_update.h: the small-leaf Adam update carried by the launch's spare workgroups (convp_wgrad.hip)
-bool convp_wgrad_adam_built(int NPX, int MT, int CT, int PG);
-int convp_launch_wgrad_adam(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const AdamArgs& ad,
-                            long n_threads, int n_role);
+int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q);
 // a data gradient and a weight gradient side by side in one launch (convp_pair.hip); convp_pair_built: is this pair compiled
 bool convp_pair_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
 int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_f, size_t f_stage, int ring, size_t f_lds,
-                      const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof,
-                      const D0Stream* ds = nullptr);
-bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG);
+                      const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof);
 int convp_launch_stage(const StageArgs& a, int n_blocks, hipStream_t q, const StageSlots* slots = nullptr);
 int convp_fwd_max_nt(int CT);
 // persistent form for launches with several items per CU (convp_pp.hip): n_wg workgroups walk n_items items

@@ -72,16 +72,9 @@ bool convp_pair_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WN
     return false;
 }
 
-bool convp_pair_stream_built(int NPA, int CT, int NQ, int NT, int WNPX, int WCT, int WNTW, int WPG) {  // pairs with the stream role
-    (void)NPA; (void)CT; (void)NQ; (void)NT; (void)WNPX; (void)WCT; (void)WNTW; (void)WPG;
-    return false;
-}
-
 int convp_launch_pair(const CFwdArgs& f, int NPA, int CT, int NQ, int NT, int n_f, size_t f_stage, int ring, size_t f_lds,
-                      const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof,
-                      const D0Stream* ds) {
+                      const CWgradArgs& w, int WNPX, int MT, int WCT, int n_w, size_t w_lds, hipStream_t q, long long* prof) {
     IDQN_REQUIRE(n_f + n_w <= 256, "conv pair: %d + %d workgroups do not fit one per CU", n_f, n_w);
-    IDQN_REQUIRE(!ds, "conv pair: stream roles exist in the IDQN_VARIANTS build only");
     IDQN_REQUIRE(f_lds <= 160 * 1024 && w_lds + 2048 <= 160 * 1024, "conv pair: %zu / %zu bytes of LDS per workgroup", f_lds, w_lds + 2048);
     const int ntw = (MT * WCT + 3) / 4;
     if (NPA == 3 && CT == 2 && NQ == 3 && WNPX == 3 && WCT == 2 && ntw == 3 && w.PG == 2) {

@@ -27,22 +27,9 @@ int launch_one(const CWgradArgs& a, int MT, int n_items, size_t lds_bytes, hipSt
 }  // namespace
 
 // MT = 32-row tiles on the M side of one workgroup (KW * CI / 32, Conv_0: its 8 kernel rows)
-bool convp_wgrad_stream_built(int, int, int, int) { return false; }
-bool convp_wgrad_adam_built(int, int, int, int) { return false; }
-
-int convp_launch_wgrad_adam(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const AdamArgs& ad,
-                            long n_threads, int n_role) {
-    IDQN_REQUIRE(lds_bytes + 2048 <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes + 2048);
-    IDQN_REQUIRE(n_role >= 1 && n_items + n_role <= 256, "plane wgrad: %d + %d workgroups do not fit one per CU", n_items, n_role);
-    IDQN_REQUIRE(convp_wgrad_adam_built(NPX, MT, CT, a.PG), "plane wgrad: no Adam-role kernel for this shape");
-    (void)q; (void)ad; (void)n_threads;
-    return IDQN_E_INVALID;
-}
-
-int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q, const D0Stream* ds) {
+int convp_launch_wgrad(const CWgradArgs& a, int NPX, int MT, int CT, int n_items, size_t lds_bytes, hipStream_t q) {
     IDQN_REQUIRE(lds_bytes + 2048 <= 160 * 1024, "plane wgrad: %zu bytes of LDS per workgroup", lds_bytes + 2048);
     const int ntw = (MT * CT + 3) / 4;
-    IDQN_REQUIRE(!ds, "plane wgrad: stream roles exist in the IDQN_VARIANTS build only");
     if (NPX == 1) {
         if (CT == 1 && ntw == 2 && a.PG == 4) return launch_one<1, 1, 2, 4>(a, MT, n_items, lds_bytes, q);
         if (CT == 2 && ntw == 4 && a.PG == 2) return launch_one<1, 2, 4, 2>(a, MT, n_items, lds_bytes, q);

@@ -1,7 +1,5 @@
-// Dense_0 weight gradient + fused Adam (+ fused data gradient): the workgroup body, shared by the stand-alone kernel
-// (cnn_kernels.h, k_dense0_wgrad) and by the STREAM ROLE of the plane conv launches (d0_stream_role below): the conv
-// launches of the step are bound by fixed costs and their matrix loops, this update by HBM, so a conv launch planned for
-// fewer CUs carries a share of the update on the CUs it leaves free (qnet.hip, overlap modes).
+// Dense_0 weight gradient + fused Adam (+ fused data gradient): the workgroup bodies of k_dense0_wgrad / k_dense0_wgrad_pair /
+// k_dense0_wgrad_alds (cnn_kernels.h).
 // Reference: optax.adam on Dense_0/kernel inside iDQN.learn_on_batch (slimdqn/networks/idqn.py:105-107).
 #pragma once
 #include <type_traits>
@@ -161,7 +159,6 @@ struct DenseWgradArgs {
     int K, nb, nb_inner, n_ft, n_jt, F, J;
     int keep_heads;  // host side only: heads [0, keep_heads) are launched with the kernel that stores theta_new with the default cache policy
     int item0;     // stand-alone kernel: workgroup b takes item b + item0 (the tail of an update that conv launches began)
-    int upd_end;   // FUSE_DG: items >= upd_end only emit their data-gradient share (update deferred to a stream role); -1: none
     // NQ = 4 (full 512-column rows) with FUSE_DG: the workgroup finishes dL/da3 itself -- what k_da3_finalize does otherwise
     unsigned short* da3p;  // bf16 planes (convp.h layout, geometry g) or nullptr
     float* da3f;           // f32 rows [K][nb][g.block] (f32 conv path) or nullptr
@@ -218,10 +215,6 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
     static_assert(!ALDS || (BF3 && NQ == 2), "a3 fragments through LDS: the 32 x 256 / 64 x 256 bf16-plane update");
     constexpr bool ROWS = FUSE_DG && NQ == 4;  // whole rows: the data gradient is complete here
     const int lane = t & 63, wave = t >> 6, bl = lane & 31, h = lane >> 5;
-    // FUSE_DG with upd_end >= 0: items from upd_end on are DEFERRED -- their update runs later, in the stream role of a conv
-    // launch; here such a workgroup only produces its share of the data gradient (theta rows -> LDS -> phase 3), because
-    // the conv backward needs dL/da3 of every row before it can start.  Workgroup-uniform.
-    const bool upd = !FUSE_DG || a.upd_end < 0 || item < a.upd_end;
 #if D0W_JT_SLOW  // locality experiment: the two column tiles of a row range far apart in dispatch order (jt slowest)
     const int ft = item % a.n_ft;
     item /= a.n_ft;
@@ -265,7 +258,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
 #endif                 // operands then does not include the twelve HBM loads of the prefetch)
     constexpr bool PRE_OPS = D0W_PRE_OPS && FUSE_ADAM && !BF3 && !ALDS && NQ <= 2;  // (the full-row kernel has no registers for it)
     constexpr bool PRE_EARLY = (!ALDS || D0W_ALDS_PRE) && !PRE_OPS;
-    if (FUSE_ADAM && upd && PRE_EARLY) prefetch();
+    if (FUSE_ADAM && PRE_EARLY) prefetch();
     f32x16 acc[NQW];
 #pragma unroll
     for (int q = 0; q < NQW; ++q)
@@ -366,7 +359,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
         if (!PRE_EARLY) prefetch();
         __syncthreads();  // the gradient tile is parked over the fragments
     } else
-    for (int bb = 0; bb < (upd ? a.nb : 0); ++bb) {
+    for (int bb = 0; bb < a.nb; ++bb) {
         if (BF3) {
             // lane (bl, h): MFMA step s, element i = sample 16 h + 8 s + i for both operands; six products, smallest first
             const long slot = (long)bb * a.K + k, pa = (long)a.nb * a.K * a.F * 32, pd = (long)a.nb * a.K * a.J * 32;
@@ -450,18 +443,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             for (int u = 0; u < 8; ++u) dv[c][u] = Dp[(long)(16 * c + 2 * u) * 32];
     };
     if constexpr (PF3 > 0) load_dv(0, std::integral_constant<int, 0>{}, std::integral_constant<int, PF3>{});
-    if (FUSE_DG && !upd) {  // deferred item: the pre-update theta tile goes to LDS as phase 2 would leave it, nothing is stored
-#pragma unroll
-        for (int i0 = 0; i0 < NIT; i0 += 8) {
-            float4 tt[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + u < NIT) tt[u] = ld4<(D0_WG_NT & 1) != 0>(a.theta + o0 + (long)(RPI * (i0 + u)) * a.J);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + u < NIT) *reinterpret_cast<float4*>(&gs[rot(RPI * (i0 + u) + prow, pcol)]) = tt[u];
-        }
-    } else if (FUSE_ADAM) {
+    if (FUSE_ADAM) {
         const float bc1 = a.bcinv[2 * k], bc2 = a.bcinv[2 * k + 1];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -508,7 +490,7 @@ __device__ __forceinline__ void dense0_wgrad_body(const DenseWgradArgs& a, int i
             [[maybe_unused]] const int bo = bb / a.nb_inner, bi = bb - bo * a.nb_inner;
             if constexpr (PF3 > 0) {
                 if (bb > 0) load_dv(bb, std::integral_constant<int, 0>{}, std::integral_constant<int, NCH3>{});
-                else if (!(D0W_PF3_MID && upd && NCH3 - PF3 <= 2)) load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
+                else if (!(D0W_PF3_MID && NCH3 - PF3 <= 2)) load_dv(0, std::integral_constant<int, PF3>{}, std::integral_constant<int, NCH3>{});
             }
             f32x16 d;
 #pragma unroll
@@ -779,23 +761,4 @@ __device__ __forceinline__ void dense0_pair_body(const DenseWgradArgs& a, int it
     }
 }
 
-// ---- stream role ---------------------------------------------------------------------------------------------------
-// A plane conv launch planned for fewer than 256 workgroups carries `n_sb` extra 512-thread workgroups (one per CU the
-// conv roles leave free) that run the fused update: each workgroup is two independent 256-thread halves, a half takes
-// item  item0 + (round * n_sb + sb) * 2 + half  per round (the two halves hold the two column tiles of the same 32 rows, so
-// the a3 rows they contract are fetched once per CU).  The host hands out whole rounds only: every half runs the same
-// number of items and of barriers.  Measured (tools/probes/overlap_cumask.py): from a subset of the CUs the update
-// streams at ~30 GB/s per CU (2.1 / 2.9 / 3.7 TB/s from 64 / 96 / 128 CUs), the whole chip at 5.5 TB/s.
-struct D0Stream {
-    DenseWgradArgs w;
-    int item0, rounds, n_sb;
-};
-__device__ __forceinline__ void d0_stream_role(const D0Stream& s, const int sb, float* lds /* >= 64 KB */) {
-    const int half = (int)threadIdx.x >> 8, t = (int)threadIdx.x & 255;
-    float* gs = lds + half * (32 * 256);
-    for (int r = 0; r < s.rounds; ++r) {
-        dense0_wgrad_body<true, 2, false, false>(s.w, s.item0 + (r * s.n_sb + sb) * 2 + half, gs, t);
-        __syncthreads();  // the tile is rewritten by the next round
-    }
-}
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(FCM_T) void k_fc_step_par(FcArgs a, FcParPlan p, Ad
     float* TH = theta + (long)k * P;
     float* MU = mu + (long)k * P;
     float* NU = nu + (long)k * P;
-    // debugging (IDQN_FC_PROF, variants build): shader-clock stamps of thread 0 at the phase boundaries -> a.ws
+    // debugging (IDQN_FC_PROF, debug build): shader-clock stamps of thread 0 at the phase boundaries -> a.ws
 #define FCP_STAMP(i) if (prof && t == 0) reinterpret_cast<long long*>(a.ws)[k * 16 + (i)] = clock64();
     FCP_STAMP(0)
     // ---- everything the step reads from global memory is requested HERE, before anything waits, in 16-byte pieces

@@ -6,14 +6,14 @@
 // Mapping onto the existing step: a (sample, quantile fraction) pair is one more "sample"; quantile index q of all 32
 // samples of the batch is one more 32-sample BLOCK, so the layouts of the plain step carry over to V = 3K "virtual nets"
 // (online k | target k for the action choice | target k for the values) x N blocks each:
-//   x[v][q][f][b] = psi[net(v)][f][b] * relu(sum_i cos(pi i tau[v][q][b]) * We[i][f] + be[f])   (k_iqn_cos, k_iqn_we_pack, k_iqn_embed3)
+//   x[v][q][f][b] = psi[net(v)][f][b] * relu(sum_i cos(pi i tau[v][q][b]) * We[i][f] + be[f])   (k_iqn_cos, k_iqn_we_pack, k_iqn_embed3l)
 //   Dense_0 over the (V, N) blocks: the tiled GEMM k_iqn_d0_fwd (iqn_gemm.h; fewer than 8 blocks: k_dense0_fwd3), k_hidden
 //   k_iqn_z, k_iqn_loss   Z, a*, targets, the N' x N quantile Huber loss and dL/dZ                (one workgroup per head)
 //   k_iqn_dh              dL/dh per block, Dense_1 / Dense_0-bias gradients (fraction groups, k_iqn_head_grad_sum)
-//   k_iqn_d0_bwd          W0 . dh (plain rows) and the Dense_0 weight gradient as GEMMs in one launch, k_iqn_d0_adam
+//   k_iqn_d0_bwd_adam     W0 . dh (plain rows) and the Dense_0 weight gradient as GEMMs in one launch, Adam of Dense_0/kernel in the
+//                         weight gradient's epilogue (few items: k_iqn_d0_bwd with two block splits + k_iqn_d0_adam)
 //   k_iqn_embed_bwd3      dL/dpsi (summed over the N fractions) and the embedding's gradients (k_iqn_embed_grad_sum)
-// then the plain step's conv backward and small-leaf Adam.  The f32-MFMA / per-block versions of these kernels stay as the
-// paths for small N and behind IDQN_IQN_GEMM=0 / IDQN_IQN_EMBED3=0 (tests/test_gpu_switches.py runs both).
+// then the plain step's conv backward and small-leaf Adam.  N not a multiple of 8 / 16: the plain step's per-block Dense_0 kernels.
 #pragma once
 #include "cnn_kernels.h"
 #include "iqn_gemm.h"

@@ -340,11 +340,6 @@ struct idqn_handle_s {
     uint8_t* rp_terminal = nullptr;
     const float* is_weight = nullptr;  // prioritized-replay extension (idqn_set_per_buffers)
     float* td_abs = nullptr;
-    // Overlap of the fused Dense_0 update with the conv backward (cnn_backward): the last n_def update items are deferred
-    // to the stream roles of the Conv_2 pair launch (S2 workgroups x r2 rounds) and of the Conv_0 weight-gradient launch
-    // (S0 x r0); `left` counts the deferred items no launch has taken yet (a stand-alone launch finishes them).
-    struct Overlap { int n_def = 0, S2 = 0, r2 = 0, S0 = 0, r0 = 0, next = 0, left = 0; DenseWgradArgs dw; } ov;
-    long adam_done_from = 0;  // > 0: the last backward's Conv_0 weight-gradient launch already updated the leaves from this element on
     bool d0_rows = false;  // the last fused Dense_0 launch (pairs of column tiles) finished dL/da3 itself
     bool wt_ready = false;  // the data-gradient kernels of this step are built (k_td_dh_wt)
     bool pend_profile = false;
@@ -1081,7 +1076,7 @@ int plan_fwd(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, 
 // output row of every variant is cut into `parts` column ranges (items never cross rows: one strip per stage), as few as
 // the tile count per wave (<= convp_pp_max_nt) and the LDS (ring x stage + the epilogue slots <= 160 KB) allow.  Candidates
 // are ranked by a per-item cost model -- supersteps x max(matrix cycles + ramp, staged bytes / fill rate), the rates read
-// off profiles/r6_cprof_b256.txt -- summed over the items and divided over the CUs; IDQN_PP_PARTS<role> (variants build)
+// off profiles/r6_cprof_b256.txt -- summed over the items and divided over the CUs; IDQN_PP_PARTS<role> (debug build)
 // overrides the choice for sweeps.  Returns IDQN_E_INVALID when no candidate fits (the caller keeps the one-item launch).
 int plan_fwd_pp(idqn_handle_s* h, int role, int n_nets, int nb, const RoleGeom& g, FwdPlan** out) {
     auto key = std::make_tuple(role + 16, n_nets, nb, 0);
@@ -1356,43 +1351,21 @@ int wgrad_args(idqn_handle_s* h, int layer, int nb, int n_chunks, CWgradArgs& a,
     return IDQN_OK;
 }
 
-// takes up to `rounds` rounds of S workgroups (two items each) of the deferred Dense_0 update for a conv launch's stream role
-bool overlap_take(idqn_handle_s* h, int S, int rounds, D0Stream& ds) {
-    auto& ov = h->ov;
-    if (S <= 0 || rounds <= 0 || ov.left < 2 * S) return false;
-    const int r = std::min(rounds, ov.left / (2 * S));
-    ds.w = ov.dw; ds.item0 = ov.next; ds.rounds = r; ds.n_sb = S;
-    ov.next += 2 * S * r;
-    ov.left -= 2 * S * r;
-    return true;
-}
-
-// spare != nullptr: plan only -- *spare = workgroups this launch would leave to a stream role (0: it cannot carry one)
-int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q, int budget = 0, int stream_rounds = 0, int* spare = nullptr) {
+int planes_wgrad(idqn_handle_s* h, int layer, int nb, hipStream_t q) {
     CWgradArgs a;
     WgradPlan* pl;
-    const int per_chunk = h->cfg.n_heads * (layer == 0 ? 1 : h->conv[layer].K);
-    int rc = wgrad_args(h, layer, nb, budget > 0 ? std::max(1, budget / per_chunk) : 0, a, pl);
+    int rc = wgrad_args(h, layer, nb, 0, a, pl);
     if (rc) return rc;
     const int NPX = layer == 0 ? 1 : 3, CT = h->conv[layer].CO / 32;
-    if (spare) {
-        *spare = convp_wgrad_stream_built(NPX, pl->MT, CT, pl->PG) ? std::max(0, 256 - pl->n_items) : 0;
-        return IDQN_OK;
-    }
     h->npc_used[layer] = pl->n_chunks;
-    D0Stream ds;
-    if (stream_rounds > 0 && convp_wgrad_stream_built(NPX, pl->MT, CT, pl->PG) && overlap_take(h, 256 - pl->n_items, stream_rounds, ds))
-        return convp_launch_wgrad(a, NPX, pl->MT, CT, pl->n_items, pl->lds, q, &ds);
     return convp_launch_wgrad(a, NPX, pl->MT, CT, pl->n_items, pl->lds, q);
 }
 
 // Data gradient of conv `layer` and weight gradient of the same layer in ONE launch (convp_pair.hip) when that pair of
 // kernels is built for the plans; *done = false: nothing was launched, the caller runs them one after the other.
-int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, int budget = 0, int stream_rounds = 0,
-                int* spare = nullptr) {
+int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done) {
     *done = false;
-    if (spare) *spare = 0;
-    const int cus = budget > 0 ? budget : cu_budget();
+    const int cus = cu_budget();
     if (layer < 1 || layer > 2) return IDQN_OK;
     // experiment knobs: IDQN_PAIR_D<layer> = workgroups planned for the data gradient, IDQN_PAIR_C<layer> = position chunks
     // of the weight gradient (default: what the data gradient leaves of the 256 CUs)
@@ -1418,18 +1391,8 @@ int planes_pair(idqn_handle_s* h, int layer, int nb, hipStream_t q, bool* done, 
     if ((rc = wgrad_args(h, layer, nb, n_chunks, w, pw))) return rc;
     const int WCT = l.CO / 32, ntw = (pw->MT * WCT + 3) / 4;
     if (pf->n_items + pw->n_items > cus || !convp_pair_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG)) return IDQN_OK;
-    if (spare) {  // plan only
-        if (pw->n_items >= 8 && convp_pair_stream_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG))
-            *spare = std::max(0, 256 - pf->n_items - pw->n_items);
-        return IDQN_OK;
-    }
     h->npc_used[layer] = pw->n_chunks;
     *done = true;
-    D0Stream ds;
-    if (stream_rounds > 0 && pw->n_items >= 8 && convp_pair_stream_built(g.NPA, g.CT, g.NQ, pf->NT, 3, WCT, ntw, pw->PG) &&
-        overlap_take(h, 256 - pf->n_items - pw->n_items, stream_rounds, ds))
-        return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT,
-                                 pw->n_items, pw->lds, q, conv_prof(h, s, role, pf), &ds);
     return convp_launch_pair(f, g.NPA, g.CT, g.NQ, pf->NT, pf->n_items, pf->stage, pf->ring, pf->lds, w, 3, pw->MT, WCT, pw->n_items,
                              pw->lds, q, conv_prof(h, s, role, pf));
 }
@@ -1603,7 +1566,7 @@ int make_dgrad_args(idqn_handle_s* h, int i, int nb, ConvFwdArgs& a) {
     return IDQN_OK;
 }
 
-int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bool adam_role = false);
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q);
 
 // Dense_0 weight gradient (+ fused Adam) over nb_total sample blocks addressed through (outer, head, inner) strides
 int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int nb_total, int nb_inner, long a3_outer,
@@ -1642,15 +1605,10 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     h->d0_rows = false;
     const int nq = (h->J % 256 == 0) ? 2 : 1;  // 256- or 128-wide column tiles
     dw.K = K; dw.nb = nb_total; dw.nb_inner = nb_inner; dw.n_ft = h->F / 32; dw.n_jt = h->J / (128 * nq);
-    dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.upd_end = -1; dw.keep_heads = d0_keep_heads(h);
+    dw.F = h->F; dw.J = h->J; dw.item0 = 0; dw.keep_heads = d0_keep_heads(h);
     dw.da3p = nullptr; dw.da3f = nullptr; dw.pb = nullptr; dw.C = 0; memset(&dw.g, 0, sizeof(dw.g));
 
     dw.n_items = (long)K * dw.n_ft * dw.n_jt;  // workgroups
-    if (fuse_dg && h->ov.n_def > 0) {
-        dw.upd_end = h->ov.next;  // first deferred item
-        h->ov.dw = dw;
-        h->ov.dw.upd_end = -1; h->ov.dw.dpart = nullptr;
-    }
     const dim3 wgrid((unsigned)dw.n_items);
     // profiling: the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so the
     // elapsed time is the kernel's, without the gaps that separate marker packets from their neighbours
@@ -1671,7 +1629,7 @@ int launch_dense0_wgrad(idqn_handle_s* h, const float* a3, const float* dh, int 
     // Measured on three boxes against two workgroups + finalize (profiles/r4_d0_pair_ab.txt): step -0.7 / -3 / -5 us; the kernel
     // itself takes 2 - 5 us more than the tile kernel (a row's two 1 KB halves are streamed 12 us apart instead of side by side by
     // sibling workgroups), the finalize launch it replaces took 5.3 us + a boundary.
-    const bool pair = fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512 && h->ov.n_def == 0 && dw.upd_end < 0;
+    const bool pair = fuse_adam && nq == 2 && fuse_dg && nb_total == 1 && h->J == 512;
     if (pair) {
         // one workgroup per PAIR of column tiles; the launch finishes dL/da3 itself
         dw.da3p = h->da3p; dw.da3f = h->da3; dw.pb = h->pbuf[2]; dw.g = h->gda3; dw.C = h->conv[2].CO;
@@ -1812,7 +1770,6 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         return IDQN_OK;
     }
     // Dense_0 weight gradient (+ Adam): the dominant, HBM-bound kernel
-    h->ov.n_def = h->ov.left = 0;
     int rcw = launch_dense0_wgrad(h, s.a3, dh_of(h, nb), nb, nb, 0, (long)nb * h->F * 32, (long)h->F * 32, 0,
                                   (long)nb * h->J * 32, (long)h->J * 32, fuse_adam, profile, q, fuse_dg);
     if (rcw) return rcw;
@@ -1828,7 +1785,7 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IDQN_HIP_CHECK(hipGetLastError());
         return IDQN_OK;
     }
-    return cnn_backward_rest(h, B, fuse_adam, q, fuse_adam);
+    return cnn_backward_rest(h, B, fuse_adam, q);
 }
 
 // the slab descriptor of conv layer i (position chunks = what its weight-gradient launch of THIS step wrote)
@@ -1849,15 +1806,8 @@ void fill_adam_args(idqn_handle_s* h, long begin, long end, long skip_b, long sk
     if (skip_b == skip_e) a.skip_begin = a.skip_end = end;  // nothing skipped
 }
 
-// adam_role (the plain fused step only, opt-in: IDQN_ADAM_ROLE=1): the Conv_0 weight-gradient launch, planned for ~160
-// workgroups, carries the Adam update of every small leaf but Conv_0's on the CUs it leaves free (convp_wgrad.hip,
-// k_cwgrad_a) -- two independent roles in one launch; the Adam launch behind it is then left with Conv_0's kernel and bias.
-// Measured SLOWER (profiles/r4_adam_role_ab.txt: step 0.2811-0.2857 -> 0.2884-0.2891 ms): 96 role workgroups walk the 366 k
-// elements in 7-8 dependent passes (25 us for the launch against 14 for the weight gradient alone) where the stand-alone
-// launch spreads them over 1600 workgroups at once; the Adam launch left behind still costs most of what the full one did.
-int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bool adam_role) {
+int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q) {
     const int K = h->cfg.n_heads, nb = cdiv(B, 32);
-    h->adam_done_from = 0;
     NetSet& s = h->train;
     const ConvL* cl[3] = {&h->conv[0], &h->conv[1], &h->conv[2]};
     SlabReduceArgs r;
@@ -1873,25 +1823,15 @@ int cnn_backward_rest(idqn_handle_s* h, int B, bool fuse_adam, hipStream_t q, bo
         int rc = IDQN_OK;
         for (int i = 2; i >= 0 && !rc; --i) {
             bool paired = false;
-            const bool ovl = h->ov.left > 0;  // deferred Dense_0 update items wait for a stream role
-            if (i == 2) rc = planes_pair(h, i, nb, q, &paired, ovl && h->ov.r2 ? 256 - h->ov.S2 : 0, ovl ? h->ov.r2 : 0);
-            else if (i == 1) rc = planes_pair(h, i, nb, q, &paired);
+            if (i >= 1) rc = planes_pair(h, i, nb, q, &paired);
             if (paired) { tl_mark(h, q, np[i]); continue; }
             if (i >= 1 && !rc) { rc = planes_conv(h, s, i == 2 ? 3 : 4, nb, q); tl_mark(h, q, nd[i]); }
             if (!rc) {
-                if (i == 0 && ovl && h->ov.r0) rc = planes_wgrad(h, i, nb, q, 256 - h->ov.S0, h->ov.r0);
-                else rc = planes_wgrad(h, i, nb, q);
+                rc = planes_wgrad(h, i, nb, q);
                 tl_mark(h, q, nw[i]);
             }
         }
         if (rc) return rc;
-        if (h->ov.left > 0) {  // whatever no stream role took (a pair that is not built, an odd remainder): finish it here
-            DenseWgradArgs dw = h->ov.dw;
-            dw.item0 = h->ov.next;
-            hipLaunchKernelGGL((k_dense0_wgrad<true, 2>), dim3((unsigned)h->ov.left), dim3(256), 0, q, dw);
-            tl_mark(h, q, "dense0 wgrad + adam (deferred rest)");
-            h->ov.left = 0;
-        }
     } else {
         // data gradients as forward convolutions over the zero-bordered dout buffers with transformed weights
         int rcb = build_dgrad_weights(h, q);
@@ -2055,9 +1995,7 @@ extern "C" int idqn_learn_on_batch(idqn_handle_t h, const void* state_dev, const
             if (!grads_only) {
                 // every leaf except Dense_0/kernel (already updated by the fused weight-gradient kernel)
                 const long w0_b = h->off_w0, w0_e = h->off_b0;
-                if (h->adam_done_from > 0) {  // the Conv_0 weight-gradient launch carried the other leaves: Conv_0's are left
-                    if ((r = launch_adam(h, 0, h->adam_done_from, 0, 0, true, qs))) return r;
-                } else if ((r = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, qs))) return r;
+                if ((r = launch_adam(h, 0, h->L.head_stride, w0_b, w0_e, true, qs))) return r;
             }
             return IDQN_OK;
         };
@@ -2167,7 +2105,7 @@ int iqn_heads_forward(idqn_handle_s* h, const float* const* wbase_v, int V, int 
     d.n_nets = V; d.nb = w.N; d.NS = w.NS; d.n_jt = h->J / 128; d.F = h->F; d.J = h->J;
     d.n_items = (long)V * w.N * d.NS * d.n_jt;
     d.net_rot = 0; d.bb_inner = 0; d.nt_from = 0;
-    // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; IDQN_IQN_GEMM=0: the per-block streaming kernel of the plain step)
+    // >= 8 fraction blocks per net: the tiled GEMM (iqn_gemm.h; fewer, or a count that is no multiple of 8: the per-block streaming kernel of the plain step)
     if (w.N % 8 == 0 && h->J % 256 == 0 && h->F % 16 == 0) {
         IqnD0FwdArgs g;
         g.x = w.xq; g.wbase = wbase_v; g.part = w.part; g.w_off = h->off_w0;
