@@ -235,11 +235,14 @@ struct IqnD0Gate {
     long long* prof;    // debug build (IDQN_CONV_PROF=11): per workgroup {start, products done, wait done, end, item, -, -, -} (100 MHz clock)
 };
 
-template <int D>
+// RT = row tiles per wave: a workgroup takes 64 RT rows of W (4: 256 rows, the GEMM tile of the other kernels; 3 / 2: more, shorter
+// items -- the host picks what fills the chip, e.g. 205 items instead of 155 on 256 CUs for K = 5 heads x 8 blocks: qnet.hip)
+template <int D, int RT = 4>
 __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int item, unsigned char* ig_lds, unsigned* arrive = nullptr) {
+    constexpr int ROWS = 64 * RT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), bl = lane & 31, h = lane >> 5;
-    // item = (net, 256-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
-    const int nbg = a.nb / 8, nfg = (a.F + 255) / 256;
+    // item = (net, ROWS-row f group, group of 8 blocks), blocks fastest: the workgroups that share a W row group are neighbours
+    const int nbg = a.nb / 8, nfg = (a.F + ROWS - 1) / ROWS;
     const int bg = item % nbg;
     item /= nbg;
     const int fg = item % nfg;
@@ -247,14 +250,14 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
     const int NC = a.J / 16;
     // producer role: W tile `wave` = rows f = 256 fg + 32 wave + bl (clamped past F: computed, not stored), lane (bl, h)
     // holds columns 16 c + 8 h .. + 7; dh tile `wave` = block 8 bg + wave, rows j = 16 c + 8 h + jj, sample bl
-    const int frow = min(fg * 256 + wave * 32 + bl, a.F - 1);
+    const int frow = min(fg * ROWS + min(wave, 2 * RT - 1) * 32 + bl, a.F - 1);  // (RT < 4: waves 2 RT .. 7 re-park the last tile, nobody reads theirs)
     const float* Wp = a.wbase[k] + a.w_off + (long)frow * a.J + 8 * h;
     const float* Dp = a.dh + ((long)k * a.nb + bg * 8 + wave) * a.J * 32 + (long)(8 * h) * 32 + bl;
-    // consumer role: W tiles 4 wn .. 4 wn + 3 against blocks 2 wm, 2 wm + 1
+    // consumer role: W tiles RT wn .. RT wn + RT - 1 against blocks 2 wm, 2 wm + 1
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[4][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -272,7 +275,7 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
     constexpr int U = (D % 2 == 0) ? D : 2 * D;
     unsigned char* const my_w = ig_lds + wave * IG_TILE + lane * 16;
     unsigned char* const my_x = ig_lds + (8 + wave) * IG_TILE + lane * 16;
-    const unsigned char* const rd_w = ig_lds + (4 * wn) * IG_TILE + lane * 16;
+    const unsigned char* const rd_w = ig_lds + (RT * wn) * IG_TILE + lane * 16;
     const unsigned char* const rd_x = ig_lds + (8 + 2 * wm) * IG_TILE + lane * 16;
     ig_park(wr[0], my_w);
     ig_park(xr[0], my_x);
@@ -294,31 +297,35 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[0][p] = *LDS_PTR(const bf16x8, rd_w + stg + p * 1024);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < 3) {
+                for (int i = 0; i < 4; ++i) {  // (four rounds of operand staging for the next k-step; products in the first RT of them)
+                    if (i + 1 < RT) {
 #pragma unroll
                         for (int p = 0; p < 3; ++p) wf[(i + 1) & 1][p] = *LDS_PTR(const bf16x8, rd_w + stg + (i + 1) * IG_TILE + p * 1024);
                     }
                     const bf16x8 w0 = wf[i & 1][0], w1 = wf[i & 1][1], w2 = wf[i & 1][2];
                     __builtin_amdgcn_sched_barrier(0);
+                    if (i < RT) {
                     acc[i][0] = mfma_bf16(xf[0][2], w0, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][2], w0, acc[i][1]);
                     acc[i][0] = mfma_bf16(xf[0][0], w2, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][0], w2, acc[i][1]);
                     acc[i][0] = mfma_bf16(xf[0][1], w1, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][1], w1, acc[i][1]);
+                    }
                     {
                         const int m = (2 * i) & 3;
                         if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
                         else split3_pk(xr[nslot][2 * m], xr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (i < RT) {
                     acc[i][0] = mfma_bf16(xf[0][1], w0, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][1], w0, acc[i][1]);
                     acc[i][0] = mfma_bf16(xf[0][0], w1, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][0], w1, acc[i][1]);
                     acc[i][0] = mfma_bf16(xf[0][0], w0, acc[i][0]);
                     acc[i][1] = mfma_bf16(xf[1][0], w0, acc[i][1]);
+                    }
                     {
                         const int m = (2 * i + 1) & 3;
                         if (i < 2) split3_pk(wr[nslot][2 * m], wr[nslot][2 * m + 1], p0[m], p1[m], p2[m]);
@@ -336,10 +343,10 @@ __device__ __forceinline__ void iqn_d0_dgrad_body(const IqnD0DgradArgs& a, int i
             }
         }
     }
-    // this lane of tile (i, j): row f = 256 fg + 32 (4 wn + i) + bl, samples (r & 3) + 8 (r >> 2) + 4 h of block 8 bg + 2 wm + j
+    // this lane of tile (i, j): row f = ROWS fg + 32 (RT wn + i) + bl, samples (r & 3) + 8 (r >> 2) + 4 h of block 8 bg + 2 wm + j
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = fg * 256 + (4 * wn + i) * 32 + bl;
+    for (int i = 0; i < RT; ++i) {
+        const int f = fg * ROWS + (RT * wn + i) * 32 + bl;
         if (f >= a.F) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -376,10 +383,10 @@ struct IqnD0WgradArgs {
     const char* dump;  // >= 2 KB + 12 rows of J floats: what the epilogue of a tile past row F reads and writes
 };
 
-template <int D>
+template <int D, int RT = 4>
 __global__ __launch_bounds__(512) void k_iqn_d0_dgrad(IqnD0DgradArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ig_lds[];
-    iqn_d0_dgrad_body<D>(a, xcd_contiguous_id(), ig_lds);
+    iqn_d0_dgrad_body<D, RT>(a, xcd_contiguous_id(), ig_lds);
 }
 
 

@@ -1733,13 +1733,30 @@ int cnn_backward(idqn_handle_s* h, const int32_t* action, const float* reward, c
         IqnD0DgradArgs g;
         g.dh = dh_of(h, nb); g.wbase = s.wbase; g.dx = h->dpart; g.w_off = h->off_w0; g.K = K; g.nb = nb; g.F = h->F; g.J = h->J;
         const size_t lds = 2 * (size_t)IG_STAGE;
-        const unsigned grid = (unsigned)(K * (nb / 8) * cdiv(h->F, 256));
+        // rows of W per workgroup (64 x row tiles per wave): what fills the chip -- rounds of items x length of an item (K = 5, 8 blocks:
+        // 205 items of 192 rows in one round instead of 155 of 256)
+        int rt = 4;
+        {
+            long best = 0;
+            for (int c = 4; c >= 2; --c) {
+                const long cost = (long)cdiv((long)K * (nb / 8) * cdiv(h->F, 64 * c), cu_budget()) * c;
+                if (c == 4 || cost < best) { best = cost; rt = c; }
+            }
+            if (debug_int("IDQN_DGRAD_RT", 0) >= 2 && debug_int("IDQN_DGRAD_RT", 0) <= 4) rt = debug_int("IDQN_DGRAD_RT", 0);
+        }
+        const unsigned grid = (unsigned)(K * (nb / 8) * cdiv(h->F, 64 * rt));
         // (mask, planes and per-position sums in the GEMM's epilogue instead of the finalize launch: bit-identical, 110.3 us against
         // 84.3 + 25.6 -- the epilogue's plane stores are 8-byte pieces a row apart)
         {
             static LdsAttrMark attr;
-            if (attr.needs(lds)) IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_iqn_d0_dgrad<2>, dim3(grid), dim3(512), lds, q, g);
+            if (attr.needs(lds)) {
+                IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                IDQN_HIP_CHECK(hipFuncSetAttribute((const void*)k_iqn_d0_dgrad<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (rt == 4) hipLaunchKernelGGL((k_iqn_d0_dgrad<2, 4>), dim3(grid), dim3(512), lds, q, g);
+            else if (rt == 3) hipLaunchKernelGGL((k_iqn_d0_dgrad<2, 3>), dim3(grid), dim3(512), lds, q, g);
+            else hipLaunchKernelGGL((k_iqn_d0_dgrad<2, 2>), dim3(grid), dim3(512), lds, q, g);
             tl_mark(h, q, "dense0 dgrad (tiled GEMM)");
             Da3FinalizeArgs fa;
             fa.dpart = h->dpart; fa.a3 = s.a3; fa.da3 = h->da3; fa.da3p = h->da3p; fa.pb = h->pbuf[2];
